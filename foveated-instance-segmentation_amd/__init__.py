@@ -1,0 +1,9 @@
+"""fovealseg -- MI355X-native FovealSeg forward/backward hot path.
+
+Host side mirrors the reference plugin surface (`ModelBuilder`, `DeformSegmentationModule`;
+/root/reference/models/models.py:476-1230); every op below that surface is a hand-written HIP
+kernel for gfx950 reached through the C-ABI library declared in include/fovealseg.h.
+"""
+from . import config, weights  # noqa: F401
+
+__all__ = ["config", "weights"]
