@@ -1,0 +1,85 @@
+// Shared device helpers for the fovealseg HIP kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FS_OK 0
+#define FS_ERR_ARG 1001   // bad shape / null pointer at the C-ABI boundary
+
+#define FS_LAUNCH_CHECK()                                   \
+  do {                                                      \
+    hipError_t _e = hipGetLastError();                      \
+    if (_e != hipSuccess) return (int)_e;                   \
+  } while (0)
+
+#define FS_REQUIRE(cond)          \
+  do {                            \
+    if (!(cond)) return FS_ERR_ARG; \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// activation codes shared with the host side
+enum { FS_ACT_NONE = 0, FS_ACT_RELU = 1, FS_ACT_RELU6 = 2 };
+
+// Dropout keep decision for linear element index e (NHWC order) -- integer hash, restated in
+// numpy by oracle/fovealseg_oracle.py:dropout_keep_mask_nhwc for replay tests.
+__device__ __forceinline__ bool fs_dropout_keep(uint32_t e, uint32_t key, uint32_t thresh) {
+  uint32_t h = e * 0x9E3779B1u + key;
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h >= thresh;
+}
+
+__device__ __forceinline__ float fs_act(float v, int act) {
+  if (act == FS_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == FS_ACT_RELU6) return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
+  return v;
+}
+// derivative mask from the activation OUTPUT z (ReLU: z>0; ReLU6: 0<z<6, as torch's hardtanh bwd)
+__device__ __forceinline__ float fs_act_mask(float z, int act) {
+  if (act == FS_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == FS_ACT_RELU6) return (z > 0.f && z < 6.f) ? 1.f : 0.f;
+  return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum (blockDim.x multiple of 64, <= 1024). `red` = __shared__ scratch of >= 16 T.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  T s = 0;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,373 @@
+// Implicit-GEMM 2-D convolution on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), NHWC activations,
+// RSCK weights ([R][S][Cin][Cout]).  Replaces ATen conv2d / convolution_backward on the path
+// (reference call sites: models/hrnetv2_nodownsp.py:26-29,72-78,190-216,278-282,327-346;
+//  saliency_network.py:308-310; models/model_utils.py:6-13,228-232,260).
+//
+//   forward   : Y[m][n]  = sum_{tap,ci} X[pix(m)+tap][ci] * W[tap][ci][n]          M=B*Ho*Wo N=Cout
+//   bwd-data  : dX[m][n] = sum_{tap,co} dY[(pix(m)+pad-tap)/s][co] * W[tap][n][co] M=B*H*W   N=Cin
+//   bwd-weight: dW[tap][ci][co] = sum_pix X[pix+tap][ci] * dY[pix][co]             K=B*Ho*Wo (split)
+//
+// Tiling: 256 threads = 4 waves; forward/bwd-data workgroup tile 128 (pixels) x 64 (channels),
+// K-step 32 inside one filter tap; each wave owns 32 x 64 = two 32x32 accumulators.  Operands are
+// staged global -> registers -> LDS with the next stage's loads in flight under the MFMAs.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 64, BK = 32;
+constexpr int A_LD = BK + 1;   // odd leading dimension: conflict-free ds_read_b32 of A[row][k]
+
+struct ConvArgs {
+  const float* src;   // fwd: X (B,Hs,Ws,Cs)      bwd-data: dY
+  const float* w;     // [R][S][Cin][Cout]
+  const float* bias;  // fwd only, may be null
+  float* dst;         // fwd: Y (B,Hd,Wd,Cd)      bwd-data: dX
+  int B, Hs, Ws, Cs, Hd, Wd, Cd;
+  int R, S, stride, pad;
+  int transposed;     // 0 = forward, 1 = bwd-data
+  float drop_scale;   // 1/(1-p)
+  uint32_t drop_thresh, drop_key;   // thresh 0 = no dropout
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  __shared__ float As[BM * A_LD];
+  __shared__ float Bs[BK * BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long M = (long)a.B * a.Hd * a.Wd;
+  const long m0 = (long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- per-thread A rows: row = (tid>>3) + 32*i, channel quad q = tid&7 -------------------
+  const int q = tid & 7, arow = tid >> 3;
+  int pb[4], py[4], px[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    long m = m0 + arow + 32 * i;
+    if (m < M) {
+      int b = (int)(m / ((long)a.Hd * a.Wd));
+      int rem = (int)(m - (long)b * a.Hd * a.Wd);
+      pb[i] = b; py[i] = rem / a.Wd; px[i] = rem - py[i] * a.Wd;
+    } else {
+      pb[i] = -1; py[i] = 0; px[i] = 0;
+    }
+  }
+  // ---- per-thread B slots ---------------------------------------------------------------
+  //   forward : tile [k][n], n contiguous in memory: n4 = tid&15, k = (tid>>4)+16*i
+  //   bwd-data: tile [n][k], k contiguous in memory: k4 = tid&7,  n = (tid>>3)+32*i
+  f32x4 ra[4], rb[2];
+  const int nchunk = (a.Cs + BK - 1) / BK;
+  const int nstage = a.R * a.S * nchunk;
+
+  auto load_stage = [&](int st) {
+    const int tap = st / nchunk, c0 = (st - tap * nchunk) * BK;
+    const int tr = tap / a.S, ts = tap - tr * a.S;
+    const int c = c0 + 4 * q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pb[i] >= 0) {
+        int iy, ix;
+        bool ok;
+        if (!a.transposed) {
+          iy = py[i] * a.stride - a.pad + tr;
+          ix = px[i] * a.stride - a.pad + ts;
+          ok = (iy >= 0) & (iy < a.Hs) & (ix >= 0) & (ix < a.Ws);
+        } else {
+          int ty = py[i] + a.pad - tr, tx = px[i] + a.pad - ts;
+          ok = (ty >= 0) & (tx >= 0);
+          if (a.stride > 1) {
+            ok = ok & (ty % a.stride == 0) & (tx % a.stride == 0);
+            iy = ty / a.stride; ix = tx / a.stride;
+          } else { iy = ty; ix = tx; }
+          ok = ok & (iy < a.Hs) & (ix < a.Ws);
+        }
+        if (ok) {
+          const float* p = a.src + (((long)pb[i] * a.Hs + iy) * a.Ws + ix) * a.Cs + c;
+          if (VEC) {
+            if (c < a.Cs) v = *reinterpret_cast<const f32x4*>(p);
+          } else {
+            if (c + 0 < a.Cs) v.x = p[0];
+            if (c + 1 < a.Cs) v.y = p[1];
+            if (c + 2 < a.Cs) v.z = p[2];
+            if (c + 3 < a.Cs) v.w = p[3];
+          }
+        }
+      }
+      ra[i] = v;
+    }
+    if (!a.transposed) {
+      const int n = n0 + 4 * (tid & 15);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int k = c0 + (tid >> 4) + 16 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < a.Cs) {
+          const float* p = a.w + ((long)tap * a.Cs + k) * a.Cd + n;
+          if (VEC) {
+            if (n < a.Cd) v = *reinterpret_cast<const f32x4*>(p);
+          } else {
+            if (n + 0 < a.Cd) v.x = p[0];
+            if (n + 1 < a.Cd) v.y = p[1];
+            if (n + 2 < a.Cd) v.z = p[2];
+            if (n + 3 < a.Cd) v.w = p[3];
+          }
+        }
+        rb[i] = v;
+      }
+    } else {
+      const int k = c0 + 4 * (tid & 7);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = n0 + (tid >> 3) + 32 * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < a.Cd) {
+          const float* p = a.w + ((long)tap * a.Cd + n) * a.Cs + k;   // W[tap][ci=n][co=k]
+          if (VEC) {
+            if (k < a.Cs) v = *reinterpret_cast<const f32x4*>(p);
+          } else {
+            if (k + 0 < a.Cs) v.x = p[0];
+            if (k + 1 < a.Cs) v.y = p[1];
+            if (k + 2 < a.Cs) v.z = p[2];
+            if (k + 3 < a.Cs) v.w = p[3];
+          }
+        }
+        rb[i] = v;
+      }
+    }
+  };
+
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* p = &As[(arow + 32 * i) * A_LD + 4 * q];
+      p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w;
+    }
+    if (!a.transposed) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<f32x4*>(&Bs[((tid >> 4) + 16 * i) * BN + 4 * (tid & 15)]) = rb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = (tid >> 3) + 32 * i, k = 4 * (tid & 7);
+        Bs[(k + 0) * BN + n] = rb[i].x;
+        Bs[(k + 1) * BN + n] = rb[i].y;
+        Bs[(k + 2) * BN + n] = rb[i].z;
+        Bs[(k + 3) * BN + n] = rb[i].w;
+      }
+    }
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float* Ap = &As[(wave * 32 + l31) * A_LD + lh];
+  const float* Bp = &Bs[lh * BN + l31];
+
+  load_stage(0);
+  for (int st = 0; st < nstage; ++st) {
+    __syncthreads();                 // previous stage's LDS reads are done
+    store_stage();
+    __syncthreads();
+    if (st + 1 < nstage) load_stage(st + 1);   // in flight under the MFMAs below
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const float av = Ap[2 * kk];
+      const float b0 = Bp[2 * kk * BN];
+      const float b1 = Bp[2 * kk * BN + 32];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: bias, dropout, store ----------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = n0 + 32 * t + l31;
+    if (n >= a.Cd) continue;
+    const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= M) continue;
+      float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
+      const long e = m * a.Cd + n;
+      if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+      a.dst[e] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// bwd-weight: per tap GEMM  dW[tap][ci][co] += sum_{pix in split} X[pix+tap][ci] * dY[pix][co]
+// tile 64(ci) x 64(co), K-step 32 pixels, one 32x32 accumulator per wave, split-K over
+// blockIdx.z with fp32 atomic accumulation into a zeroed dW.
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* x;    // (B,H,W,Cin)
+  const float* dy;   // (B,Ho,Wo,Cout)
+  float* dw;         // [R][S][Cin][Cout], zero-initialised
+  int B, H, W, Cin, Ho, Wo, Cout;
+  int R, S, stride, pad;
+  int pix_per_split;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  __shared__ float As[BK * 64];   // [pix][ci]
+  __shared__ float Bs[BK * 64];   // [pix][co]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_n = (a.Cout + 63) / 64;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int ci0 = tm * 64, co0 = tn * 64;
+  const int tap = blockIdx.y, tr = tap / a.S, ts = tap - tr * a.S;
+  const long P = (long)a.B * a.Ho * a.Wo;
+  const long p_begin = (long)blockIdx.z * a.pix_per_split;
+  const long p_end = (p_begin + a.pix_per_split < P) ? p_begin + a.pix_per_split : P;
+
+  const int c4 = 4 * (tid & 15), prow = tid >> 4;   // rows prow + 16*i, i<2
+  f32x4 ra[2], rb[2];
+
+  auto load_stage = [&](long p0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long p = p0 + prow + 16 * i;
+      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+      if (p < p_end) {
+        const int b = (int)(p / ((long)a.Ho * a.Wo));
+        const int rem = (int)(p - (long)b * a.Ho * a.Wo);
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        const int iy = oy * a.stride - a.pad + tr, ix = ox * a.stride - a.pad + ts;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+          const int c = ci0 + c4;
+          const float* q = a.x + (((long)b * a.H + iy) * a.W + ix) * a.Cin + c;
+          if (VEC) {
+            if (c < a.Cin) va = *reinterpret_cast<const f32x4*>(q);
+          } else {
+            if (c + 0 < a.Cin) va.x = q[0];
+            if (c + 1 < a.Cin) va.y = q[1];
+            if (c + 2 < a.Cin) va.z = q[2];
+            if (c + 3 < a.Cin) va.w = q[3];
+          }
+        }
+        {
+          const int c = co0 + c4;
+          const float* q = a.dy + p * a.Cout + c;
+          if (VEC) {
+            if (c < a.Cout) vb = *reinterpret_cast<const f32x4*>(q);
+          } else {
+            if (c + 0 < a.Cout) vb.x = q[0];
+            if (c + 1 < a.Cout) vb.y = q[1];
+            if (c + 2 < a.Cout) vb.z = q[2];
+            if (c + 3 < a.Cout) vb.w = q[3];
+          }
+        }
+      }
+      ra[i] = va; rb[i] = vb;
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f32x4*>(&As[(prow + 16 * i) * 64 + c4]) = ra[i];
+      *reinterpret_cast<f32x4*>(&Bs[(prow + 16 * i) * 64 + c4]) = rb[i];
+    }
+  };
+
+  f32x16 acc = {0};
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const float* Ap = &As[lh * 64 + 32 * wm + l31];
+  const float* Bp = &Bs[lh * 64 + 32 * wn + l31];
+
+  if (p_begin < p_end) load_stage(p_begin);
+  for (long p0 = p_begin; p0 < p_end; p0 += BK) {
+    __syncthreads();
+    store_stage();
+    __syncthreads();
+    if (p0 + BK < p_end) load_stage(p0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap[2 * kk * 64], Bp[2 * kk * 64], acc, 0, 0, 0);
+  }
+  const int co = co0 + 32 * wn + l31;
+  if (co < a.Cout) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ci < a.Cin) atomicAdd(&a.dw[((long)tap * a.Cin + ci) * a.Cout + co], acc[r]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// include/fovealseg.h: fs_conv2d_fwd
+int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
+                  int Ho, int Wo, int Cout, int R, int S, int stride, int pad, float drop_p, uint32_t drop_key,
+                  hipStream_t stream) {
+  FS_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
+  FS_REQUIRE(Ho == (H + 2 * pad - R) / stride + 1 && Wo == (W + 2 * pad - S) / stride + 1);
+  FS_REQUIRE(drop_p >= 0.f && drop_p < 1.f);
+  ConvArgs a{x, w, bias, y, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, 0, 1.f, 0u, drop_key};
+  if (drop_p > 0.f) {
+    a.drop_scale = 1.0f / (float)(1.0 - (double)drop_p);
+    a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
+  }
+  const long M = (long)B * Ho * Wo;
+  FS_REQUIRE(M * Cout < 4294967296L);
+  dim3 grid(cdiv(M, BM), cdiv(Cout, BN));
+  if ((Cin % 4 == 0) && (Cout % 4 == 0))
+    hipLaunchKernelGGL(conv_igemm_kernel<true>, grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(conv_igemm_kernel<false>, grid, dim3(256), 0, stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// include/fovealseg.h: fs_conv2d_bwd_data   (dX has the forward input's shape B,H,W,Cin)
+int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
+                       int Cout, int R, int S, int stride, int pad, hipStream_t stream) {
+  FS_REQUIRE(dy && w && dx && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
+  FS_REQUIRE(Ho == (H + 2 * pad - R) / stride + 1 && Wo == (W + 2 * pad - S) / stride + 1);
+  ConvArgs a{dy, w, nullptr, dx, B, Ho, Wo, Cout, H, W, Cin, R, S, stride, pad, 1, 1.f, 0u, 0u};
+  const long M = (long)B * H * W;
+  dim3 grid(cdiv(M, BM), cdiv(Cin, BN));
+  if ((Cin % 4 == 0) && (Cout % 4 == 0))
+    hipLaunchKernelGGL(conv_igemm_kernel<true>, grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(conv_igemm_kernel<false>, grid, dim3(256), 0, stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// include/fovealseg.h: fs_conv2d_bwd_weight   (dw is overwritten)
+int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo,
+                         int Cout, int R, int S, int stride, int pad, hipStream_t stream) {
+  FS_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
+  FS_REQUIRE(Ho == (H + 2 * pad - R) / stride + 1 && Wo == (W + 2 * pad - S) / stride + 1);
+  hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)R * S * Cin * Cout, stream);
+  if (e != hipSuccess) return (int)e;
+  const long P = (long)B * Ho * Wo;
+  const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);
+  long nsplit = (2048 + (long)tiles * R * S - 1) / ((long)tiles * R * S);
+  long maxsplit = (P + 255) / 256;
+  if (nsplit > maxsplit) nsplit = maxsplit;
+  if (nsplit < 1) nsplit = 1;
+  long pps = (P + nsplit - 1) / nsplit;
+  pps = ((pps + BK - 1) / BK) * BK;
+  nsplit = (P + pps - 1) / pps;
+  WgradArgs a{x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, (int)pps};
+  dim3 grid(tiles, R * S, (unsigned)nsplit);
+  if ((Cin % 4 == 0) && (Cout % 4 == 0))
+    hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,485 @@
+// HBM-bound NHWC passes around the convolutions: train/eval BatchNorm (+dropout-aware backward),
+// activation, residual add, HRNet multi-resolution fuse, bilinear up-sampling into the 960-channel
+// concat buffer, bias gradients, global average pool.
+// Reference semantics: lib/nn/modules/batchnorm.py:56-61 (F.batch_norm fallback),
+// models/hrnetv2_nodownsp.py:46-64 (BasicBlock), :228-252 (fuse), :434-442 (concat),
+// models/model_utils.py:254-255 (AvgPool2d(10)).
+#include "common.h"
+
+namespace {
+
+// Column-group layout shared by the BN kernels: a thread owns one float4 channel group
+// (cw = C/4 groups) and walks rows with stride rpi = 256/cw.
+struct RowWalk {
+  int cw, rpi, col, r0;
+  __device__ RowWalk(int C) {
+    cw = C >> 2;
+    rpi = 256 / cw; if (rpi < 1) rpi = 1;
+    col = threadIdx.x % cw;
+    r0 = threadIdx.x / cw;
+  }
+  __device__ bool active() const { return r0 < rpi; }
+};
+
+// ---- BN statistics: per-channel sum and sum of squares (double accumulators) --------------
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, long M, int C, int rows_per_block,
+                                                       double* __restrict__ sums /* [2][C] */) {
+  extern __shared__ double sm[];   // [rpi][C][2] partials
+  RowWalk w(C);
+  const long rb = (long)blockIdx.x * rows_per_block;
+  long re = rb + rows_per_block; if (re > M) re = M;
+  f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
+  if (w.active())
+    for (long r = rb + w.r0; r < re; r += w.rpi) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + 4 * w.col);
+      s += v; ss += v * v;
+    }
+  if (w.active()) {
+    double* p = sm + ((long)w.r0 * C + 4 * w.col) * 2;
+    p[0] = s.x; p[1] = ss.x; p[2] = s.y; p[3] = ss.y; p[4] = s.z; p[5] = ss.z; p[6] = s.w; p[7] = ss.w;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double a = 0, b = 0;
+    for (int r = 0; r < w.rpi; ++r) { a += sm[((long)r * C + c) * 2]; b += sm[((long)r * C + c) * 2 + 1]; }
+    atomicAdd(&sums[c], a);
+    atomicAdd(&sums[C + c], b);
+  }
+}
+
+// ---- BN finalize: mean / invstd, running-stat update ---------------------------------------
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, long M, int C, float momentum, float eps,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean, float* __restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = sums[c] / (double)M;
+  double var = sums[C + c] / (double)M - mu * mu;
+  if (var < 0) var = 0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {
+    const float unbiased = (float)(var * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+    running_mean[c] = momentum * (float)mu + (1.f - momentum) * running_mean[c];
+    running_var[c] = momentum * unbiased + (1.f - momentum) * running_var[c];
+  }
+}
+
+__global__ void bn_eval_prepare_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                       int C, float eps, float* __restrict__ mean, float* __restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = running_mean[c];
+  invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+// ---- BN apply + residual + activation --------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ res,
+                                                         float* __restrict__ out, long M, int C, int rows_per_block, int act) {
+  RowWalk w(C);
+  if (!w.active()) return;
+  const int c = 4 * w.col;
+  f32x4 sc, sh;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = invstd[c + j] * gamma[c + j];
+    sc[j] = a; sh[j] = beta[c + j] - mean[c + j] * a;
+  }
+  const long rb = (long)blockIdx.x * rows_per_block;
+  long re = rb + rows_per_block; if (re > M) re = M;
+  for (long r = rb + w.r0; r < re; r += w.rpi) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + c);
+    v = v * sc + sh;
+    if (res != nullptr) v += *reinterpret_cast<const f32x4*>(res + r * C + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fs_act(v[j], act);
+    *reinterpret_cast<f32x4*>(out + r * C + c) = v;
+  }
+}
+
+// ---- BN backward pass 1: sum(g), sum(g*xhat), g = dz * act'(z) --------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                            const float* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, long M, int C,
+                                                            int rows_per_block, int act, double* __restrict__ sums) {
+  extern __shared__ double sm[];
+  RowWalk w(C);
+  const int c = 4 * w.col;
+  f32x4 s = {0, 0, 0, 0}, sx = {0, 0, 0, 0};
+  if (w.active()) {
+    f32x4 mu, is;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; is[j] = invstd[c + j]; }
+    const long rb = (long)blockIdx.x * rows_per_block;
+    long re = rb + rows_per_block; if (re > M) re = M;
+    for (long r = rb + w.r0; r < re; r += w.rpi) {
+      f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * C + c);
+      if (act != FS_ACT_NONE) {
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] *= fs_act_mask(zz[j], act);
+      }
+      const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + r * C + c) - mu) * is;
+      s += g; sx += g * xh;
+    }
+    double* p = sm + ((long)w.r0 * C + c) * 2;
+    p[0] = s.x; p[1] = sx.x; p[2] = s.y; p[3] = sx.y; p[4] = s.z; p[5] = sx.z; p[6] = s.w; p[7] = sx.w;
+  }
+  __syncthreads();
+  for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
+    double a = 0, b = 0;
+    for (int r = 0; r < w.rpi; ++r) { a += sm[((long)r * C + cc) * 2]; b += sm[((long)r * C + cc) * 2 + 1]; }
+    atomicAdd(&sums[cc], a);
+    atomicAdd(&sums[C + cc], b);
+  }
+}
+
+// ---- BN backward pass 2: dy (conv-output gradient, dropout applied), dres, dgamma/dbeta -------
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                           const float* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const double* __restrict__ sums, long M, int C, int rows_per_block,
+                                                           int act, int training, float drop_scale, uint32_t drop_thresh,
+                                                           uint32_t drop_key, float* __restrict__ dy, float* __restrict__ dres,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  RowWalk w(C);
+  if (blockIdx.x == 0 && dgamma != nullptr)
+    for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
+      dbeta[cc] = (float)sums[cc];
+      dgamma[cc] = (float)sums[C + cc];
+    }
+  if (!w.active()) return;
+  const int c = 4 * w.col;
+  f32x4 mu, is, ga, mg, mgx;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mu[j] = mean[c + j]; is[j] = invstd[c + j]; ga[j] = gamma[c + j] * is[j];
+    mg[j] = training ? (float)(sums[c + j] / (double)M) : 0.f;
+    mgx[j] = training ? (float)(sums[C + c + j] / (double)M) : 0.f;
+  }
+  const long rb = (long)blockIdx.x * rows_per_block;
+  long re = rb + rows_per_block; if (re > M) re = M;
+  for (long r = rb + w.r0; r < re; r += w.rpi) {
+    f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * C + c);
+    if (act != FS_ACT_NONE) {
+      const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * C + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] *= fs_act_mask(zz[j], act);
+    }
+    if (dres != nullptr) *reinterpret_cast<f32x4*>(dres + r * C + c) = g;
+    const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + r * C + c) - mu) * is;
+    f32x4 d = ga * (g - mg - xh * mgx);
+    if (drop_thresh != 0u) {
+      const uint32_t e = (uint32_t)(r * C + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = fs_dropout_keep(e + j, drop_key, drop_thresh) ? d[j] * drop_scale : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(dy + r * C + c) = d;
+  }
+}
+
+// ---- bilinear source coordinates (align_corners=False, ATen upsample_bilinear2d) ------------
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_coord(int d, int in, int out) {
+  Lerp L;
+  if (in == out) { L.i0 = d; L.i1 = d; L.l0 = 1.f; L.l1 = 0.f; return L; }
+  const float scale = (float)in / (float)out;
+  float s = scale * ((float)d + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  L.i0 = (int)s;
+  L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
+  L.l1 = s - (float)L.i0;
+  L.l0 = 1.f - L.l1;
+  return L;
+}
+
+__device__ __forceinline__ f32x4 bilerp4(const float* __restrict__ src, int b, int th, int tw, int C, int c,
+                                         const Lerp& Ly, const Lerp& Lx) {
+  const float* base = src + (long)b * th * tw * C + c;
+  const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((long)Ly.i0 * tw + Lx.i0) * C);
+  const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((long)Ly.i0 * tw + Lx.i1) * C);
+  const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((long)Ly.i1 * tw + Lx.i0) * C);
+  const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((long)Ly.i1 * tw + Lx.i1) * C);
+  return Ly.l0 * (Lx.l0 * v00 + Lx.l1 * v01) + Ly.l1 * (Lx.l0 * v10 + Lx.l1 * v11);
+}
+
+// ---- HRNet fuse: out = relu(t0 + t1 + t2 + t3), lower-resolution terms bilinearly up-sampled ---
+struct FuseArgs {
+  const float* t[4];
+  int th[4], tw[4];
+  int nterms;
+  float* out;
+  int B, Ho, Wo, C, relu;
+};
+__global__ __launch_bounds__(256) void hr_fuse_fwd_kernel(FuseArgs a) {
+  const int cw = a.C >> 2;
+  const long total = (long)a.B * a.Ho * a.Wo * cw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = 4 * (int)(i % cw);
+    const long pix = i / cw;
+    const int ox = (int)(pix % a.Wo);
+    const int oy = (int)((pix / a.Wo) % a.Ho);
+    const int b = (int)(pix / ((long)a.Wo * a.Ho));
+    f32x4 acc = {0, 0, 0, 0};
+    for (int t = 0; t < a.nterms; ++t) {
+      f32x4 v;
+      if (a.th[t] == a.Ho && a.tw[t] == a.Wo) {
+        v = *reinterpret_cast<const f32x4*>(a.t[t] + pix * a.C + c);
+      } else {
+        const Lerp Ly = lerp_coord(oy, a.th[t], a.Ho), Lx = lerp_coord(ox, a.tw[t], a.Wo);
+        v = bilerp4(a.t[t], b, a.th[t], a.tw[t], a.C, c, Ly, Lx);
+      }
+      acc = (t == 0) ? v : acc + v;
+    }
+    if (a.relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = acc[j] > 0.f ? acc[j] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(a.out + pix * a.C + c) = acc;
+  }
+}
+
+// g = dout * (out > 0)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                       float* __restrict__ g, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 d = reinterpret_cast<const f32x4*>(dout)[i];
+    const f32x4 o = reinterpret_cast<const f32x4*>(out)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+    reinterpret_cast<f32x4*>(g)[i] = d;
+  }
+}
+
+// ---- bilinear up-sample into a channel slice of a wider NHWC buffer (final 960-ch concat) ------
+__global__ __launch_bounds__(256) void upsample_slice_fwd_kernel(const float* __restrict__ src, int B, int th, int tw, int C,
+                                                                 float* __restrict__ dst, int Ho, int Wo, int Cdst, int coff) {
+  const int cw = C >> 2;
+  const long total = (long)B * Ho * Wo * cw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = 4 * (int)(i % cw);
+    const long pix = i / cw;
+    const int ox = (int)(pix % Wo);
+    const int oy = (int)((pix / Wo) % Ho);
+    const int b = (int)(pix / ((long)Wo * Ho));
+    const Lerp Ly = lerp_coord(oy, th, Ho), Lx = lerp_coord(ox, tw, Wo);
+    *reinterpret_cast<f32x4*>(dst + pix * Cdst + coff + c) = bilerp4(src, b, th, tw, C, c, Ly, Lx);
+  }
+}
+
+// transpose of the above as a gather: dsrc[b,qy,qx,c] = sum over the <= (2f)^2 output pixels whose
+// 2x2 footprint touches (qy,qx).  g is read from a channel slice (stride Cg, offset coff).
+__global__ __launch_bounds__(256) void upsample_slice_bwd_kernel(const float* __restrict__ g, int B, int Ho, int Wo, int Cg,
+                                                                 int coff, float* __restrict__ dsrc, int th, int tw, int C) {
+  const int cw = C >> 2;
+  const long total = (long)B * th * tw * cw;
+  const int fy = Ho / th, fx = Wo / tw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = 4 * (int)(i % cw);
+    const long q = i / cw;
+    const int qx = (int)(q % tw);
+    const int qy = (int)((q / tw) % th);
+    const int b = (int)(q / ((long)tw * th));
+    f32x4 acc = {0, 0, 0, 0};
+    if (fy == 1 && fx == 1) {
+      acc = *reinterpret_cast<const f32x4*>(g + (((long)b * Ho + qy) * Wo + qx) * Cg + coff + c);
+    } else {
+      int y_lo = fy * qy - fy / 2, y_hi = fy * qy + (3 * fy) / 2 - 1;
+      int x_lo = fx * qx - fx / 2, x_hi = fx * qx + (3 * fx) / 2 - 1;
+      if (y_lo < 0) y_lo = 0;
+      if (x_lo < 0) x_lo = 0;
+      if (y_hi > Ho - 1 || qy == th - 1) y_hi = Ho - 1;
+      if (x_hi > Wo - 1 || qx == tw - 1) x_hi = Wo - 1;
+      for (int oy = y_lo; oy <= y_hi; ++oy) {
+        const Lerp Ly = lerp_coord(oy, th, Ho);
+        const float wy = (Ly.i0 == qy ? Ly.l0 : 0.f) + (Ly.i1 == qy ? Ly.l1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = x_lo; ox <= x_hi; ++ox) {
+          const Lerp Lx = lerp_coord(ox, tw, Wo);
+          const float wx = (Lx.i0 == qx ? Lx.l0 : 0.f) + (Lx.i1 == qx ? Lx.l1 : 0.f);
+          if (wx == 0.f) continue;
+          acc += (wy * wx) * *reinterpret_cast<const f32x4*>(g + (((long)b * Ho + oy) * Wo + ox) * Cg + coff + c);
+        }
+      }
+    }
+    *reinterpret_cast<f32x4*>(dsrc + q * C + c) = acc;
+  }
+}
+
+// ---- column sums (bias gradients), out zeroed by the launcher ----------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long M, int C, int rows_per_block,
+                                                     float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const long rb = (long)blockIdx.y * rows_per_block;
+  long re = rb + rows_per_block; if (re > M) re = M;
+  float s = 0.f;
+  for (long r = rb; r < re; ++r) s += x[r * C + c];
+  atomicAdd(&out[c], s);
+}
+
+// ---- global average pool over HW (AvgPool2d((10,10)) on a 10x10 map) ---------------------------
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, int B, int HW, int C, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  float s = 0.f;
+  for (int p = 0; p < HW; ++p) s += x[((long)b * HW + p) * C + c];
+  out[i] = s / (float)HW;
+}
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dout, int B, int HW, int C, float* __restrict__ dx) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * HW * C) return;
+  const int c = (int)(i % C);
+  const int b = (int)(i / ((long)HW * C));
+  dx[i] = dout[b * C + c] / (float)HW;
+}
+
+int rows_per_block_for(long M, int C) {
+  const int cw = C / 4;
+  int rpi = 256 / cw; if (rpi < 1) rpi = 1;
+  long rpb = (M + 1023) / 1024;
+  rpb = ((rpb + rpi - 1) / rpi) * rpi;
+  if (rpb < rpi) rpb = rpi;
+  return (int)rpb;
+}
+size_t stats_smem(int C) {
+  const int cw = C / 4;
+  int rpi = 256 / cw; if (rpi < 1) rpi = 1;
+  return (size_t)rpi * C * 2 * sizeof(double);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Training-mode statistics of y (M rows, C channels): mean/invstd out, running stats updated in
+// place with `momentum` (unbiased variance), `sums` = 2*C doubles of scratch.
+int fs_bn_stats(const float* y, long M, int C, float momentum, float eps, float* running_mean, float* running_var,
+                float* mean, float* invstd, double* sums, hipStream_t stream) {
+  FS_REQUIRE(y && mean && invstd && sums && M > 0 && C > 0 && C % 4 == 0 && C <= 1024);
+  hipError_t e = hipMemsetAsync(sums, 0, 2 * C * sizeof(double), stream);
+  if (e != hipSuccess) return (int)e;
+  const int rpb = rows_per_block_for(M, C);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(M, rpb)), dim3(256), stats_smem(C), stream, y, M, C, rpb, sums);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, sums, M, C, momentum, eps,
+                     running_mean, running_var, mean, invstd);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_bn_eval_prepare(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* invstd,
+                       hipStream_t stream) {
+  FS_REQUIRE(running_mean && running_var && mean && invstd && C > 0);
+  hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, running_mean, running_var, C, eps,
+                     mean, invstd);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_bn_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  const float* res, float* out, long M, int C, int act, hipStream_t stream) {
+  FS_REQUIRE(y && mean && invstd && gamma && beta && out && M > 0 && C > 0 && C % 4 == 0 && C <= 1024);
+  const int rpb = rows_per_block_for(M, C);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, stream, y, mean, invstd, gamma, beta, res, out,
+                     M, C, rpb, act);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// Backward of out = act(bn(y) + res).  training=1: batch statistics (sum terms); 0: running stats.
+// dy = gradient w.r.t. the (dropped-out) conv output, multiplied by the dropout mask when
+// drop_p > 0; dres (nullable) = gradient w.r.t. res; dgamma/dbeta overwritten.
+int fs_bn_act_bwd(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+                  const float* gamma, long M, int C, int act, int training, float drop_p, uint32_t drop_key, float* dy,
+                  float* dres, float* dgamma, float* dbeta, double* sums, hipStream_t stream) {
+  FS_REQUIRE(dz && y && mean && invstd && gamma && dy && dgamma && dbeta && sums && M > 0 && C % 4 == 0 && C <= 1024);
+  FS_REQUIRE(act == FS_ACT_NONE || z != nullptr);
+  hipError_t e = hipMemsetAsync(sums, 0, 2 * C * sizeof(double), stream);
+  if (e != hipSuccess) return (int)e;
+  const int rpb = rows_per_block_for(M, C);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(M, rpb)), dim3(256), stats_smem(C), stream, dz, z, y, mean, invstd, M,
+                     C, rpb, act, sums);
+  FS_LAUNCH_CHECK();
+  float scale = 1.f; uint32_t thresh = 0u;
+  if (drop_p > 0.f) { scale = 1.0f / (float)(1.0 - (double)drop_p); thresh = (uint32_t)((double)drop_p * 4294967296.0); }
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, stream, dz, z, y, mean, invstd, gamma, sums, M,
+                     C, rpb, act, training, scale, thresh, drop_key, dy, dres, dgamma, dbeta);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_hr_fuse_fwd(const float* const* terms, const int* th, const int* tw, int nterms, float* out, int B, int Ho, int Wo,
+                   int C, int relu, hipStream_t stream) {
+  FS_REQUIRE(terms && th && tw && out && nterms >= 1 && nterms <= 4 && C % 4 == 0);
+  FuseArgs a;
+  for (int t = 0; t < 4; ++t) { a.t[t] = nullptr; a.th[t] = 0; a.tw[t] = 0; }
+  for (int t = 0; t < nterms; ++t) {
+    FS_REQUIRE(terms[t] && th[t] > 0 && tw[t] > 0 && Ho % th[t] == 0 && Wo % tw[t] == 0);
+    a.t[t] = terms[t]; a.th[t] = th[t]; a.tw[t] = tw[t];
+  }
+  a.nterms = nterms; a.out = out; a.B = B; a.Ho = Ho; a.Wo = Wo; a.C = C; a.relu = relu;
+  const long total = (long)B * Ho * Wo * (C / 4);
+  int blocks = cdiv(total, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(hr_fuse_fwd_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_relu_bwd(const float* dout, const float* out, float* g, long n, hipStream_t stream) {
+  FS_REQUIRE(dout && out && g && n > 0 && n % 4 == 0);
+  int blocks = cdiv(n / 4, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dout, out, g, n / 4);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_upsample_slice_fwd(const float* src, int B, int th, int tw, int C, float* dst, int Ho, int Wo, int Cdst, int coff,
+                          hipStream_t stream) {
+  FS_REQUIRE(src && dst && C % 4 == 0 && Cdst % 4 == 0 && coff % 4 == 0 && coff + C <= Cdst && Ho % th == 0 && Wo % tw == 0);
+  const long total = (long)B * Ho * Wo * (C / 4);
+  int blocks = cdiv(total, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(upsample_slice_fwd_kernel, dim3(blocks), dim3(256), 0, stream, src, B, th, tw, C, dst, Ho, Wo, Cdst, coff);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_upsample_slice_bwd(const float* g, int B, int Ho, int Wo, int Cg, int coff, float* dsrc, int th, int tw, int C,
+                          hipStream_t stream) {
+  FS_REQUIRE(g && dsrc && C % 4 == 0 && Cg % 4 == 0 && coff % 4 == 0 && coff + C <= Cg && Ho % th == 0 && Wo % tw == 0);
+  FS_REQUIRE((Ho / th == 1 || (Ho / th) % 2 == 0) && (Wo / tw == 1 || (Wo / tw) % 2 == 0));
+  const long total = (long)B * th * tw * (C / 4);
+  int blocks = cdiv(total, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(upsample_slice_bwd_kernel, dim3(blocks), dim3(256), 0, stream, g, B, Ho, Wo, Cg, coff, dsrc, th, tw, C);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_colsum(const float* x, long M, int C, float* out, hipStream_t stream) {
+  FS_REQUIRE(x && out && M > 0 && C > 0);
+  hipError_t e = hipMemsetAsync(out, 0, C * sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  int chunks = (int)((M + 255) / 256); if (chunks > 512) chunks = 512;
+  const int rpb = (int)((M + chunks - 1) / chunks);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 256), cdiv(M, rpb)), dim3(256), 0, stream, x, M, C, rpb, out);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_avgpool_fwd(const float* x, int B, int HW, int C, float* out, hipStream_t stream) {
+  FS_REQUIRE(x && out && B > 0 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, stream, x, B, HW, C, out);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+int fs_avgpool_bwd(const float* dout, int B, int HW, int C, float* dx, hipStream_t stream) {
+  FS_REQUIRE(dout && dx && B > 0 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(cdiv((long)B * HW * C, 256)), dim3(256), 0, stream, dout, B, HW, C, dx);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+}  // extern "C"

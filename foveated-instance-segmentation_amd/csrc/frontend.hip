@@ -1,0 +1,601 @@
+// Foveation front-end kernels (HBM / gather bound):
+//   K1  gaze map + bilinear low-res RGB -> 5-channel NHWC saliency input   (models/models.py:684-705)
+//   K3  ReLU -> 1x1 conv 24->1 -> softmax over HxW                          (models/models.py:369-372,715-723)
+//   K4  replication pad + separable Gaussian accumulation -> sampling grid  (models/models.py:594-637,819-821)
+//   K5  non-uniform bilinear grid_sample (image -> NHWC, label -> int64)    (models/models.py:880,909,951)
+//   K6  grid_sample backward w.r.t. the grid (+ scatter-add w.r.t. input)
+//   K11 area pooling of the full-resolution mask + min/max-normalised MSE   (models/models.py:730,889-898)
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// K1
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gaze_lowres_kernel(const float* __restrict__ x, const float* __restrict__ focus,
+                                                          float* __restrict__ out, int B, int H, int W, int hs, int ws) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * hs * ws) return;
+  const int ox = (int)(i % ws), oy = (int)((i / ws) % hs), b = (int)(i / ((long)ws * hs));
+  // bilinear, align_corners=False (ATen upsample_bilinear2d)
+  const float sy = (float)H / (float)hs, sx = (float)W / (float)ws;
+  float fy = sy * ((float)oy + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+  float fx = sx * ((float)ox + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+  float* o = out + i * 5;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* p = x + ((long)b * 3 + c) * H * W;
+    const float v00 = p[(long)y0 * W + x0], v01 = p[(long)y0 * W + x1];
+    const float v10 = p[(long)y1 * W + x0], v11 = p[(long)y1 * W + x1];
+    o[c] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+  }
+  // gaze map: ((sqrt((i-h)^2+(j-w)^2)) / sqrt(hs^2+ws^2))^2
+  const float h = focus[2 * b] * (float)(hs - 1), w = focus[2 * b + 1] * (float)(ws - 1);
+  const float dy = (float)oy - h, dx = (float)ox - w;
+  const float dist = sqrtf(dy * dy + dx * dx);
+  const float maxd = (float)sqrt((double)hs * hs + (double)ws * ws);
+  const float r = dist / maxd;
+  o[3] = r * r;
+  o[4] = r * r;
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: one workgroup per image
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void compress_softmax_fwd_kernel(const float* __restrict__ s, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, float* __restrict__ xs,
+                                                                    int HW, int C) {
+  extern __shared__ float logit[];
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  const float* sb = s + (long)b * HW * C;
+  float lmax = -INFINITY;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = sb[(long)p * C + c];
+      acc += (v > 0.f ? v : 0.f) * w[c];
+    }
+    acc += bias[0];
+    logit[p] = acc;
+    lmax = fmaxf(lmax, acc);
+  }
+  lmax = wave_max(lmax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lmax;
+  __syncthreads();
+  float m = red[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, red[i]);
+  float lsum = 0.f;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const float e = expf(logit[p] - m);
+    logit[p] = e;
+    lsum += e;
+  }
+  const float tot = block_sum<float>(lsum, red);
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) xs[(long)b * HW + p] = logit[p] / tot;
+}
+
+// dlogit = xs * (g - sum(g*xs)); ds[p][c] = dlogit*w[c]*(s>0); dw[c] += sum dlogit*relu(s); db += sum dlogit
+__global__ __launch_bounds__(1024) void compress_softmax_bwd_kernel(const float* __restrict__ g, const float* __restrict__ xs,
+                                                                    const float* __restrict__ s, const float* __restrict__ w,
+                                                                    float* __restrict__ ds, float* __restrict__ dw,
+                                                                    float* __restrict__ db, int HW, int C) {
+  __shared__ float red[16];
+  __shared__ float dwacc[64];
+  const int b = blockIdx.x;
+  const float* gb = g + (long)b * HW;
+  const float* xb = xs + (long)b * HW;
+  const float* sb = s + (long)b * HW * C;
+  float* dsb = ds + (long)b * HW * C;
+  if (threadIdx.x < 64) dwacc[threadIdx.x] = 0.f;
+  float dot = 0.f;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) dot += gb[p] * xb[p];
+  dot = block_sum<float>(dot, red);
+  float dbl = 0.f;
+  float dwl[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) dwl[c] = 0.f;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const float dl = xb[p] * (gb[p] - dot);
+    dbl += dl;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      if (c < C) {
+        const float v = sb[(long)p * C + c];
+        dsb[(long)p * C + c] = v > 0.f ? dl * w[c] : 0.f;
+        dwl[c] += dl * (v > 0.f ? v : 0.f);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    if (c < C) {
+      const float v = wave_sum(dwl[c]);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&dwacc[c], v);
+    }
+  }
+  dbl = block_sum<float>(dbl, red);
+  __syncthreads();
+  if (threadIdx.x < C) atomicAdd(&dw[threadIdx.x], dwacc[threadIdx.x]);
+  if (threadIdx.x == 0) atomicAdd(db, dbl);
+}
+
+// ------------------------------------------------------------------------------------------
+// K11: area pool (adaptive average, windows [floor(o*H/h), ceil((o+1)*H/h)) ), one block per (b, oy)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void area_pool_kernel(const float* __restrict__ y, float* __restrict__ out, int H, int W,
+                                                        int hs, int ws) {
+  extern __shared__ float colsum[];   // W floats
+  const int oy = blockIdx.x % hs, b = blockIdx.x / hs;
+  const int y0 = (int)(((long)oy * H) / hs);
+  const int y1 = (int)((((long)(oy + 1)) * H + hs - 1) / hs);
+  const float* base = y + (long)b * H * W;
+  for (int xcol = threadIdx.x; xcol < W; xcol += blockDim.x) {
+    float s = 0.f;
+    for (int r = y0; r < y1; ++r) s += base[(long)r * W + xcol];
+    colsum[xcol] = s;
+  }
+  __syncthreads();
+  for (int ox = threadIdx.x; ox < ws; ox += blockDim.x) {
+    const int x0 = (int)(((long)ox * W) / ws);
+    const int x1 = (int)((((long)(ox + 1)) * W + ws - 1) / ws);
+    float s = 0.f;
+    for (int c = x0; c < x1; ++c) s += colsum[c];
+    out[((long)b * hs + oy) * ws + ox] = s / (float)((y1 - y0) * (x1 - x0));
+  }
+}
+
+// edge loss = coef * mean(((xs-min)/(max-min) - (t-tmin)/(tmax-tmin))^2), whole-batch min/max.
+// stats out: [xs_min, xs_max, t_min, t_max, n_argmin, n_argmax]; single workgroup (n ~ 4e5).
+__global__ __launch_bounds__(1024) void edge_loss_fwd_kernel(const float* __restrict__ xs, const float* __restrict__ t, long n,
+                                                             float coef, float* __restrict__ loss, float* __restrict__ stats) {
+  __shared__ float red[4][16];
+  __shared__ double dred[16];
+  float mn = INFINITY, mx = -INFINITY, tmn = INFINITY, tmx = -INFINITY;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float a = xs[i], b = t[i];
+    mn = fminf(mn, a); mx = fmaxf(mx, a); tmn = fminf(tmn, b); tmx = fmaxf(tmx, b);
+  }
+  mn = wave_min(mn); mx = wave_max(mx); tmn = wave_min(tmn); tmx = wave_max(tmx);
+  const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = mn; red[1][wv] = mx; red[2][wv] = tmn; red[3][wv] = tmx; }
+  __syncthreads();
+  mn = red[0][0]; mx = red[1][0]; tmn = red[2][0]; tmx = red[3][0];
+  for (int i = 1; i < nw; ++i) {
+    mn = fminf(mn, red[0][i]); mx = fmaxf(mx, red[1][i]); tmn = fminf(tmn, red[2][i]); tmx = fmaxf(tmx, red[3][i]);
+  }
+  const float r = mx - mn, tr = tmx - tmn;
+  double acc = 0.0, cmin = 0.0, cmax = 0.0;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float a = xs[i];
+    const float u = (a - mn) / r, v = (t[i] - tmn) / tr;
+    const float d = u - v;
+    acc += (double)(d * d);
+    cmin += (a == mn) ? 1.0 : 0.0;
+    cmax += (a == mx) ? 1.0 : 0.0;
+  }
+  acc = block_sum<double>(acc, dred);
+  cmin = block_sum<double>(cmin, dred);
+  cmax = block_sum<double>(cmax, dred);
+  if (threadIdx.x == 0) {
+    loss[0] = coef * (float)(acc / (double)n);
+    stats[0] = mn; stats[1] = mx; stats[2] = tmn; stats[3] = tmx; stats[4] = (float)cmin; stats[5] = (float)cmax;
+  }
+}
+
+__global__ __launch_bounds__(1024) void edge_loss_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ t, long n,
+                                                             float coef, const float* __restrict__ gout,
+                                                             const float* __restrict__ stats, float* __restrict__ dxs) {
+  __shared__ double dred[16];
+  const float mn = stats[0], mx = stats[1], tmn = stats[2], tmx = stats[3];
+  const float r = mx - mn, tr = tmx - tmn;
+  const float k = 2.f * coef * gout[0] / (float)n;
+  double s_gu1 = 0.0, s_gu = 0.0;    // sum g*(u-1), sum g*u
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float u = (xs[i] - mn) / r, v = (t[i] - tmn) / tr;
+    const float g = k * (u - v);
+    s_gu1 += (double)(g * (u - 1.f));
+    s_gu += (double)(g * u);
+  }
+  s_gu1 = block_sum<double>(s_gu1, dred);
+  s_gu = block_sum<double>(s_gu, dred);
+  const float dmn = (float)(s_gu1 / (double)r) / stats[4];
+  const float dmx = (float)(-s_gu / (double)r) / stats[5];
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float a = xs[i];
+    const float u = (a - mn) / r, v = (t[i] - tmn) / tr;
+    float d = k * (u - v) / r;
+    if (a == mn) d += dmn;
+    if (a == mx) d += dmx;
+    dxs[i] = d;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: Gaussian-saliency accumulation -> grid.  One workgroup per image, everything in LDS.
+//   p  = sum_{r,s} g[r]g[s] x~[oy+r][ox+s]
+//   ax = sum g[r]g[s] x~ * cx(ox+s),  cx(j) = (j-pad)/(ws-1)     ay likewise with cy(i)=(i-pad)/(hs-1)
+//   gx = clamp(2ax/p-1), gy = clamp(2ay/p-1); x~ = replication-padded saliency.
+// The filter is separable (makeGaussian, models/models.py:157), so it runs as a row pass (91 taps)
+// and a column pass (91 taps) with double accumulators instead of an 8281-tap direct conv.
+// ------------------------------------------------------------------------------------------
+constexpr int GMAX = 6400;   // hs*ws upper bound of the LDS layout (80x80)
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// row pass: R0[y][ox] = sum_s g[s] xs[y][clamp(ox+s-pad)],  R1 = same * cx(ox+s)
+__device__ void gauss_rows(const float* xs, const double* g, int hs, int ws, int pad, float* R0, float* R1) {
+  const int K = 2 * pad + 1;
+  const double inv = 1.0 / (double)(ws - 1);
+  for (int i = threadIdx.x; i < hs * ws; i += blockDim.x) {
+    const int y = i / ws, ox = i - y * ws;
+    double a0 = 0.0, a1 = 0.0;
+    for (int s = 0; s < K; ++s) {
+      const int j = ox + s;
+      const double v = g[s] * (double)xs[y * ws + clampi(j - pad, 0, ws - 1)];
+      a0 += v;
+      a1 += v * ((double)(j - pad) * inv);
+    }
+    R0[i] = (float)a0; R1[i] = (float)a1;
+  }
+}
+
+__device__ __forceinline__ void gauss_cols_at(const float* R0, const float* R1, const double* g, int hs, int ws, int pad,
+                                              int oy, int ox, double& p, double& ax, double& ay) {
+  const int K = 2 * pad + 1;
+  const double inv = 1.0 / (double)(hs - 1);
+  p = 0.0; ax = 0.0; ay = 0.0;
+  for (int r = 0; r < K; ++r) {
+    const int i = oy + r;
+    const int y = clampi(i - pad, 0, hs - 1);
+    const double v0 = g[r] * (double)R0[y * ws + ox];
+    p += v0;
+    ax += g[r] * (double)R1[y * ws + ox];
+    ay += v0 * ((double)(i - pad) * inv);
+  }
+}
+
+__global__ __launch_bounds__(1024) void gauss_grid_fwd_kernel(const float* __restrict__ xs_g, const double* __restrict__ g1d,
+                                                              float* __restrict__ grid, int hs, int ws, int pad) {
+  extern __shared__ float sm[];
+  float* X = sm; float* R0 = sm + GMAX; float* R1 = sm + 2 * GMAX;
+  __shared__ double g[256];
+  const int b = blockIdx.x, n = hs * ws;
+  for (int i = threadIdx.x; i < 2 * pad + 1; i += blockDim.x) g[i] = g1d[i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) X[i] = xs_g[(long)b * n + i];
+  __syncthreads();
+  gauss_rows(X, g, hs, ws, pad, R0, R1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int oy = i / ws, ox = i - oy * ws;
+    double p, ax, ay;
+    gauss_cols_at(R0, R1, g, hs, ws, pad, oy, ox, p, ax, ay);
+    float gx = (float)(ax / p * 2.0 - 1.0), gy = (float)(ay / p * 2.0 - 1.0);
+    gx = fminf(fmaxf(gx, -1.f), 1.f);
+    gy = fminf(fmaxf(gy, -1.f), 1.f);
+    grid[((long)b * n + i) * 2 + 0] = gx;
+    grid[((long)b * n + i) * 2 + 1] = gy;
+  }
+}
+
+// backward: dgrid (B,hs,ws,2) -> dxs (B,hs,ws).  Recomputes p/ax/ay, then runs the transposed
+// separable filter and folds the replication padding back onto the border pixels.
+__global__ __launch_bounds__(1024) void gauss_grid_bwd_kernel(const float* __restrict__ xs_g, const double* __restrict__ g1d,
+                                                              const float* __restrict__ dgrid, float* __restrict__ dxs,
+                                                              int hs, int ws, int pad) {
+  extern __shared__ float sm[];
+  float* A = sm; float* Bf = sm + GMAX; float* Cf = sm + 2 * GMAX; float* D = sm + 3 * GMAX; float* E = sm + 4 * GMAX;
+  __shared__ double g[256];
+  const int b = blockIdx.x, n = hs * ws, K = 2 * pad + 1;
+  for (int i = threadIdx.x; i < K; i += blockDim.x) g[i] = g1d[i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) A[i] = xs_g[(long)b * n + i];
+  __syncthreads();
+  gauss_rows(A, g, hs, ws, pad, Bf, Cf);
+  __syncthreads();
+  // D0 -> A, D1 -> D, D2 -> E   (gradients w.r.t. p, ax, ay)
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int oy = i / ws, ox = i - oy * ws;
+    double p, ax, ay;
+    gauss_cols_at(Bf, Cf, g, hs, ws, pad, oy, ox, p, ax, ay);
+    const double ux = ax / p * 2.0 - 1.0, uy = ay / p * 2.0 - 1.0;
+    // clamp(-1,1) passes the gradient where the un-clamped value lies inside [-1,1] (bounds included)
+    const double dgx = (ux >= -1.0 && ux <= 1.0) ? (double)dgrid[((long)b * n + i) * 2 + 0] : 0.0;
+    const double dgy = (uy >= -1.0 && uy <= 1.0) ? (double)dgrid[((long)b * n + i) * 2 + 1] : 0.0;
+    const double dax = 2.0 * dgx / p, day = 2.0 * dgy / p;
+    const double dp = -(dax * ax + day * ay) / p;
+    A[i] = (float)dp; D[i] = (float)dax; E[i] = (float)day;   // A (xs) is dead after the row pass
+  }
+  __syncthreads();
+  // row pass (transposed, folded): for every source row oy and folded column x:
+  //   Va[oy][x] = sum_{j -> x} sum_ox g[j-ox] (D0 + cx(j) D1)[oy][ox],   Vb[oy][x] = sum_{j->x} sum_ox g[j-ox] D2[oy][ox]
+  const double invx = 1.0 / (double)(ws - 1), invy = 1.0 / (double)(hs - 1);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int oy = i / ws, x = i - oy * ws;
+    const int j_lo = (x == 0) ? 0 : x + pad, j_hi = (x == ws - 1) ? ws + 2 * pad - 1 : x + pad;
+    double va = 0.0, vb = 0.0;
+    for (int j = j_lo; j <= j_hi; ++j) {
+      const double cx = (double)(j - pad) * invx;
+      int o_lo = j - (K - 1); if (o_lo < 0) o_lo = 0;
+      int o_hi = j; if (o_hi > ws - 1) o_hi = ws - 1;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int ox = o_lo; ox <= o_hi; ++ox) {
+        const double gv = g[j - ox];
+        s0 += gv * (double)A[oy * ws + ox];
+        s1 += gv * (double)D[oy * ws + ox];
+        s2 += gv * (double)E[oy * ws + ox];
+      }
+      va += s0 + cx * s1;
+      vb += s2;
+    }
+    Bf[i] = (float)va; Cf[i] = (float)vb;
+  }
+  __syncthreads();
+  // column pass (transposed, folded): dxs[y][x] = sum_{i -> y} sum_oy g[i-oy] (Va + cy(i) Vb)[oy][x]
+  for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
+    const int y = idx / ws, x = idx - y * ws;
+    const int i_lo = (y == 0) ? 0 : y + pad, i_hi = (y == hs - 1) ? hs + 2 * pad - 1 : y + pad;
+    double acc = 0.0;
+    for (int i = i_lo; i <= i_hi; ++i) {
+      const double cy = (double)(i - pad) * invy;
+      int o_lo = i - (K - 1); if (o_lo < 0) o_lo = 0;
+      int o_hi = i; if (o_hi > hs - 1) o_hi = hs - 1;
+      double s0 = 0.0, s1 = 0.0;
+      for (int oy = o_lo; oy <= o_hi; ++oy) {
+        const double gv = g[i - oy];
+        s0 += gv * (double)Bf[oy * ws + x];
+        s1 += gv * (double)Cf[oy * ws + x];
+      }
+      acc += s0 + cy * s1;
+    }
+    dxs[(long)b * n + idx] = (float)acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5 / K6: grid_sample, bilinear, zeros padding, align_corners=False.  Arithmetic follows the
+// bit-exact recipe of SURVEY.md §8(a)-A12 (verified against ATen's CPU kernel by the goldens):
+//   ix = fma(gx+1, W/2, -0.5); w = ix-floor(ix); weights nw=(1-n)(1-w) ...; acc = nw*v_nw;
+//   acc = fma(v_ne,ne,acc); acc = fma(v_sw,sw,acc); acc = fma(v_se,se,acc).
+// Explicit __f*_rn intrinsics keep hipcc from re-associating or contracting differently.
+// ------------------------------------------------------------------------------------------
+struct Taps {
+  int x0, y0;
+  float nw, ne, sw, se;
+  bool okx0, okx1, oky0, oky1;
+  float w, n, e, s;   // fractional parts (east/south weights) and their complements
+};
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int H, int W) {
+  Taps t;
+  const float ix = __fmaf_rn(__fadd_rn(gx, 1.f), (float)W * 0.5f, -0.5f);
+  const float iy = __fmaf_rn(__fadd_rn(gy, 1.f), (float)H * 0.5f, -0.5f);
+  const float fx = floorf(ix), fy = floorf(iy);
+  t.w = __fsub_rn(ix, fx); t.e = __fsub_rn(1.f, t.w);
+  t.n = __fsub_rn(iy, fy); t.s = __fsub_rn(1.f, t.n);
+  t.nw = __fmul_rn(t.s, t.e); t.ne = __fmul_rn(t.s, t.w);
+  t.sw = __fmul_rn(t.n, t.e); t.se = __fmul_rn(t.n, t.w);
+  // floor of a possibly huge/NaN coordinate: clamp before the int conversion
+  const float cx = fminf(fmaxf(fx, -2.f), (float)W + 1.f), cy = fminf(fmaxf(fy, -2.f), (float)H + 1.f);
+  t.x0 = (int)cx; t.y0 = (int)cy;
+  t.okx0 = (t.x0 >= 0) & (t.x0 < W); t.okx1 = (t.x0 + 1 >= 0) & (t.x0 + 1 < W);
+  t.oky0 = (t.y0 >= 0) & (t.y0 < H); t.oky1 = (t.y0 + 1 >= 0) & (t.y0 + 1 < H);
+  return t;
+}
+__device__ __forceinline__ float sample_plane(const float* __restrict__ p, int W, const Taps& t) {
+  const float vnw = (t.oky0 & t.okx0) ? p[(long)t.y0 * W + t.x0] : 0.f;
+  const float vne = (t.oky0 & t.okx1) ? p[(long)t.y0 * W + t.x0 + 1] : 0.f;
+  const float vsw = (t.oky1 & t.okx0) ? p[(long)(t.y0 + 1) * W + t.x0] : 0.f;
+  const float vse = (t.oky1 & t.okx1) ? p[(long)(t.y0 + 1) * W + t.x0 + 1] : 0.f;
+  float acc = __fmul_rn(vnw, t.nw);
+  acc = __fmaf_rn(vne, t.ne, acc);
+  acc = __fmaf_rn(vsw, t.sw, acc);
+  acc = __fmaf_rn(vse, t.se, acc);
+  return acc;
+}
+
+// x (B,C,H,W) NCHW -> out (B,h,w,C) NHWC  [nhwc_out=1]  or (B,C,h,w) NCHW [nhwc_out=0]
+__global__ __launch_bounds__(256) void grid_sample_fwd_kernel(const float* __restrict__ x, const float* __restrict__ grid,
+                                                              float* __restrict__ out, int B, int C, int H, int W, int h,
+                                                              int w, int nhwc_out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * h * w) return;
+  const int b = (int)(i / ((long)h * w));
+  const long pix = i - (long)b * h * w;
+  const Taps t = make_taps(grid[2 * i], grid[2 * i + 1], H, W);
+  for (int c = 0; c < C; ++c) {
+    const float v = sample_plane(x + ((long)b * C + c) * H * W, W, t);
+    if (nhwc_out) out[i * C + c] = v;
+    else out[((long)b * C + c) * h * w + pix] = v;
+  }
+}
+
+// y (B,1,H,W) float mask -> label (B,h,w) int64 = trunc(bilinear(y))   (models/models.py:880,951)
+__global__ __launch_bounds__(256) void grid_sample_label_kernel(const float* __restrict__ y, const float* __restrict__ grid,
+                                                                long long* __restrict__ label, float* __restrict__ ysamp,
+                                                                int B, int H, int W, int h, int w) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * h * w) return;
+  const int b = (int)(i / ((long)h * w));
+  const Taps t = make_taps(grid[2 * i], grid[2 * i + 1], H, W);
+  const float v = sample_plane(y + (long)b * H * W, W, t);
+  if (ysamp != nullptr) ysamp[i] = v;
+  label[i] = (long long)v;
+}
+
+// gout (B,h,w,C) NHWC [nhwc=1] or (B,C,h,w): dgrid (B,h,w,2)
+__global__ __launch_bounds__(256) void grid_sample_bwd_grid_kernel(const float* __restrict__ gout, const float* __restrict__ x,
+                                                                   const float* __restrict__ grid, float* __restrict__ dgrid,
+                                                                   int B, int C, int H, int W, int h, int w, int nhwc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * h * w) return;
+  const int b = (int)(i / ((long)h * w));
+  const long pix = i - (long)b * h * w;
+  const Taps t = make_taps(grid[2 * i], grid[2 * i + 1], H, W);
+  float gix = 0.f, giy = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float* p = x + ((long)b * C + c) * H * W;
+    const float go = nhwc ? gout[i * C + c] : gout[((long)b * C + c) * h * w + pix];
+    const float vnw = (t.oky0 & t.okx0) ? p[(long)t.y0 * W + t.x0] : 0.f;
+    const float vne = (t.oky0 & t.okx1) ? p[(long)t.y0 * W + t.x0 + 1] : 0.f;
+    const float vsw = (t.oky1 & t.okx0) ? p[(long)(t.y0 + 1) * W + t.x0] : 0.f;
+    const float vse = (t.oky1 & t.okx1) ? p[(long)(t.y0 + 1) * W + t.x0 + 1] : 0.f;
+    gix += go * ((vne - vnw) * t.s + (vse - vsw) * t.n);
+    giy += go * ((vsw - vnw) * t.e + (vse - vne) * t.w);
+  }
+  dgrid[2 * i] = gix * ((float)W * 0.5f);
+  dgrid[2 * i + 1] = giy * ((float)H * 0.5f);
+}
+
+// scatter-add w.r.t. the input image (dx zeroed by the launcher); not on the default path
+// (x needs no gradient) -- provided for loss_at_high_res / the inverse warp.
+__global__ __launch_bounds__(256) void grid_sample_bwd_input_kernel(const float* __restrict__ gout, const float* __restrict__ grid,
+                                                                    float* __restrict__ dx, int B, int C, int H, int W, int h,
+                                                                    int w, int nhwc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * h * w) return;
+  const int b = (int)(i / ((long)h * w));
+  const long pix = i - (long)b * h * w;
+  const Taps t = make_taps(grid[2 * i], grid[2 * i + 1], H, W);
+  for (int c = 0; c < C; ++c) {
+    float* p = dx + ((long)b * C + c) * H * W;
+    const float go = nhwc ? gout[i * C + c] : gout[((long)b * C + c) * h * w + pix];
+    if (t.oky0 & t.okx0) atomicAdd(&p[(long)t.y0 * W + t.x0], go * t.nw);
+    if (t.oky0 & t.okx1) atomicAdd(&p[(long)t.y0 * W + t.x0 + 1], go * t.ne);
+    if (t.oky1 & t.okx0) atomicAdd(&p[(long)(t.y0 + 1) * W + t.x0], go * t.sw);
+    if (t.oky1 & t.okx1) atomicAdd(&p[(long)(t.y0 + 1) * W + t.x0 + 1], go * t.se);
+  }
+}
+
+// integer index maps of the inverse deformation (models/models.py:644-645): trunc toward zero
+__global__ void inverse_index_kernel(const float* __restrict__ grid, long long* __restrict__ u, long long* __restrict__ v,
+                                     long n, int H, int W) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gx = grid[2 * i], gy = grid[2 * i + 1];
+  const float fu = __fmul_rn(__fmul_rn(__fadd_rn(gx, 1.f), 0.5f), (float)(W - 1));
+  const float fv = __fmul_rn(__fmul_rn(__fadd_rn(gy, 1.f), 0.5f), (float)(H - 1));
+  u[i] = (long long)(int)fu;
+  v[i] = (long long)(int)fv;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fs_gaze_lowres_fwd(const float* x, const float* focus, float* out, int B, int H, int W, int hs, int ws,
+                       hipStream_t stream) {
+  FS_REQUIRE(x && focus && out && B > 0 && H > 0 && W > 0 && hs > 1 && ws > 1);
+  hipLaunchKernelGGL(gaze_lowres_kernel, dim3(cdiv((long)B * hs * ws, 256)), dim3(256), 0, stream, x, focus, out, B, H, W, hs, ws);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_compress_softmax_fwd(const float* s, const float* w, const float* bias, float* xs, int B, int HW, int C,
+                            hipStream_t stream) {
+  FS_REQUIRE(s && w && bias && xs && B > 0 && HW > 0 && HW <= 16384 && C > 0 && C <= 32);
+  hipLaunchKernelGGL(compress_softmax_fwd_kernel, dim3(B), dim3(1024), HW * sizeof(float), stream, s, w, bias, xs, HW, C);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_compress_softmax_bwd(const float* g, const float* xs, const float* s, const float* w, float* ds, float* dw, float* db,
+                            int B, int HW, int C, hipStream_t stream) {
+  FS_REQUIRE(g && xs && s && w && ds && dw && db && B > 0 && HW > 0 && C > 0 && C <= 32);
+  hipError_t e = hipMemsetAsync(dw, 0, C * sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(db, 0, sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(compress_softmax_bwd_kernel, dim3(B), dim3(1024), 0, stream, g, xs, s, w, ds, dw, db, HW, C);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_area_pool_fwd(const float* y, float* out, int B, int H, int W, int hs, int ws, hipStream_t stream) {
+  FS_REQUIRE(y && out && B > 0 && H >= hs && W >= ws && hs > 0 && ws > 0 && W <= 16384);
+  hipLaunchKernelGGL(area_pool_kernel, dim3(B * hs), dim3(256), W * sizeof(float), stream, y, out, H, W, hs, ws);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_edge_loss_fwd(const float* xs, const float* t, long n, float coef, float* loss, float* stats, hipStream_t stream) {
+  FS_REQUIRE(xs && t && loss && stats && n > 0);
+  hipLaunchKernelGGL(edge_loss_fwd_kernel, dim3(1), dim3(1024), 0, stream, xs, t, n, coef, loss, stats);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_edge_loss_bwd(const float* xs, const float* t, long n, float coef, const float* gout, const float* stats, float* dxs,
+                     hipStream_t stream) {
+  FS_REQUIRE(xs && t && gout && stats && dxs && n > 0);
+  hipLaunchKernelGGL(edge_loss_bwd_kernel, dim3(1), dim3(1024), 0, stream, xs, t, n, coef, gout, stats, dxs);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_gauss_grid_fwd(const float* xs, const double* g1d, float* grid, int B, int hs, int ws, int pad, hipStream_t stream) {
+  FS_REQUIRE(xs && g1d && grid && B > 0 && hs > 1 && ws > 1 && hs * ws <= GMAX && pad >= 0 && 2 * pad + 1 <= 256);
+  hipLaunchKernelGGL(gauss_grid_fwd_kernel, dim3(B), dim3(1024), 3 * GMAX * sizeof(float), stream, xs, g1d, grid, hs, ws, pad);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_gauss_grid_bwd(const float* xs, const double* g1d, const float* dgrid, float* dxs, int B, int hs, int ws, int pad,
+                      hipStream_t stream) {
+  FS_REQUIRE(xs && g1d && dgrid && dxs && B > 0 && hs > 1 && ws > 1 && hs * ws <= GMAX && pad >= 0 && 2 * pad + 1 <= 256);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gauss_grid_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       5 * GMAX * (int)sizeof(float));
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gauss_grid_bwd_kernel, dim3(B), dim3(1024), 5 * GMAX * sizeof(float), stream, xs, g1d, dgrid, dxs, hs, ws, pad);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_grid_sample_fwd(const float* x, const float* grid, float* out, int B, int C, int H, int W, int h, int w, int nhwc_out,
+                       hipStream_t stream) {
+  FS_REQUIRE(x && grid && out && B > 0 && C > 0 && H > 0 && W > 0 && h > 0 && w > 0);
+  hipLaunchKernelGGL(grid_sample_fwd_kernel, dim3(cdiv((long)B * h * w, 256)), dim3(256), 0, stream, x, grid, out, B, C, H, W, h, w, nhwc_out);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_grid_sample_label(const float* y, const float* grid, long long* label, float* ysamp, int B, int H, int W, int h, int w,
+                         hipStream_t stream) {
+  FS_REQUIRE(y && grid && label && B > 0 && H > 0 && W > 0 && h > 0 && w > 0);
+  hipLaunchKernelGGL(grid_sample_label_kernel, dim3(cdiv((long)B * h * w, 256)), dim3(256), 0, stream, y, grid, label, ysamp, B, H, W, h, w);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_grid_sample_bwd_grid(const float* gout, const float* x, const float* grid, float* dgrid, int B, int C, int H, int W, int h,
+                            int w, int nhwc, hipStream_t stream) {
+  FS_REQUIRE(gout && x && grid && dgrid && B > 0 && C > 0 && H > 0 && W > 0 && h > 0 && w > 0);
+  hipLaunchKernelGGL(grid_sample_bwd_grid_kernel, dim3(cdiv((long)B * h * w, 256)), dim3(256), 0, stream, gout, x, grid, dgrid, B, C, H, W, h, w, nhwc);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_grid_sample_bwd_input(const float* gout, const float* grid, float* dx, int B, int C, int H, int W, int h, int w, int nhwc,
+                             hipStream_t stream) {
+  FS_REQUIRE(gout && grid && dx && B > 0 && C > 0 && H > 0 && W > 0 && h > 0 && w > 0);
+  hipError_t e = hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * C * H * W, stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(grid_sample_bwd_input_kernel, dim3(cdiv((long)B * h * w, 256)), dim3(256), 0, stream, gout, grid, dx, B, C, H, W, h, w, nhwc);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_inverse_index_maps(const float* grid, long long* u, long long* v, long n, int H, int W, hipStream_t stream) {
+  FS_REQUIRE(grid && u && v && n > 0 && H > 0 && W > 0);
+  hipLaunchKernelGGL(inverse_index_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, grid, u, v, n, H, W);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+}  // extern "C"

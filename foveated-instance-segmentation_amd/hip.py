@@ -1,0 +1,101 @@
+"""ctypes binding of libfovealseg_hip.so (C ABI: include/fovealseg.h).
+
+There is NO fallback: if the library is missing or a launch is rejected the call raises.  torch is
+used only for device memory (tensor.data_ptr()) and the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfovealseg_hip.so")
+
+_P, _I, _L, _F, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint32
+
+# name -> argument type string (p pointer, i int, l long, f float, u uint32); the trailing stream
+# pointer is appended automatically.
+SIGNATURES = {
+    "fs_gaze_lowres_fwd": "pppiiiii",
+    "fs_compress_softmax_fwd": "ppppiii",
+    "fs_compress_softmax_bwd": "pppppppiii",
+    "fs_area_pool_fwd": "ppiiiii",
+    "fs_edge_loss_fwd": "pplfpp",
+    "fs_edge_loss_bwd": "pplfppp",
+    "fs_gauss_grid_fwd": "pppiiii",
+    "fs_gauss_grid_bwd": "ppppiiii",
+    "fs_grid_sample_fwd": "pppiiiiiii",
+    "fs_grid_sample_label": "ppppiiiii",
+    "fs_grid_sample_bwd_grid": "ppppiiiiiii",
+    "fs_grid_sample_bwd_input": "pppiiiiiii",
+    "fs_inverse_index_maps": "ppplii",
+    "fs_conv2d_fwd": "ppppiiiiiiiiiiifu",
+    "fs_conv2d_bwd_data": "pppiiiiiiiiiii",
+    "fs_conv2d_bwd_weight": "pppiiiiiiiiiii",
+    "fs_bn_stats": "pliffppppp",
+    "fs_bn_eval_prepare": "ppifpp",
+    "fs_bn_act_fwd": "ppppppplii",
+    "fs_bn_act_bwd": "ppppppliiifuppppp",
+    "fs_hr_fuse_fwd": "pppipiiiii",
+    "fs_relu_bwd": "pppl",
+    "fs_upsample_slice_fwd": "piiiipiiii",
+    "fs_upsample_slice_bwd": "piiiiipiii",
+    "fs_colsum": "plip",
+    "fs_avgpool_fwd": "piiip",
+    "fs_avgpool_bwd": "piiip",
+    "fs_mask_head_fwd": "ppppli",
+    "fs_mask_head_bwd": "pppppppli",
+    "fs_pred_assemble_fwd": "pppiii",
+    "fs_pred_assemble_bwd": "pppppiii",
+    "fs_seg_loss_fwd": "ppiiiffppp",
+    "fs_seg_loss_bwd": "pppppiiif",
+}
+_CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (building it first if the sources are newer and hipcc is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU/eager fallback for the fovealseg path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, sig in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = _I
+        fn.argtypes = [_CT[c] for c in sig] + [_P]
+    _lib = lib
+    return lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Launch `name` on torch's current HIP stream; raises on any non-zero status."""
+    lib = _lib if _lib is not None else load()
+    err = getattr(lib, name)(*args, _stream())
+    if err != 0:
+        what = "argument rejected at the C-ABI boundary" if err == 1001 else f"hipError {err}"
+        raise HipLibraryError(f"{name}: {what}")
+
+
+def ptr(t):
+    """Device pointer of a tensor the kernels may touch: fp32/fp64/int64, CUDA(HIP), contiguous."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipLibraryError("fovealseg kernels need device tensors (got a CPU tensor); there is no CPU path")
+    if not t.is_contiguous():
+        raise HipLibraryError(f"non-contiguous tensor {tuple(t.shape)} strides {t.stride()} passed to a HIP kernel")
+    return t.data_ptr()

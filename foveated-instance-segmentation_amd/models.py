@@ -1,0 +1,178 @@
+"""Plugin surface of the reference, backed by the HIP path.
+
+`ModelBuilder` (models/models.py:1146-1230) and `DeformSegmentationModule` (models/models.py:476-1094)
+with the same constructor/forward signatures, attribute names, return tuples, state_dict keys and the
+`feed_dict['seg_label']` side effect (:951), under the effective LVIS-50 configuration
+(SURVEY.md Appendix A).  Branches the default run never takes raise NotImplementedError.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import modules as M
+from . import ops
+from .weights import apply_name_keyed_init  # noqa: F401  (re-export for callers)
+
+
+def make_gaussian_1d(size: int, fwhm: float) -> np.ndarray:
+    """1-D factor of makeGaussian (models/models.py:140-157): G[i,j] = g[i]*g[j], float64."""
+    ax = np.arange(0, size, 1, float)
+    return np.exp(-4 * np.log(2) * (ax - size // 2) ** 2 / fwhm ** 2)
+
+
+class ModelBuilder:
+    @staticmethod
+    def weights_init(m):
+        """models/models.py:1149-1155 (by class name: Conv -> kaiming normal, BatchNorm -> w=1, b=1e-4)."""
+        classname = m.__class__.__name__
+        if classname.find("Conv2d") != -1 and hasattr(m, "weight"):
+            nn.init.kaiming_normal_(m.weight.data)
+        elif classname.find("BatchNorm") != -1:
+            m.weight.data.fill_(1.0)
+            m.bias.data.fill_(1e-4)
+
+    @staticmethod
+    def _load(net, weights):
+        if len(weights) > 0:
+            net.load_state_dict(torch.load(weights, map_location=lambda storage, loc: storage), strict=False)
+        return net
+
+    @staticmethod
+    def build_encoder(arch="resnet50", fc_dim=2048, weights="", dilate_rate=4):
+        arch = arch.lower()
+        if arch == "hrnetv2_nodownsp":
+            net = M.hrnetv2_nodownsp(pretrained=False)
+        elif arch in ("segformer", "deeplab"):
+            raise NotImplementedError(f"encoder '{arch}' is a later SURVEY §8 row (A22/A23); only hrnetv2_nodownsp is built")
+        else:
+            raise Exception("Architecture undefined!")
+        return ModelBuilder._load(net, weights)
+
+    @staticmethod
+    def build_decoder(arch="upernet", fc_dim=2048, num_class=150, weights="", use_softmax=False):
+        arch = arch.lower()
+        if arch == "c1":
+            net = M.C1(num_class=num_class, fc_dim=fc_dim, use_softmax=use_softmax)
+        else:
+            raise Exception("Architecture undefined!")
+        net.apply(ModelBuilder.weights_init)
+        return ModelBuilder._load(net, weights)
+
+    @staticmethod
+    def build_net_saliency(cfg=None, weights=""):
+        if not (cfg.MODEL.track_running_stats and cfg.MODEL.saliency_net == "fovsimple"):
+            raise Exception("Architecture undefined!")
+        net = M.fov_simple(cfg)
+        if len(weights) == 0:
+            net.apply(ModelBuilder.weights_init)
+        return ModelBuilder._load(net, weights)
+
+    @staticmethod
+    def build_net_compress(cfg=None, weights=""):
+        net = M.CompressNet(cfg)
+        if len(weights) == 0:
+            net.apply(ModelBuilder.weights_init)
+        return ModelBuilder._load(net, weights)
+
+
+class _FilterHolder(nn.Module):
+    """Keeps the `filter.weight` state_dict key of the reference (a fixed 91x91 Gaussian, Q6)."""
+
+    def __init__(self, k, fwhm):
+        super().__init__()
+        g = make_gaussian_1d(k, fwhm)
+        self.register_buffer("weight", torch.from_numpy(np.outer(g, g)).float().view(1, 1, k, k))
+
+
+class DeformSegmentationModule(nn.Module):
+    def __init__(self, net_encoder, net_decoder, net_saliency, net_compress, crit, cfg, deep_sup_scale=None):
+        super().__init__()
+        self.encoder = net_encoder
+        self.decoder = net_decoder
+        self.localization = net_saliency
+        self.net_compress = net_compress
+        self.cfg = cfg
+        self.deep_sup_scale = deep_sup_scale
+        T = cfg.TRAIN
+        if cfg.MODEL.saliency_output_size_short != 0 or cfg.MODEL.gaussian_ap != 0.0:
+            raise NotImplementedError("only saliency_output_size_short=0, gaussian_ap=0.0 (defaults) are built")
+        self.grid_size_x, self.grid_size_y = int(T.saliency_input_size[0]), int(T.saliency_input_size[1])
+        self.padding_size_x = self.padding_size_y = int(cfg.MODEL.gaussian_radius)
+        self.input_size = tuple(T.saliency_input_size)
+        self.input_size_net = tuple(T.task_input_size)
+        if tuple(self.input_size_net) != tuple(self.input_size):
+            raise NotImplementedError("task_input_size must equal saliency_input_size (models/models.py:968 assumes it)")
+        k = 2 * self.padding_size_x + 1
+        self.filter = _FilterHolder(k, cfg.MODEL.gaussian_radius)
+        self.register_buffer("g1d", torch.from_numpy(make_gaussian_1d(k, cfg.MODEL.gaussian_radius)), persistent=False)
+        self._check_cfg()
+
+    def _check_cfg(self):
+        c = self.cfg
+        off = [("MODEL.upsample", c.MODEL.upsample), ("MODEL.loss_at_high_res", c.MODEL.loss_at_high_res),
+               ("MODEL.gt_gradient", c.MODEL.gt_gradient), ("TRAIN.opt_deform_LabelEdge", c.TRAIN.opt_deform_LabelEdge)]
+        for name, val in off:
+            if val:
+                raise NotImplementedError(f"{name}=True is outside the built hot path (SURVEY.md Appendix A)")
+        if c.MODEL.uniform_sample != "":
+            raise NotImplementedError("MODEL.uniform_sample must be '' (learned sampling)")
+        if c.TRAIN.def_saliency_pad_mode != "replication":
+            raise NotImplementedError("only replication padding of the saliency map is built")
+        if not c.TRAIN.opt_deform_LabelEdge_norm:
+            raise NotImplementedError("only the min/max-normalised edge loss is built")
+        if self.deep_sup_scale is not None:
+            raise NotImplementedError("deep supervision is not used on this path")
+
+    # ---- stages (exposed for stage-wise parity tests) -------------------------------------------
+    def saliency(self, x, focus):
+        """x (B,3,H,W), focus (B,2) -> xs (B,1,hs,ws), x_low (B,hs,ws,5) NHWC."""
+        x_low = ops.gaze_lowres(x, focus, self.grid_size_x, self.grid_size_y)
+        s = self.localization.forward_nhwc(x_low)
+        return self.net_compress.softmax_nhwc(s), x_low
+
+    def create_grid(self, xs):
+        """xs (B,1,hs,ws) -> grid (B,hs,ws,2); replication pad folded in (models/models.py:594-637,821)."""
+        return ops.GaussGrid.apply(xs, self.g1d, self.padding_size_x)
+
+    def forward(self, feed_dict, *, writer=None, segSize=None, F_Xlr_acc_map=False, count=None, epoch=None,
+                feed_dict_info=None, feed_batch_count=None, cur_iter=None, is_inference=False, rank=None):
+        if segSize is not None:
+            raise NotImplementedError("segSize inference branch (models/models.py:621-631) is not on the default path")
+        cfg = self.cfg
+        x = feed_dict["img_data"].contiguous()
+        y = feed_dict["seg_label"]
+        if y.dim() == 3:
+            y = y.unsqueeze(1)
+        y = y.float().contiguous()
+        focus = feed_dict["focus_point"].float().contiguous()
+        hs, ws = self.grid_size_x, self.grid_size_y
+
+        xs, _ = self.saliency(x, focus)
+        assert not torch.isnan(xs).any(), "xs contains NaN values!"
+        grid = self.create_grid(xs)
+
+        joint = cfg.TRAIN.deform_joint_loss
+        if joint:
+            target = ops.area_pool(y, hs, ws)
+            edge_loss = ops.EdgeLoss.apply(xs, target, 0.05 * float(cfg.TRAIN.edge_loss_scale))
+
+        label = ops.grid_sample_label(y, grid.detach())
+        x_sampled = ops.GridSample.apply(x, grid)                      # (B,hs,ws,3) NHWC
+        feat = self.encoder.forward_nhwc(x_sampled)
+        pred = self.decoder.forward_nhwc(feat)                         # (B,K,hs,ws)
+        feed_dict["seg_label"] = label                                  # models/models.py:951
+
+        cls = feed_dict["cls_label"].to(label.dtype)
+        gt = label * cls[:, :, None] + (1 - label) * (cfg.DATASET.num_class - 1)
+        out = ops.SegLoss.apply(pred, gt.contiguous(), 5.0)
+        loss = out[0]
+        if joint:
+            loss = loss + edge_loss
+        acc = out[3].detach()
+        if joint:
+            if not is_inference:
+                return loss, acc, edge_loss
+            return loss, acc, edge_loss, out[4].detach(), out[5].detach(), out[6].detach()
+        if not is_inference:
+            return loss, acc
+        return loss, acc, out[4].detach(), out[5].detach(), out[6].detach()

@@ -1,0 +1,462 @@
+"""torch.autograd bindings of the HIP kernels (one Function per kernel group).
+
+Activations travel as contiguous NHWC fp32 tensors (B,H,W,C).  Convolution weights keep the
+reference's logical (Cout,Cin,R,S) shape with RSCK strides, so `w.permute(2,3,1,0)` is the contiguous
+[R][S][Cin][Cout] array the kernels read (DESIGN.md "Data layout").
+"""
+import ctypes
+import zlib
+
+import torch
+from torch.autograd import Function
+
+from . import hip
+
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+BN_EPS = 1e-5
+
+
+# ----------------------------------------------------------------------------------------------
+# dropout keys (integer hash shared with csrc/common.h and the oracle replay)
+# ----------------------------------------------------------------------------------------------
+class DropoutState:
+    """Global (seed, step) pair; every conv layer derives its key from it and its own id."""
+    seed = 0
+    step = 0
+
+    @classmethod
+    def key(cls, layer_id: int) -> int:
+        return layer_key(cls.seed * 1000003 + cls.step, layer_id)
+
+
+def layer_key(seed: int, layer_id: int) -> int:
+    x = (seed * 0x9E3779B1 + layer_id * 0x85EBCA6B + 0x27D4EB2F) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+    x ^= x >> 12
+    x = (x * 0x297A2D39) & 0xFFFFFFFF
+    x ^= x >> 15
+    return x
+
+
+def layer_id_from_name(name: str) -> int:
+    return zlib.crc32(name.encode()) & 0x7FFFFFFF
+
+
+# ----------------------------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------------------------
+def rsck(w: torch.Tensor) -> torch.Tensor:
+    """Contiguous [R][S][Cin][Cout] view of a logical (Cout,Cin,R,S) weight."""
+    v = w.permute(2, 3, 1, 0)
+    if not v.is_contiguous():
+        raise hip.HipLibraryError(f"conv weight {tuple(w.shape)} is not stored RSCK (strides {w.stride()})")
+    return v
+
+
+def new_rsck_weight(cout, cin, r, s, device=None) -> torch.Tensor:
+    """Uninitialised logical (Cout,Cin,R,S) tensor with RSCK storage."""
+    return torch.empty(r, s, cin, cout, device=device, dtype=torch.float32).permute(3, 2, 0, 1)
+
+
+def _out_hw(h, w, r, s, stride, pad):
+    return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
+
+
+def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0):
+    B, H, W, Cin = x.shape
+    Cout, Cin2, R, S = w.shape
+    assert Cin == Cin2, (x.shape, w.shape)
+    Ho, Wo = _out_hw(H, W, R, S, stride, pad)
+    y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+    hip.call("fs_conv2d_fwd", hip.ptr(x), hip.ptr(rsck(w)), hip.ptr(bias), hip.ptr(y), B, H, W, Cin, Ho, Wo, Cout, R, S,
+             stride, pad, float(drop_p), int(drop_key))
+    return y
+
+
+def conv2d_bwd_data(dy, w, x_shape, stride, pad):
+    B, H, W, Cin = x_shape
+    Cout, _, R, S = w.shape
+    _, Ho, Wo, _ = dy.shape
+    dx = torch.empty(B, H, W, Cin, device=dy.device, dtype=torch.float32)
+    hip.call("fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad)
+    return dx
+
+
+def conv2d_bwd_weight(x, dy, w_shape, stride, pad):
+    B, H, W, Cin = x.shape
+    Cout, _, R, S = w_shape
+    _, Ho, Wo, _ = dy.shape
+    dw = torch.empty(R, S, Cin, Cout, device=x.device, dtype=torch.float32)
+    hip.call("fs_conv2d_bwd_weight", hip.ptr(x), hip.ptr(dy), hip.ptr(dw), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad)
+    return dw.permute(3, 2, 0, 1)
+
+
+def colsum(x2d_rows, C):
+    out = torch.empty(C, device=x2d_rows.device, dtype=torch.float32)
+    hip.call("fs_colsum", hip.ptr(x2d_rows), x2d_rows.numel() // C, C, hip.ptr(out))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# conv (+bias) (+dropout) + BatchNorm + residual + activation
+# ----------------------------------------------------------------------------------------------
+class ConvBnAct(Function):
+    """z = act(BN(dropout(conv(x, w) + bias)) + res).
+    meta: dict(stride, pad, act, training, momentum, drop_p, drop_key, running_mean, running_var,
+    num_batches_tracked)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, res, meta):
+        training = meta["training"]
+        drop_p = meta["drop_p"] if training else 0.0
+        y = conv2d_fwd(x, w, bias, meta["stride"], meta["pad"], drop_p, meta["drop_key"])
+        B, Ho, Wo, C = y.shape
+        M = B * Ho * Wo
+        mean = torch.empty(C, device=y.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=y.device, dtype=torch.float32)
+        if training:
+            sums = torch.empty(2 * C, device=y.device, dtype=torch.float64)
+            hip.call("fs_bn_stats", hip.ptr(y), M, C, float(meta["momentum"]), BN_EPS, hip.ptr(meta["running_mean"]),
+                     hip.ptr(meta["running_var"]), hip.ptr(mean), hip.ptr(invstd), hip.ptr(sums))
+            meta["num_batches_tracked"].add_(1)
+        else:
+            hip.call("fs_bn_eval_prepare", hip.ptr(meta["running_mean"]), hip.ptr(meta["running_var"]), C, BN_EPS,
+                     hip.ptr(mean), hip.ptr(invstd))
+        z = torch.empty_like(y)
+        hip.call("fs_bn_act_fwd", hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(beta), hip.ptr(res),
+                 hip.ptr(z), M, C, meta["act"])
+        ctx.meta = dict(stride=meta["stride"], pad=meta["pad"], act=meta["act"], training=training, drop_p=drop_p,
+                        drop_key=meta["drop_key"], has_bias=bias is not None, has_res=res is not None)
+        ctx.save_for_backward(x, w, gamma, y, z, mean, invstd)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w, gamma, y, z, mean, invstd = ctx.saved_tensors
+        m = ctx.meta
+        dz = dz.contiguous()
+        B, Ho, Wo, C = y.shape
+        M = B * Ho * Wo
+        dy = torch.empty_like(y)
+        dres = torch.empty_like(y) if m["has_res"] else None
+        dgamma = torch.empty(C, device=y.device, dtype=torch.float32)
+        dbeta = torch.empty(C, device=y.device, dtype=torch.float32)
+        sums = torch.empty(2 * C, device=y.device, dtype=torch.float64)
+        hip.call("fs_bn_act_bwd", hip.ptr(dz), hip.ptr(z), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), M, C,
+                 m["act"], 1 if m["training"] else 0, float(m["drop_p"]), int(m["drop_key"]), hip.ptr(dy), hip.ptr(dres),
+                 hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums))
+        dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"]) if ctx.needs_input_grad[0] else None
+        dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"])
+        dbias = colsum(dy, C) if m["has_bias"] else None
+        return dx, dw, dbias, dgamma, dbeta, dres, None
+
+
+class ConvBias(Function):
+    """y = conv(x, w) + bias without normalisation (used for the FC layer as a 1x1 conv)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad):
+        ctx.save_for_backward(x, w)
+        ctx.sp = (stride, pad, bias is not None)
+        return conv2d_fwd(x, w, bias, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, has_bias = ctx.sp
+        dy = dy.contiguous()
+        dx = conv2d_bwd_data(dy, w, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
+        dw = conv2d_bwd_weight(x, dy, w.shape, stride, pad)
+        db = colsum(dy, dy.shape[-1]) if has_bias else None
+        return dx, dw, db, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# HRNet fuse + final concat
+# ----------------------------------------------------------------------------------------------
+class HrFuse(Function):
+    """out = relu(sum_t up(t)) over up to 4 NHWC terms (lower-resolution terms bilinearly up-sampled)."""
+
+    @staticmethod
+    def forward(ctx, Ho, Wo, *terms):
+        n = len(terms)
+        B, _, _, C = terms[0].shape
+        out = torch.empty(B, Ho, Wo, C, device=terms[0].device, dtype=torch.float32)
+        ptrs = (ctypes.c_void_p * n)(*[hip.ptr(t) for t in terms])
+        th = (ctypes.c_int * n)(*[t.shape[1] for t in terms])
+        tw = (ctypes.c_int * n)(*[t.shape[2] for t in terms])
+        hip.call("fs_hr_fuse_fwd", ptrs, th, tw, n, hip.ptr(out), B, Ho, Wo, C, 1)
+        ctx.save_for_backward(out)
+        ctx.shapes = [tuple(t.shape) for t in terms]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        g = torch.empty_like(out)
+        hip.call("fs_relu_bwd", hip.ptr(dout), hip.ptr(out), hip.ptr(g), out.numel())
+        B, Ho, Wo, C = out.shape
+        grads = []
+        for i, shp in enumerate(ctx.shapes):
+            if not ctx.needs_input_grad[2 + i]:
+                grads.append(None)
+            elif shp[1] == Ho and shp[2] == Wo:
+                grads.append(g)
+            else:
+                d = torch.empty(shp, device=out.device, dtype=torch.float32)
+                hip.call("fs_upsample_slice_bwd", hip.ptr(g), B, Ho, Wo, C, 0, hip.ptr(d), shp[1], shp[2], C)
+                grads.append(d)
+        return (None, None, *grads)
+
+
+class UpsampleConcat(Function):
+    """cat([x0, up(x1), up(x2), up(x3)], channel) written straight into one NHWC buffer."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        B, Ho, Wo, _ = xs[0].shape
+        Ct = sum(t.shape[3] for t in xs)
+        out = torch.empty(B, Ho, Wo, Ct, device=xs[0].device, dtype=torch.float32)
+        off = 0
+        for t in xs:
+            hip.call("fs_upsample_slice_fwd", hip.ptr(t), B, t.shape[1], t.shape[2], t.shape[3], hip.ptr(out), Ho, Wo, Ct, off)
+            off += t.shape[3]
+        ctx.shapes = [tuple(t.shape) for t in xs]
+        ctx.out_shape = (B, Ho, Wo, Ct)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, Ho, Wo, Ct = ctx.out_shape
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            d = torch.empty(shp, device=g.device, dtype=torch.float32)
+            hip.call("fs_upsample_slice_bwd", hip.ptr(g), B, Ho, Wo, Ct, off, hip.ptr(d), shp[1], shp[2], shp[3])
+            grads.append(d)
+            off += shp[3]
+        return tuple(grads)
+
+
+# ----------------------------------------------------------------------------------------------
+# C1 tail
+# ----------------------------------------------------------------------------------------------
+class MaskHead(Function):
+    """m = sigmoid(conv1x1(x) + b) - 0.5; x (B,H,W,C) -> m (B,H,W)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        B, H, W, C = x.shape
+        m = torch.empty(B, H, W, device=x.device, dtype=torch.float32)
+        hip.call("fs_mask_head_fwd", hip.ptr(x), hip.ptr(w), hip.ptr(bias), hip.ptr(m), B * H * W, C)
+        ctx.save_for_backward(x, w, m)
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        x, w, m = ctx.saved_tensors
+        dm = dm.contiguous()
+        C = x.shape[-1]
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty(1, device=x.device, dtype=torch.float32)
+        hip.call("fs_mask_head_bwd", hip.ptr(dm), hip.ptr(m), hip.ptr(x), hip.ptr(w), hip.ptr(dx), hip.ptr(dw), hip.ptr(db),
+                 m.numel(), C)
+        return dx, dw, db
+
+
+class AvgPoolHW(Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C = x.shape
+        out = torch.empty(B, C, device=x.device, dtype=torch.float32)
+        hip.call("fs_avgpool_fwd", hip.ptr(x), B, H * W, C, hip.ptr(out))
+        ctx.shape = (B, H, W, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, C = ctx.shape
+        dx = torch.empty(B, H, W, C, device=g.device, dtype=torch.float32)
+        hip.call("fs_avgpool_bwd", hip.ptr(g.contiguous()), B, H * W, C, hip.ptr(dx))
+        return dx
+
+
+class PredAssemble(Function):
+    """pred (B,K,H,W): channels < K-1 = class logits broadcast, channel K-1 = logit * mask."""
+
+    @staticmethod
+    def forward(ctx, cls, m):
+        B, K = cls.shape
+        _, H, W = m.shape
+        pred = torch.empty(B, K, H, W, device=cls.device, dtype=torch.float32)
+        hip.call("fs_pred_assemble_fwd", hip.ptr(cls), hip.ptr(m), hip.ptr(pred), B, K, H * W)
+        ctx.save_for_backward(cls, m)
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        cls, m = ctx.saved_tensors
+        B, K = cls.shape
+        dcls = torch.empty_like(cls)
+        dm = torch.empty_like(m)
+        hip.call("fs_pred_assemble_bwd", hip.ptr(dpred.contiguous()), hip.ptr(cls), hip.ptr(m), hip.ptr(dcls), hip.ptr(dm), B, K,
+                 m.shape[1] * m.shape[2])
+        return dcls, dm
+
+
+class SegLoss(Function):
+    """(pred (B,K,H,W), gt (B,H,W) int64) -> 7 scalars {dice+focal, focal, dice, 4 accuracies};
+    only element 0 carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, gamma):
+        B, K, H, W = pred.shape
+        accum = torch.empty(3 * K + 1 + 6 * B, device=pred.device, dtype=torch.float64)
+        out = torch.empty(7, device=pred.device, dtype=torch.float32)
+        coef = torch.empty(2 * K, device=pred.device, dtype=torch.float32)
+        hip.call("fs_seg_loss_fwd", hip.ptr(pred), hip.ptr(gt), B, K, H * W, float(gamma), 1e-7, hip.ptr(accum), hip.ptr(out),
+                 hip.ptr(coef))
+        ctx.save_for_backward(pred, gt, coef)
+        ctx.gamma = float(gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, gt, coef = ctx.saved_tensors
+        B, K, H, W = pred.shape
+        g0 = gout[0:1].contiguous()
+        dpred = torch.empty_like(pred)
+        hip.call("fs_seg_loss_bwd", hip.ptr(pred), hip.ptr(gt), hip.ptr(coef), hip.ptr(g0), hip.ptr(dpred), B, K, H * W, ctx.gamma)
+        return dpred, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# foveation front-end
+# ----------------------------------------------------------------------------------------------
+def gaze_lowres(x, focus, hs, ws):
+    B, C, H, W = x.shape
+    assert C == 3
+    out = torch.empty(B, hs, ws, 5, device=x.device, dtype=torch.float32)
+    hip.call("fs_gaze_lowres_fwd", hip.ptr(x), hip.ptr(focus), hip.ptr(out), B, H, W, hs, ws)
+    return out
+
+
+class CompressSoftmax(Function):
+    """xs = softmax_HW(conv1x1(relu(s)) + b): s (B,H,W,C) -> xs (B,1,H,W)."""
+
+    @staticmethod
+    def forward(ctx, s, w, bias):
+        B, H, W, C = s.shape
+        xs = torch.empty(B, 1, H, W, device=s.device, dtype=torch.float32)
+        hip.call("fs_compress_softmax_fwd", hip.ptr(s), hip.ptr(w), hip.ptr(bias), hip.ptr(xs), B, H * W, C)
+        ctx.save_for_backward(s, w, xs)
+        return xs
+
+    @staticmethod
+    def backward(ctx, g):
+        s, w, xs = ctx.saved_tensors
+        B, H, W, C = s.shape
+        ds = torch.empty_like(s)
+        dw = torch.empty_like(w)
+        db = torch.empty(1, device=s.device, dtype=torch.float32)
+        hip.call("fs_compress_softmax_bwd", hip.ptr(g.contiguous()), hip.ptr(xs), hip.ptr(s), hip.ptr(w), hip.ptr(ds), hip.ptr(dw),
+                 hip.ptr(db), B, H * W, C)
+        return ds, dw, db
+
+
+def area_pool(y, hs, ws):
+    B, C, H, W = y.shape
+    assert C == 1
+    out = torch.empty(B, 1, hs, ws, device=y.device, dtype=torch.float32)
+    hip.call("fs_area_pool_fwd", hip.ptr(y), hip.ptr(out), B, H, W, hs, ws)
+    return out
+
+
+class EdgeLoss(Function):
+    @staticmethod
+    def forward(ctx, xs, target, coef):
+        loss = torch.empty(1, device=xs.device, dtype=torch.float32)
+        stats = torch.empty(6, device=xs.device, dtype=torch.float32)
+        hip.call("fs_edge_loss_fwd", hip.ptr(xs), hip.ptr(target), xs.numel(), float(coef), hip.ptr(loss), hip.ptr(stats))
+        ctx.save_for_backward(xs, target, stats)
+        ctx.coef = float(coef)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, target, stats = ctx.saved_tensors
+        dxs = torch.empty_like(xs)
+        hip.call("fs_edge_loss_bwd", hip.ptr(xs), hip.ptr(target), xs.numel(), ctx.coef, hip.ptr(g.reshape(1).contiguous()),
+                 hip.ptr(stats), hip.ptr(dxs))
+        return dxs, None, None
+
+
+class GaussGrid(Function):
+    """xs (B,1,hs,ws) -> grid (B,hs,ws,2); g1d = separable Gaussian taps (float64, device)."""
+
+    @staticmethod
+    def forward(ctx, xs, g1d, pad):
+        B, _, hs, ws = xs.shape
+        grid = torch.empty(B, hs, ws, 2, device=xs.device, dtype=torch.float32)
+        hip.call("fs_gauss_grid_fwd", hip.ptr(xs), hip.ptr(g1d), hip.ptr(grid), B, hs, ws, pad)
+        ctx.save_for_backward(xs, g1d)
+        ctx.pad = pad
+        return grid
+
+    @staticmethod
+    def backward(ctx, dgrid):
+        xs, g1d = ctx.saved_tensors
+        B, _, hs, ws = xs.shape
+        dxs = torch.empty_like(xs)
+        hip.call("fs_gauss_grid_bwd", hip.ptr(xs), hip.ptr(g1d), hip.ptr(dgrid.contiguous()), hip.ptr(dxs), B, hs, ws, ctx.pad)
+        return dxs, None, None
+
+
+class GridSample(Function):
+    """x (B,C,H,W) NCHW, grid (B,h,w,2) -> (B,h,w,C) NHWC; gradient w.r.t. the grid (and, when asked,
+    w.r.t. x by scatter-add)."""
+
+    @staticmethod
+    def forward(ctx, x, grid):
+        B, C, H, W = x.shape
+        _, h, w, _ = grid.shape
+        out = torch.empty(B, h, w, C, device=x.device, dtype=torch.float32)
+        hip.call("fs_grid_sample_fwd", hip.ptr(x), hip.ptr(grid), hip.ptr(out), B, C, H, W, h, w, 1)
+        ctx.save_for_backward(x, grid)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, grid = ctx.saved_tensors
+        B, C, H, W = x.shape
+        _, h, w, _ = grid.shape
+        gout = gout.contiguous()
+        dx = dgrid = None
+        if ctx.needs_input_grad[1]:
+            dgrid = torch.empty_like(grid)
+            hip.call("fs_grid_sample_bwd_grid", hip.ptr(gout), hip.ptr(x), hip.ptr(grid), hip.ptr(dgrid), B, C, H, W, h, w, 1)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            hip.call("fs_grid_sample_bwd_input", hip.ptr(gout), hip.ptr(grid), hip.ptr(dx), B, C, H, W, h, w, 1)
+        return dx, dgrid
+
+
+def grid_sample_label(y, grid, return_float=False):
+    B, C, H, W = y.shape
+    assert C == 1
+    _, h, w, _ = grid.shape
+    label = torch.empty(B, h, w, device=y.device, dtype=torch.int64)
+    ys = torch.empty(B, h, w, device=y.device, dtype=torch.float32) if return_float else None
+    hip.call("fs_grid_sample_label", hip.ptr(y), hip.ptr(grid), hip.ptr(label), hip.ptr(ys), B, H, W, h, w)
+    return (label, ys) if return_float else label
+
+
+def inverse_index_maps(grid, H, W):
+    n = grid.numel() // 2
+    u = torch.empty(grid.shape[:-1], device=grid.device, dtype=torch.int64)
+    v = torch.empty_like(u)
+    hip.call("fs_inverse_index_maps", hip.ptr(grid), hip.ptr(u), hip.ptr(v), n, H, W)
+    return u, v

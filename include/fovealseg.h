@@ -1,0 +1,122 @@
+/* fovealseg.h -- C ABI of libfovealseg_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary of the FovealSeg forward/backward hot path.  The reference has no FFI: every op on
+ * this path is an ATen call made from Python (models/models.py:666-1094 and the modules it drives).
+ * Each entry point below replaces one such call (or a fixed group of them); the citation after each
+ * prototype names the reference call site it stands in for (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (PyTorch caching allocator);
+ *     the library never allocates, frees or synchronises;
+ *   - activations are NHWC fp32 (B,H,W,C) unless a prototype says NCHW; conv weights are RSCK
+ *     ([R][S][Cin][Cout]) -- the physical layout behind the reference's logical (Cout,Cin,R,S) shape;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and return immediately;
+ *   - return value: 0 on success, 1001 (FS_ERR_ARG) for a rejected shape/pointer, otherwise the
+ *     hipError_t of the failed launch.  Nothing is launched when an argument is rejected.
+ *   - ACT codes: 0 none, 1 ReLU, 2 ReLU6.
+ */
+#ifndef FOVEALSEG_H
+#define FOVEALSEG_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fs_stream_t;
+
+/* ---- foveation front-end ------------------------------------------------------------------ */
+/* x (B,3,H,W) NCHW, focus (B,2)=(row,col) -> out (B,hs,ws,5): bilinear RGB + 2x squared gaze distance.
+ * models/models.py:684-705 (gen_grid_mtx_2xHxW, sqrt/square, b_imresize, 2x cat). */
+int fs_gaze_lowres_fwd(const float* x, const float* focus, float* out, int B, int H, int W, int hs, int ws, fs_stream_t stream);
+/* s (B,HW,C) -> xs (B,HW) = softmax_HW(w . relu(s) + bias).  models/models.py:369-372,715-723. */
+int fs_compress_softmax_fwd(const float* s, const float* w, const float* bias, float* xs, int B, int HW, int C, fs_stream_t stream);
+int fs_compress_softmax_bwd(const float* g, const float* xs, const float* s, const float* w, float* ds, float* dw, float* db,
+                            int B, int HW, int C, fs_stream_t stream);
+/* y (B,1,H,W) -> (B,1,hs,ws) adaptive area average.  models/models.py:730. */
+int fs_area_pool_fwd(const float* y, float* out, int B, int H, int W, int hs, int ws, fs_stream_t stream);
+/* loss = coef * mean((minmax(xs) - minmax(t))^2) with whole-batch min/max; stats = 6 floats kept for bwd.
+ * models/models.py:889-891,898 (coef = 0.05 * edge_loss_scale). */
+int fs_edge_loss_fwd(const float* xs, const float* t, long n, float coef, float* loss, float* stats, fs_stream_t stream);
+int fs_edge_loss_bwd(const float* xs, const float* t, long n, float coef, const float* gout, const float* stats, float* dxs,
+                     fs_stream_t stream);
+/* xs (B,hs,ws) -> grid (B,hs,ws,2)=(x,y) in [-1,1]: replication pad + Gaussian-weighted centroid + clamp.
+ * g1d = the 2*pad+1 separable Gaussian taps (double).  models/models.py:594-637,819-821. */
+int fs_gauss_grid_fwd(const float* xs, const double* g1d, float* grid, int B, int hs, int ws, int pad, fs_stream_t stream);
+int fs_gauss_grid_bwd(const float* xs, const double* g1d, const float* dgrid, float* dxs, int B, int hs, int ws, int pad,
+                      fs_stream_t stream);
+/* F.grid_sample(x, grid): bilinear / zeros / align_corners=False, bit-exact with ATen-CPU.
+ * x (B,C,H,W) NCHW; out (B,h,w,C) if nhwc_out else (B,C,h,w).  models/models.py:909. */
+int fs_grid_sample_fwd(const float* x, const float* grid, float* out, int B, int C, int H, int W, int h, int w, int nhwc_out,
+                       fs_stream_t stream);
+/* label = trunc(F.grid_sample(y, grid)) as int64; ysamp (nullable) gets the float sample.  models/models.py:880,951. */
+int fs_grid_sample_label(const float* y, const float* grid, long long* label, float* ysamp, int B, int H, int W, int h, int w,
+                         fs_stream_t stream);
+/* autograd of grid_sample w.r.t. grid / w.r.t. input (scatter-add, dx overwritten). */
+int fs_grid_sample_bwd_grid(const float* gout, const float* x, const float* grid, float* dgrid, int B, int C, int H, int W, int h,
+                            int w, int nhwc, fs_stream_t stream);
+int fs_grid_sample_bwd_input(const float* gout, const float* grid, float* dx, int B, int C, int H, int W, int h, int w, int nhwc,
+                             fs_stream_t stream);
+/* u=int((gx+1)/2*(W-1)), v=int((gy+1)/2*(H-1)) for n grid points.  models/models.py:644-645. */
+int fs_inverse_index_maps(const float* grid, long long* u, long long* v, long n, int H, int W, fs_stream_t stream);
+
+/* ---- convolution engine (fp32 MFMA implicit GEMM) --------------------------------------------- */
+/* F.conv2d(x, w, bias, stride, pad) [+ Dropout(drop_p) keyed by drop_key when drop_p > 0].
+ * models/hrnetv2_nodownsp.py:49-50,54-55 and every nn.Conv2d on the path. */
+int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Ho, int Wo,
+                  int Cout, int R, int S, int stride, int pad, float drop_p, uint32_t drop_key, fs_stream_t stream);
+/* convolution_backward: input gradient / weight gradient (dw overwritten). */
+int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R,
+                       int S, int stride, int pad, fs_stream_t stream);
+int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                         int R, int S, int stride, int pad, fs_stream_t stream);
+
+/* ---- BatchNorm / activation / residual ------------------------------------------------------ */
+/* F.batch_norm(training=True) statistics over M rows; running stats updated in place (nullable).
+ * lib/nn/modules/batchnorm.py:56-61.  sums = 2*C doubles scratch. */
+int fs_bn_stats(const float* y, long M, int C, float momentum, float eps, float* running_mean, float* running_var, float* mean,
+                float* invstd, double* sums, fs_stream_t stream);
+int fs_bn_eval_prepare(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* invstd,
+                       fs_stream_t stream);
+/* out = act((y-mean)*invstd*gamma + beta [+ res]).  models/hrnetv2_nodownsp.py:51-52,56-62. */
+int fs_bn_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* res,
+                  float* out, long M, int C, int act, fs_stream_t stream);
+int fs_bn_act_bwd(const float* dz, const float* z, const float* y, const float* mean, const float* invstd, const float* gamma,
+                  long M, int C, int act, int training, float drop_p, uint32_t drop_key, float* dy, float* dres, float* dgamma,
+                  float* dbeta, double* sums, fs_stream_t stream);
+
+/* ---- HRNet multi-resolution fuse / concat ------------------------------------------------------ */
+/* out = [relu](sum_t up(terms[t])), terms at (th[t],tw[t]) bilinearly up-sampled (align_corners=False).
+ * models/hrnetv2_nodownsp.py:235-251.  terms/th/tw are HOST arrays of length nterms (<= 4). */
+int fs_hr_fuse_fwd(const float* const* terms, const int* th, const int* tw, int nterms, float* out, int B, int Ho, int Wo, int C,
+                   int relu, fs_stream_t stream);
+int fs_relu_bwd(const float* dout, const float* out, float* g, long n, fs_stream_t stream);
+/* dst[..., coff:coff+C] = up(src); models/hrnetv2_nodownsp.py:434-442 (interpolate + cat). */
+int fs_upsample_slice_fwd(const float* src, int B, int th, int tw, int C, float* dst, int Ho, int Wo, int Cdst, int coff,
+                          fs_stream_t stream);
+int fs_upsample_slice_bwd(const float* g, int B, int Ho, int Wo, int Cg, int coff, float* dsrc, int th, int tw, int C,
+                          fs_stream_t stream);
+int fs_colsum(const float* x, long M, int C, float* out, fs_stream_t stream);
+/* AvgPool2d((10,10)) on a 10x10 map.  models/model_utils.py:254,272. */
+int fs_avgpool_fwd(const float* x, int B, int HW, int C, float* out, fs_stream_t stream);
+int fs_avgpool_bwd(const float* dout, int B, int HW, int C, float* dx, fs_stream_t stream);
+
+/* ---- C1 head tail + losses --------------------------------------------------------------------- */
+/* m = sigmoid(w . x + bias) - 0.5 per pixel.  models/model_utils.py:293-298. */
+int fs_mask_head_fwd(const float* x, const float* w, const float* bias, float* m, long npix, int C, fs_stream_t stream);
+int fs_mask_head_bwd(const float* dm, const float* m, const float* x, const float* w, float* dx, float* dw, float* db, long npix,
+                     int C, fs_stream_t stream);
+/* pred (B,K,HW) NCHW: pred[:, :K-1] = cls, pred[:, K-1] = cls[K-1]*m.  models/model_utils.py:300-306. */
+int fs_pred_assemble_fwd(const float* cls, const float* m, float* pred, int B, int K, int HW, fs_stream_t stream);
+int fs_pred_assemble_bwd(const float* dpred, const float* cls, const float* m, float* dcls, float* dm, int B, int K, int HW,
+                         fs_stream_t stream);
+/* out[7] = {dice+focal, focal, dice, acc, acc_bin_fg, acc_cls_fbg, acc_bin_fbg}; models/models.py:87-120,378-474,1057-1078.
+ * accum = (3K+1+6B) doubles scratch, coef = 2K floats kept for the backward. */
+int fs_seg_loss_fwd(const float* pred, const long long* gt, int B, int K, int HW, float gamma, float eps, double* accum,
+                    float* out, float* coef, fs_stream_t stream);
+int fs_seg_loss_bwd(const float* pred, const long long* gt, const float* coef, const float* gout, float* dpred, int B, int K,
+                    int HW, float gamma, fs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

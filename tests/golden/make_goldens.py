@@ -243,21 +243,35 @@ def main():
         _, Fp, Y, cls = synth_batch(2, 256, 256, seed=112)
         feed = {"img_data": X, "seg_label": Y.clone(), "focus_point": Fp, "cls_label": cls}
         m.zero_grad()
+        captured = {}
+        orig_cg = m.create_grid
+
+        def capture_grid(*a, _o=orig_cg, **k):
+            out = _o(*a, **k)
+            if "segSize" not in k and "grid" not in captured:
+                captured["grid"] = out[0].detach().clone()
+            return out
+        m.create_grid = capture_grid
         if mode == "eval":
             with torch.no_grad():
                 outs = m(feed, is_inference=True, rank=1, cur_iter=0)
             save("g11_e2e_eval", x=X, y=Y, focus=Fp, cls=cls, outs=torch.stack([o.float() for o in outs]),
-                 label=feed["seg_label"])
+                 label=feed["seg_label"], grid=captured["grid"])
         else:
             loss, acc, edge = m(feed, rank=1, cur_iter=0)
             loss.mean().backward()
             gn = {k: p.grad.norm() for k, p in m.named_parameters()
                   if k in ("localization.fov_expand_1.weight", "encoder.conv1.weight",
                            "decoder.conv_last.weight", "net_compress.conv_last.weight",
-                           "encoder.stage4.2.branches.3.3.conv2.weight", "decoder.cls_net.fc.weight")}
+                           "encoder.stage4.2.branches.3.3.conv2.weight", "decoder.cls_net.fc.weight",
+                           "encoder.layer1.0.conv2.weight", "encoder.stage2.0.fuse_layers.1.0.0.0.weight",
+                           "encoder.stage3.2.branches.1.1.bn2.weight", "encoder.transition2.2.0.0.weight",
+                           "decoder.cbr.0.weight", "decoder.cls_net.layer2.0.conv1.0.bias",
+                           "localization.norm2.bias")}
             save("g11_e2e_train_p0", x=X, y=Y, focus=Fp, cls=cls, outs=torch.stack([loss, acc, edge]),
                  label=feed["seg_label"], gn_names=np.array(list(gn.keys())),
-                 gn=torch.stack(list(gn.values())))
+                 gn=torch.stack(list(gn.values())), grid=captured["grid"])
+        del m.create_grid
     for d in m.modules():
         if isinstance(d, torch.nn.Dropout):
             d.p = 0.3

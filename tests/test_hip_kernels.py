@@ -1,0 +1,570 @@
+"""GPU parity tests: every HIP kernel (through the C ABI) against the CPU oracle / torch-CPU fp32 and
+the committed golden fixtures.  Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+Tolerances: bit-exact for integer/index work and grid_sample forward; fp32 otherwise, stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import fovealseg  # noqa: E402
+from fovealseg import ops  # noqa: E402
+import fovealseg_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def nhwc(x):          # (B,C,H,W) cpu -> (B,H,W,C) device contiguous
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def nchw(x):          # (B,H,W,C) device -> (B,C,H,W) cpu
+    return x.detach().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rsck_param(w):    # logical (Co,Ci,R,S) cpu -> device tensor with RSCK storage
+    p = ops.new_rsck_weight(*w.shape, device=DEV)
+    p.copy_(w)
+    return p
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution engine
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, bias
+    (2, 20, 20, 64, 64, 3, 1, False),
+    (3, 17, 13, 3, 64, 3, 1, False),       # stem, scalar path, ragged M
+    (2, 16, 16, 5, 192, 3, 1, False),      # saliency first layer
+    (2, 16, 16, 192, 24, 3, 1, False),     # Cout < tile
+    (2, 20, 20, 64, 128, 3, 2, False),     # stride 2
+    (2, 20, 20, 256, 64, 1, 1, False),     # 1x1
+    (1, 12, 12, 960, 240, 3, 1, False),    # C1 cbr
+    (2, 20, 20, 96, 512, 3, 4, True),      # cls_net stride 4 + bias
+    (2, 20, 20, 96, 64, 1, 4, True),       # 1x1 stride 4 downsample
+    (5, 1, 1, 512, 51, 1, 1, True),        # FC as 1x1 conv, scalar path
+    (1, 10, 10, 512, 512, 3, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case):
+    B, H, W, Ci, Co, k, s, has_bias = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    b = torch.randn(Co, generator=g) if has_bias else None
+    pad = k // 2
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, b, s, pad)
+    cot = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(cot)
+
+    xd, wd = nhwc(x), rsck_param(w)
+    bd = b.to(DEV) if has_bias else None
+    y = ops.conv2d_fwd(xd, wd, bd, s, pad)
+    assert relerr(nchw(y), y_ref.detach()) <= 2e-5
+    dyd = nhwc(cot)
+    dx = ops.conv2d_bwd_data(dyd, wd, xd.shape, s, pad)
+    assert relerr(nchw(dx), xr.grad) <= 2e-5
+    dw = ops.conv2d_bwd_weight(xd, dyd, w.shape, s, pad)
+    assert dw.shape == w.shape
+    assert relerr(dw.cpu(), wr.grad) <= 5e-5
+
+
+def test_conv_rejects_bad_shapes():
+    x = torch.zeros(1, 4, 4, 4, device=DEV)
+    w = ops.new_rsck_weight(4, 4, 3, 3, device=DEV)
+    y = torch.zeros(1, 5, 5, 4, device=DEV)       # wrong output size
+    with pytest.raises(fovealseg.hip.HipLibraryError):
+        fovealseg.hip.call("fs_conv2d_fwd", x.data_ptr(), ops.rsck(w).data_ptr(), None, y.data_ptr(), 1, 4, 4, 4, 5, 5, 4, 3, 3, 1, 1, 0.0, 0)
+    with pytest.raises(fovealseg.hip.HipLibraryError):
+        ops.conv2d_fwd(torch.zeros(1, 4, 4, 4), w, None, 1, 1)   # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("act,use_res,drop", [(1, True, 0.3), (2, False, 0.0), (0, False, 0.0)])
+def test_conv_bn_act(training, act, use_res, drop):
+    B, C, H, W = 3, 64, 12, 12
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / 24.0
+    gamma = 0.5 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    rm = 0.1 * torch.randn(C, generator=g)
+    rv = 1 + 0.1 * torch.rand(C, generator=g)
+    res = torch.randn(B, C, H, W, generator=g) if use_res else None
+    key = ops.layer_key(123, 456)
+
+    # ---- oracle side (torch CPU) ----
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if use_res else None
+    y = F.conv2d(xr, wr, None, 1, 1)
+    if training and drop > 0:
+        keep = O.dropout_keep_mask_nhwc(B * H * W * C, key, drop).reshape(B, H, W, C)
+        mask = torch.from_numpy(keep).permute(0, 3, 1, 2).float() * np.float32(1.0 / (1.0 - drop))
+        y = y * mask
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = F.batch_norm(y, rm_ref, rv_ref, gr, br, training, 0.1, 1e-5)
+    if use_res:
+        z = z + rr
+    z = F.relu(z) if act == 1 else (F.relu6(z) if act == 2 else z)
+    cot = torch.randn(z.shape, generator=g)
+    z.backward(cot)
+
+    # ---- HIP side ----
+    xd = nhwc(x).requires_grad_(True)
+    wd = rsck_param(w).requires_grad_(True)
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    rd = nhwc(res).requires_grad_(True) if use_res else None
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+
+    class Cnt:
+        n = 0
+
+        def add_(self, k):
+            self.n += k
+    meta = dict(stride=1, pad=1, act=act, training=training, momentum=0.1, drop_p=drop, drop_key=key,
+                running_mean=rmd, running_var=rvd, num_batches_tracked=Cnt())
+    zd = ops.ConvBnAct.apply(xd, wd, None, gd, bd, rd, meta)
+    zd.backward(nhwc(cot))
+    assert relerr(nchw(zd), z.detach()) <= 2e-5
+    assert relerr(nchw(xd.grad), xr.grad) <= 1e-4
+    assert relerr(wd.grad.cpu(), wr.grad) <= 1e-4
+    assert relerr(gd.grad.cpu(), gr.grad) <= 1e-4
+    assert relerr(bd.grad.cpu(), br.grad) <= 1e-4
+    if use_res:
+        assert relerr(nchw(rd.grad), rr.grad) <= 1e-5
+    if training:
+        assert relerr(rmd.cpu(), rm_ref) <= 1e-5 and relerr(rvd.cpu(), rv_ref) <= 1e-5
+        assert meta["num_batches_tracked"].n == 1
+
+
+# ------------------------------------------------------------------------------------------------
+# front-end
+# ------------------------------------------------------------------------------------------------
+def test_gaze_lowres_g2(golden):
+    g = golden("g2_lowres_128")
+    out = ops.gaze_lowres(T(g["x"]).to(DEV), T(g["focus"]).to(DEV), 80, 80)
+    assert np.abs(nchw(out).numpy() - g["x_low"]).max() <= 1e-6
+    g = golden("g2_lowres_640")
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    X = torch.rand(2, 3, 640, 640, generator=gen)
+    out = ops.gaze_lowres(X.to(DEV), T(g["focus"]).to(DEV), 80, 80)
+    assert np.abs(nchw(out).numpy() - g["x_low"]).max() <= 1e-6
+
+
+def test_compress_softmax():
+    g = torch.Generator().manual_seed(3)
+    s = torch.randn(3, 24, 80, 80, generator=g)
+    w = torch.randn(1, 24, 1, 1, generator=g) * 0.3
+    b = torch.randn(1, generator=g)
+    sr, wr, br = s.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xs_ref = F.softmax(F.conv2d(F.relu(sr), wr, br).view(3, -1), 1).view(3, 1, 80, 80)
+    cot = torch.randn(xs_ref.shape, generator=g)
+    xs_ref.backward(cot)
+    sd = nhwc(s).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    xs = ops.CompressSoftmax.apply(sd, wd, bd)
+    xs.backward(cot.to(DEV))
+    assert np.abs(xs.detach().cpu().numpy() - xs_ref.detach().numpy()).max() <= 1e-7
+    assert abs(float(xs.sum()) - 3.0) <= 1e-4
+    assert relerr(nchw(sd.grad), sr.grad) <= 1e-4
+    assert relerr(wd.grad.cpu(), wr.grad) <= 1e-4
+    assert abs(float(bd.grad) - float(br.grad)) <= 1e-6      # softmax is shift-invariant: d/db == 0
+
+
+def test_g3_saliency_stack(golden):
+    g = golden("g3_saliency")
+    cfg = fovealseg.lvis50_cfg()
+    sal = fovealseg.ModelBuilder.build_net_saliency(cfg)
+    comp = fovealseg.ModelBuilder.build_net_compress(cfg)
+    for mode in ("eval", "train"):
+        fovealseg.weights.apply_name_keyed_init(sal, "localization.")
+        fovealseg.weights.apply_name_keyed_init(comp, "net_compress.")
+        sal.to(DEV).train(mode == "train")
+        with torch.no_grad():
+            xs = comp.to(DEV).softmax_nhwc(sal.forward_nhwc(nhwc(T(g["x_low"]))))
+        assert np.abs(xs.cpu().numpy() - g["xs_" + mode]).max() <= 2e-7
+
+
+def test_area_pool_and_edge_loss_g10(golden):
+    g = golden("g10_losses")
+    gen = torch.Generator().manual_seed(int(g["y_seed"]))
+    torch.rand(3, 3, 256, 256, generator=gen)
+    Fp = torch.rand(3, 2, generator=gen) * 0.8 + 0.1
+    ii = torch.arange(256, dtype=torch.float32)
+    cy, cx = (Fp[:, 0] * 255)[:, None, None], (Fp[:, 1] * 255)[:, None, None]
+    Y = (((ii[None, :, None] - cy) ** 2 + (ii[None, None, :] - cx) ** 2) <= (0.15 * 256) ** 2).float().unsqueeze(1)
+    t = ops.area_pool(Y.to(DEV), 80, 80)
+    assert np.abs(t.cpu().numpy() - g["area"]).max() <= 1e-6
+    # non-binary, non-divisible sizes
+    R = torch.rand(2, 1, 333, 517)
+    tr = ops.area_pool(R.to(DEV), 80, 80)
+    assert np.abs(tr.cpu().numpy() - F.interpolate(R, size=(80, 80), mode="area").numpy()).max() <= 1e-6
+    xs = T(g["xs"]).to(DEV).requires_grad_(True)
+    el = ops.EdgeLoss.apply(xs, t, 0.05 * 100.0)
+    el.backward()
+    assert abs(float(el) - float(g["edge"])) <= 1e-6
+    assert relerr(xs.grad.cpu(), T(g["dxs"])) <= 1e-4
+
+
+def test_gauss_grid_g4(golden):
+    g = golden("g4_grid")
+    g1d = torch.from_numpy(O.gaussian_1d(91, 45)).to(DEV)
+    xs = T(g["xs"]).to(DEV).requires_grad_(True)
+    grid = ops.GaussGrid.apply(xs, g1d, 45)
+    got = grid.detach().cpu().numpy()
+    assert np.abs(got - g["grid"]).max() <= 3e-5          # reference fp32 (itself 1.75e-5 from fp64)
+    x64 = T(g["xs"]).double().requires_grad_(True)
+    g64 = O.create_grid_f64(x64, 45)
+    assert np.abs(got - g64.detach().numpy()).max() <= 3e-6    # fp64 evaluation of the same formula
+    assert got.min() >= -1.0 and got.max() <= 1.0
+    # backward, random-saliency samples: well conditioned, must match the reference's own autograd
+    grid.backward(T(g["cot"]).to(DEV))
+    assert relerr(xs.grad.cpu()[:2], T(g["dxs"])[:2]) <= 1e-4
+    # backward, all samples, against the fp64 evaluation.  A uniform background + replication padding
+    # puts every border grid point EXACTLY on the clamp bound (centroid of a symmetric window), where
+    # rounding noise decides the clamp mask (the reference's own fp32 gradient is 12 % from fp64 there);
+    # those points get a zero cotangent so the comparison is well conditioned.
+    safe = ((g64.detach().abs() - 1).abs() > 1e-4).to(torch.float64)
+    cot = T(g["cot"]).double() * safe
+    (g64 * cot).sum().backward()
+    xs2 = T(g["xs"]).to(DEV).requires_grad_(True)
+    ops.GaussGrid.apply(xs2, g1d, 45).backward(cot.float().to(DEV))
+    assert relerr(xs2.grad.cpu(), x64.grad.float()) <= 1e-4
+
+
+@pytest.mark.parametrize("tag", ["128x128", "200x136"])
+def test_grid_sample_g5_bitexact(golden, tag):
+    g = golden("g5_gridsample_" + tag)
+    x, y, grid = T(g["x"]).to(DEV), T(g["y"]).to(DEV), T(g["grid"]).to(DEV).requires_grad_(True)
+    out = ops.GridSample.apply(x, grid)
+    assert np.array_equal(nchw(out).numpy(), g["x_sampled"])             # bit-exact fp32
+    label, ys = ops.grid_sample_label(y, grid.detach(), return_float=True)
+    assert np.array_equal(ys.cpu().numpy(), g["y_sampled"])
+    assert np.array_equal(label.cpu().numpy(), g["label"])                 # bit-exact int64
+    out.backward(nhwc(T(g["cot"])))
+    assert np.abs(grid.grad.cpu().numpy() - g["dgrid"]).max() <= 1e-6 * max(1.0, np.abs(g["dgrid"]).max())
+
+
+def test_grid_sample_bwd_input():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 40, 56, generator=g)
+    grid = torch.rand(2, 16, 16, 2, generator=g) * 2.2 - 1.1
+    xr = x.clone().requires_grad_(True)
+    out_ref = F.grid_sample(xr, grid, align_corners=False)
+    cot = torch.randn(out_ref.shape, generator=g)
+    out_ref.backward(cot)
+    xd = x.to(DEV).requires_grad_(True)
+    out = ops.GridSample.apply(xd, grid.to(DEV))
+    out.backward(nhwc(cot))
+    assert relerr(xd.grad.cpu(), xr.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("H", [128, 640])
+def test_inverse_index_maps_g6(golden, H):
+    g = golden(f"g6_inverse_{H}")
+    u, v = ops.inverse_index_maps(T(g["grid"]).to(DEV), H, H)
+    assert np.array_equal(u.cpu().numpy(), g["u"]) and np.array_equal(v.cpu().numpy(), g["v"])
+
+
+# ------------------------------------------------------------------------------------------------
+# fuse / concat / head / loss
+# ------------------------------------------------------------------------------------------------
+def test_hr_fuse_and_concat():
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    xs = [torch.randn(B, 32, 16, 16, generator=g), torch.randn(B, 32, 8, 8, generator=g),
+          torch.randn(B, 32, 4, 4, generator=g), torch.randn(B, 32, 2, 2, generator=g)]
+    xr = [t.clone().requires_grad_(True) for t in xs]
+    y = xr[0]
+    for t in xr[1:]:
+        y = y + F.interpolate(t, size=(16, 16), mode="bilinear", align_corners=False)
+    y = F.relu(y)
+    cot = torch.randn(y.shape, generator=g)
+    y.backward(cot)
+    xd = [nhwc(t).requires_grad_(True) for t in xs]
+    out = ops.HrFuse.apply(16, 16, *xd)
+    out.backward(nhwc(cot))
+    assert relerr(nchw(out), y.detach()) <= 1e-6
+    for a, b in zip(xd, xr):
+        assert relerr(nchw(a.grad), b.grad) <= 1e-5
+    # concat
+    xr = [t.clone().requires_grad_(True) for t in xs]
+    cat = torch.cat([xr[0]] + [F.interpolate(t, size=(16, 16), mode="bilinear", align_corners=False) for t in xr[1:]], 1)
+    cot = torch.randn(cat.shape, generator=g)
+    cat.backward(cot)
+    xd = [nhwc(t).requires_grad_(True) for t in xs]
+    out = ops.UpsampleConcat.apply(*xd)
+    out.backward(nhwc(cot))
+    assert relerr(nchw(out), cat.detach()) <= 1e-6
+    for a, b in zip(xd, xr):
+        assert relerr(nchw(a.grad), b.grad) <= 1e-5
+
+
+def test_seg_loss_g10(golden):
+    g = golden("g10_losses")
+    pred = T(g["pred"]).to(DEV).requires_grad_(True)
+    gt = T(g["gt"]).to(DEV)
+    out = ops.SegLoss.apply(pred, gt, 5.0)
+    out[0].backward()
+    o = out.detach().cpu().numpy()
+    assert abs(o[1] - float(g["focal"])) <= 1e-6 and abs(o[2] - float(g["dice"])) <= 1e-6
+    assert np.abs(o[3:7] - g["accs"]).max() <= 1e-6
+    assert np.abs(pred.grad.cpu().numpy() - g["dpred"]).max() <= 1e-6 * max(1.0, np.abs(g["dpred"]).max())
+
+
+def _hip_module():
+    cfg = fovealseg.lvis50_cfg()
+    MB = fovealseg.ModelBuilder
+    m = fovealseg.DeformSegmentationModule(MB.build_encoder("hrnetv2_nodownsp", 960, ""), MB.build_decoder("c1", 960, 51, ""),
+                                           MB.build_net_saliency(cfg), MB.build_net_compress(cfg), None, cfg)
+    fovealseg.weights.apply_name_keyed_init(m)
+    return m.to(DEV)
+
+
+@pytest.fixture(scope="module")
+def hipmod():
+    return _hip_module()
+
+
+def _sub(m, path):
+    for p in path.split("."):
+        m = m[int(p)] if p.isdigit() else getattr(m, p)
+    return m
+
+
+def _set_drop(m, p):
+    for d in m.modules():
+        if hasattr(d, "drop_p"):
+            d.drop_p = p
+
+
+@pytest.mark.parametrize("name", ["basic", "bottleneck", "hrmodule4"])
+@pytest.mark.parametrize("mode", ["eval", "train_p0"])
+def test_g7_blocks(golden, hipmod, name, mode):
+    g = golden(f"g7_{name}_{mode}")
+    fovealseg.weights.apply_name_keyed_init(hipmod)
+    blk = _sub(hipmod, str(g["prefix"]))
+    blk.train(mode != "eval")
+    _set_drop(blk, 0.0)
+    n_in = sum(1 for k in g.files if k.startswith("in"))
+    ins = [nhwc(T(g[f"in{i}"])).requires_grad_(True) for i in range(n_in)]
+    outs = blk(ins[0]) if n_in == 1 else blk(ins)
+    outs = [outs] if isinstance(outs, torch.Tensor) else list(outs)
+    blk.zero_grad()
+    torch.autograd.backward(outs, [nhwc(T(g[f"cot{i}"])) for i in range(len(outs))])
+    for i, o in enumerate(outs):
+        ref = g[f"out{i}"]
+        assert np.abs(nchw(o).numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    for i, t in enumerate(ins):
+        ref = g[f"din{i}"]
+        assert np.abs(nchw(t.grad).numpy() - ref).max() <= 2e-4 * max(1e-3, np.abs(ref).max())
+    params = dict(blk.named_parameters())
+    for k in g.files:
+        if k.startswith("dw:") or k.startswith("dgamma:"):
+            gr = params[k.split(":", 1)[1]].grad.cpu()
+            ref = g[k]
+            if gr.shape != ref.shape:
+                gr = gr[:16, :16]
+            assert np.abs(gr.numpy() - ref).max() <= 5e-4 * max(1e-3, np.abs(ref).max()), k
+    _set_drop(blk, 0.3)
+    fovealseg.weights.apply_name_keyed_init(hipmod)
+
+
+def test_g8_hrnet_eval(golden, hipmod):
+    g = golden("g8_hrnet_eval")
+    fovealseg.weights.apply_name_keyed_init(hipmod)
+    hipmod.eval()
+    with torch.no_grad():
+        feat = hipmod.encoder(T(g["x"]).to(DEV), return_feature_maps=True)[0]
+    assert feat.shape == (1, 960, 80, 80)
+    feat = feat.cpu()
+    scale = max(1.0, np.abs(g["crop"]).max())
+    assert np.abs(feat[0, :, 32:48, 32:48].numpy() - g["crop"]).max() <= 1e-4 * scale
+    assert np.abs(feat.mean(dim=(0, 2, 3)).numpy() - g["chan_mean"]).max() <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_g9_c1(golden, hipmod, mode):
+    g = golden(f"g9_c1_{mode}")
+    fovealseg.weights.apply_name_keyed_init(hipmod)
+    hipmod.decoder.train(mode == "train")
+    gg = torch.Generator().manual_seed(int(g["seed"]))
+    f9 = torch.randn(2, 960, 80, 80, generator=gg) * 0.5
+    fd = f9.to(DEV).requires_grad_(True)
+    pred = hipmod.decoder([fd])
+    cot = torch.randn(pred.shape, generator=gg) * 0.01
+    hipmod.decoder.zero_grad()
+    pred.backward(cot.to(DEV))
+    p = pred.detach().cpu()
+    assert np.abs(p[:, :50, 0, 0].numpy() - g["pred_ch0"]).max() <= 2e-5
+    assert np.abs(p[:, 50].numpy() - g["pred_last"]).max() <= 2e-5
+    ref = g["dfeat_crop"]
+    assert np.abs(fd.grad.cpu()[:, ::60, 20:36, 20:36].numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+    ref = g["dfc"]
+    assert np.abs(hipmod.decoder.cls_net.fc.weight.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+    ref = g["dw_conv_last"]
+    assert np.abs(hipmod.decoder.conv_last.weight.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+    ref = g["dcbr_crop"]
+    assert np.abs(hipmod.decoder.cbr[0].weight.grad.cpu()[:8, :8].numpy() - ref).max() <= 5e-4 * np.abs(ref).max()
+    fovealseg.weights.apply_name_keyed_init(hipmod)
+
+
+class _InjectValue(torch.autograd.Function):
+    """forward: the injected value; backward: gradient flows to the computed tensor."""
+
+    @staticmethod
+    def forward(ctx, computed, value):
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def _feed(g):
+    return {"img_data": T(g["x"]).to(DEV), "seg_label": T(g["y"]).to(DEV), "focus_point": T(g["focus"]).to(DEV),
+            "cls_label": T(g["cls"]).to(DEV)}
+
+
+def test_g11_end_to_end(golden, hipmod):
+    """End to end against the reference run.  The reference's own fp32 grid is 1.75e-5 from the fp64
+    value of its formula; a 1.5e-5 perturbation of the grid flips 0.2 % of the truncated
+    labels and moves the reference's OWN gradient norms by up to 21 % (measured with the oracle), so
+    (a) the free-running path gets a label-flip / scalar budget, and (b) tight gradient parity is
+    checked with the reference's grid injected (bit-identical labels and x_sampled)."""
+    try:
+        g = golden("g11_e2e_eval")
+        fovealseg.weights.apply_name_keyed_init(hipmod)
+        hipmod.eval()
+        feed = _feed(g)
+        with torch.no_grad():
+            outs = hipmod(feed, is_inference=True)
+        assert len(outs) == 6
+        got = np.array([float(o) for o in outs])
+        flips = float((feed["seg_label"].cpu().numpy() != g["label"]).mean())
+        assert flips <= 3e-3, flips
+        assert np.abs(got - g["outs"]).max() <= 2e-3, (got, g["outs"])
+
+        g = golden("g11_e2e_train_p0")
+        _set_drop(hipmod, 0.0)
+        # (a) free running
+        fovealseg.weights.apply_name_keyed_init(hipmod)
+        hipmod.train()
+        feed = _feed(g)
+        hipmod.zero_grad()
+        loss, acc, edge = hipmod(feed)
+        loss.mean().backward()
+        got = np.array([float(loss), float(acc), float(edge)])
+        assert np.abs(got - g["outs"]).max() <= 2e-3, (got, g["outs"])
+        assert float((feed["seg_label"].cpu().numpy() != g["label"]).mean()) <= 3e-3
+        assert abs(float(edge) - float(g["outs"][2])) <= 1e-5
+        grid_free = hipmod.create_grid(hipmod.saliency(feed["img_data"], feed["focus_point"])[0]).detach().cpu().numpy()
+        assert np.abs(grid_free - g["grid"]).max() <= 3e-5
+        # (b) reference grid injected
+        fovealseg.weights.apply_name_keyed_init(hipmod)
+        hipmod.train()
+        ref_grid = T(g["grid"]).to(DEV)
+        orig = hipmod.create_grid
+        hipmod.create_grid = lambda xs: _InjectValue.apply(orig(xs), ref_grid)
+        try:
+            feed = _feed(g)
+            hipmod.zero_grad()
+            loss, acc, edge = hipmod(feed)
+            loss.mean().backward()
+        finally:
+            del hipmod.create_grid
+        assert np.array_equal(feed["seg_label"].cpu().numpy(), g["label"])          # bit-exact label map
+        got = np.array([float(loss), float(acc), float(edge)])
+        assert np.abs(got - g["outs"]).max() <= 1e-4, (got, g["outs"])
+        params = dict(hipmod.named_parameters())
+        for n, ref in zip(g["gn_names"], g["gn"]):
+            gn = float(params[str(n)].grad.norm())
+            # saliency-side gradients pass through the clamp mask of create_grid (ill-conditioned, see g4)
+            tol = 5e-2 if (str(n).startswith("localization") or str(n).startswith("net_compress")) else 2e-3
+            assert abs(gn - float(ref)) <= tol * max(abs(float(ref)), 1e-6), (n, gn, ref)
+    finally:
+        _set_drop(hipmod, 0.3)
+        fovealseg.weights.apply_name_keyed_init(hipmod)
+
+
+def test_dropout_replay_basic_block(hipmod):
+    """Train-mode BasicBlock with Dropout(0.3): the kernel's hash mask replayed in the oracle."""
+    fovealseg.weights.apply_name_keyed_init(hipmod)
+    o = O.OracleDeformSeg()
+    fovealseg.weights.apply_name_keyed_init(o)
+    path = "stage3.1.branches.1.2"
+    blk = _sub(hipmod.encoder, path).train()
+    oblk = _sub(o.encoder, path).train()
+    ops.DropoutState.seed, ops.DropoutState.step = 5, 17
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 128, 10, 10, generator=g)
+
+    def drop_fn(name, t):
+        B, C, H, W = t.shape
+        key = ops.DropoutState.key(ops.layer_id_from_name(name))
+        keep = O.dropout_keep_mask_nhwc(t.numel(), key, 0.3).reshape(B, H, W, C)
+        return t * torch.from_numpy(keep).permute(0, 3, 1, 2).float() * np.float32(1.0 / 0.7)
+    xr = x.clone().requires_grad_(True)
+    ref = oblk(xr, O._Ctx(True, drop_fn), path)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot)
+    xd = nhwc(x).requires_grad_(True)
+    out = blk(xd)
+    out.backward(nhwc(cot))
+    assert relerr(nchw(out), ref.detach()) <= 2e-5
+    assert relerr(nchw(xd.grad), xr.grad) <= 2e-4
+    frac = float((nchw(out) == 0).float().mean())
+    assert 0.0 < frac < 1.0
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config-2 sizes: size-independent properties (B=64, 1024x1024 -> 80x80)
+# ------------------------------------------------------------------------------------------------
+def test_full_size_properties():
+    B, H = 64, 1024
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(B, 3, H, H, generator=g).to(DEV)
+    focus = (torch.rand(B, 2, generator=g) * 0.8 + 0.1).to(DEV)
+    # (1) an identity grid at the low-res pixel centres reproduces F.interpolate-free bilinear taps:
+    #     sampling a constant image returns the constant exactly inside, and linearity holds
+    ys, xs_ = torch.meshgrid(torch.linspace(-0.95, 0.95, 80), torch.linspace(-0.95, 0.95, 80), indexing="ij")
+    grid = torch.stack((xs_, ys), -1)[None].repeat(B, 1, 1, 1).contiguous().to(DEV)
+    ones = torch.ones(B, 3, H, H, device=DEV)
+    s1 = ops.GridSample.apply(ones, grid)
+    assert float((s1 - 1).abs().max()) <= 2e-7
+    a = ops.GridSample.apply(x, grid)
+    b2 = ops.GridSample.apply(x * 2, grid)
+    assert torch.equal(a * 2, b2)                                   # exact: power-of-two scaling
+    # (2) label map of an all-ones mask is 1 wherever all four taps are in range
+    lab = ops.grid_sample_label(torch.ones(B, 1, H, H, device=DEV), grid)
+    assert int(lab.min()) == 0 or int(lab.min()) == 1
+    assert int(lab.sum()) >= int(0.9 * lab.numel())
+    # (3) low-res input: gaze channel is zero at the gaze pixel and both copies are identical
+    xl = ops.gaze_lowres(x, focus, 80, 80)
+    assert torch.equal(xl[..., 3], xl[..., 4])
+    assert float(xl[..., :3].min()) >= 0 and float(xl[..., :3].max()) <= 1
+    # (4) area pool of a constant is the constant; softmax saliency sums to one per image
+    ap = ops.area_pool(torch.full((B, 1, H, H), 0.25, device=DEV), 80, 80)
+    assert float((ap - 0.25).abs().max()) <= 1e-7
+    # (5) uniform saliency -> (near-)uniform grid, symmetric about the centre
+    uni = torch.full((B, 1, 80, 80), 1.0 / 6400, device=DEV)
+    g1d = torch.from_numpy(O.gaussian_1d(91, 45)).to(DEV)
+    gr = ops.GaussGrid.apply(uni, g1d, 45)
+    assert float((gr[:, :, :, 0] + gr[:, :, :, 0].flip(2)).abs().max()) <= 1e-6
+    assert float((gr[:, :, :, 1] + gr[:, :, :, 1].flip(1)).abs().max()) <= 1e-6
