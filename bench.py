@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Benchmark of the FovealSeg hot path on MI355X.
+
+metric  : images/sec, forward + backward + optimiser step, 1024x1024 -> 80x80 foveated HRNetV2 + C1,
+          batch 64 per GPU (BASELINE.json configs[1]), train mode (BN batch statistics, Dropout 0.3).
+step    : one full optimisation step (train_deform_semantic.py:74-129) on a synthetic batch that is
+          already resident in HBM.
+Usage   : python bench.py --gpus N --steps K --warmup W        (N>1 under torch.distributed.run)
+Output  : ONE JSON line on rank 0 (see README/DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(batch=4, H=1024, threads=None):
+    """The CPU oracle (port of the reference algorithm) timed on this host: B=4, 1024^2, one warm-up and
+    one timed train-mode forward+backward (BASELINE.json configs[0])."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fovealseg_oracle as O
+    from fovealseg.weights import apply_name_keyed_init
+    from fovealseg.train import synthetic_batch
+    if threads:
+        torch.set_num_threads(threads)
+    o = O.OracleDeformSeg()
+    apply_name_keyed_init(o)
+    o.train()
+    X, Fp, Y, cls = synthetic_batch(batch, H, H, seed=1, device="cpu")
+    times = []
+    for it in range(2):
+        feed = {"img_data": X, "seg_label": Y.clone(), "focus_point": Fp, "cls_label": cls}
+        o.zero_grad()
+        t0 = time.perf_counter()
+        loss, acc, edge = o(feed)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    t = times[-1]
+    return {"value": round(batch / t, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/fovealseg_oracle.py OracleDeformSeg, B={batch}, {H}x{H}->80x80, train mode, 1 warm-up + 1 timed fwd+bwd (no optimiser step), {t:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE config 2: 64)")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    import fovealseg
+    from fovealseg import train as T
+    from fovealseg import ops
+
+    fovealseg.hip.load()       # fail loudly if the HIP library is missing
+    rank, local_rank, world = T.ddp_setup()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    cfg = fovealseg.lvis50_cfg()
+    module, nets = T.build_module(cfg, device=dev)
+    module.train()
+    optimizers = T.create_optimizers(nets, cfg)
+    T.broadcast_parameters(optimizers, module)
+    batch = T.synthetic_batch(args.batch, args.size, args.size, seed=1 + rank, device=dev)
+    ops.DropoutState.seed = 1234 + rank
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for i in range(args.warmup):
+        out = T.train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=i)
+    barrier()
+    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = T.train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    loss_val = float(out[0])
+    assert loss_val == loss_val, "loss is NaN"
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t)
+    imgs = args.batch * world * args.steps
+    line = {
+        "metric": "images/sec fwd+bwd, 1024->80 foveated HRNetV2, batch 64",
+        "value": round(imgs / elapsed, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: HRNetV2-nodownsp + C1, {args.size}x{args.size}->80x80, gaussian_radius 45, "
+                               f"batch {args.batch}/GPU, train mode (BN batch stats, Dropout 0.3), fwd+bwd+Adam x4",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": round(loss_val, 5)},
+    }
+    if rank == 0:
+        if timer is not None:
+            summ = timer.summary()
+            k = summ.get("conv_igemm")
+            if k:
+                achieved = k["flops"] / (k["total_ms"] * 1e-3) / 1e12
+                line["roofline"] = {
+                    "kernel": "conv_igemm_kernel<true> (fwd + bwd-data implicit GEMM, fp32 MFMA)",
+                    "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": k["launches"] // args.steps,
+                    "avg_launch_us": round(1000.0 * k["total_ms"] / k["launches"], 2),
+                    "gflop_per_launch": round(k["flops"] / k["launches"] / 1e9, 3),
+                    "share_of_step": round(k["total_ms"] / (1000.0 * elapsed), 3)}
+            w = summ.get("conv_wgrad")
+            if w:
+                line["roofline_wgrad"] = {
+                    "kernel": "conv_wgrad_kernel<true>", "bound": "mfma",
+                    "achieved": round(w["flops"] / (w["total_ms"] * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(w["flops"] / (w["total_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                    "avg_launch_us": round(1000.0 * w["total_ms"] / w["launches"], 2),
+                    "share_of_step": round(w["total_ms"] / (1000.0 * elapsed), 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

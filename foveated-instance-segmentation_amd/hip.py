@@ -49,6 +49,7 @@ SIGNATURES = {
     "fs_pred_assemble_bwd": "pppppiii",
     "fs_seg_loss_fwd": "ppiiiffppp",
     "fs_seg_loss_bwd": "pppppiiif",
+    "fs_adam_step": "pppplfffffif",
 }
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 

@@ -63,14 +63,48 @@ def _out_hw(h, w, r, s, stride, pad):
     return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual conv launches on the current stream (bench.py only).
+    `flops` are algorithmic: 2 * B*Ho*Wo * Cout * R*S*Cin for every variant."""
+
+    def __init__(self):
+        self.records = {}          # kind -> list of (start_event, stop_event, flops)
+
+    def launch(self, kind, flops, fn):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.records.setdefault(kind, []).append((s, e, flops))
+
+    def summary(self):
+        out = {}
+        for kind, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[kind] = dict(launches=len(recs), total_ms=ms, flops=fl)
+        return out
+
+
+TIMER = None      # set to a KernelTimer by bench.py around the timed region
+
+
+def _launch(kind, flops, name, *args):
+    if TIMER is None:
+        hip.call(name, *args)
+    else:
+        TIMER.launch(kind, flops, lambda: hip.call(name, *args))
+
+
 def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0):
     B, H, W, Cin = x.shape
     Cout, Cin2, R, S = w.shape
     assert Cin == Cin2, (x.shape, w.shape)
     Ho, Wo = _out_hw(H, W, R, S, stride, pad)
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
-    hip.call("fs_conv2d_fwd", hip.ptr(x), hip.ptr(rsck(w)), hip.ptr(bias), hip.ptr(y), B, H, W, Cin, Ho, Wo, Cout, R, S,
-             stride, pad, float(drop_p), int(drop_key))
+    _launch("conv_igemm", 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd", hip.ptr(x), hip.ptr(rsck(w)), hip.ptr(bias),
+            hip.ptr(y), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, float(drop_p), int(drop_key))
     return y
 
 
@@ -79,7 +113,8 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad):
     Cout, _, R, S = w.shape
     _, Ho, Wo, _ = dy.shape
     dx = torch.empty(B, H, W, Cin, device=dy.device, dtype=torch.float32)
-    hip.call("fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad)
+    _launch("conv_igemm", 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx),
+            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad)
     return dx
 
 
@@ -88,7 +123,8 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad):
     Cout, _, R, S = w_shape
     _, Ho, Wo, _ = dy.shape
     dw = torch.empty(R, S, Cin, Cout, device=x.device, dtype=torch.float32)
-    hip.call("fs_conv2d_bwd_weight", hip.ptr(x), hip.ptr(dy), hip.ptr(dw), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad)
+    _launch("conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_bwd_weight", hip.ptr(x), hip.ptr(dy), hip.ptr(dw),
+            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad)
     return dw.permute(3, 2, 0, 1)
 
 

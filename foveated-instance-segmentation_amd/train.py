@@ -1,0 +1,252 @@
+"""Training-step plumbing around DeformSegmentationModule.
+
+Mirrors train_deform_semantic.py: `ddp_setup` (:45-55), the per-step order of `train()` (:74-129:
+zero_grad -> adjust_learning_rate -> forward -> loss.mean().backward() -> 4 optimiser steps),
+`create_optimizers` (:260-290, Adam x4 over encoder/decoder/saliency/compress) and
+`adjust_learning_rate` (:302-350).
+
+MI355X-first differences (DESIGN.md "Multi-GPU"): each optimiser owns ONE flat fp32 arena holding all
+its parameters (params are views into it, conv weights keep RSCK strides), one flat gradient arena
+and flat Adam moments, so a step is one fused HIP kernel and the data-parallel exchange is one RCCL
+all-reduce per arena (4 per step, 522 MB total) instead of DDP's ~20 x 25 MB buckets.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import hip
+
+_ALIGN = 4   # elements; keeps every parameter 16-byte aligned for the float4 kernels
+
+
+class FlatParams:
+    """Re-homes a list of parameters into one flat arena (+ a matching gradient arena)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params]
+        assert self.params, "empty parameter list"
+        dev = self.params[0].device
+        offs, n = [], 0
+        for p in self.params:
+            assert p.dtype == torch.float32
+            offs.append(n)
+            n += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = n
+        self.data = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        for p, o in zip(self.params, offs):
+            size, stride = tuple(p.shape), tuple(p.stride())
+            dense = self._dense_strides(p)
+            view = self.data.as_strided(size, dense, o)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad.as_strided(size, dense, o)
+            del stride
+        self.offsets = offs
+
+    @staticmethod
+    def _dense_strides(p):
+        """Strides of p if it is non-overlapping and dense (any permutation), else contiguous ones."""
+        size, stride = p.shape, p.stride()
+        order = sorted(range(p.dim()), key=lambda d: (stride[d], size[d]))
+        expect, ok = 1, True
+        for d in order:
+            if size[d] == 1:
+                continue
+            if stride[d] != expect:
+                ok = False
+                break
+            expect *= size[d]
+        if ok:
+            return tuple(stride)
+        return tuple(torch.empty(size).stride())
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):     # autograd may have re-pointed .grad
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad.as_strided(tuple(p.shape), tuple(p.stride()), o)
+
+
+class FlatAdam:
+    """torch.optim.Adam(weight_decay) semantics over a FlatParams arena, one fused HIP launch."""
+
+    def __init__(self, params, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, **group_extras):
+        self.flat = FlatParams(params)
+        self.m = torch.zeros_like(self.flat.data)
+        self.v = torch.zeros_like(self.flat.data)
+        self.t = 0
+        self.grad_scale = 1.0
+        g = dict(params=self.flat.params, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
+        g.update(group_extras)
+        self.param_groups = [g]
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def step(self):
+        g = self.param_groups[0]
+        self.t += 1
+        hip.call("fs_adam_step", hip.ptr(self.flat.data), hip.ptr(self.flat.grad), hip.ptr(self.m), hip.ptr(self.v),
+                 self.flat.numel, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                 float(g["weight_decay"]), self.t, float(self.grad_scale))
+
+    def state_dict(self):
+        return dict(t=self.t, m=self.m, v=self.v, param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+
+    def load_state_dict(self, sd):
+        self.t = sd["t"]
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+
+
+def create_optimizers(nets, cfg):
+    """train_deform_semantic.py:260-290 -- returns (encoder, decoder, saliency, compress) optimisers."""
+    net_encoder, net_decoder, crit, net_saliency, net_compress = nets
+    if cfg.TRAIN.optim.lower() != "adam":
+        raise NotImplementedError("only TRAIN.optim='adam' is usable in the reference (the sgd branch returns undefined names)")
+    T = cfg.TRAIN
+    mk = lambda net, mult, zoom: FlatAdam(list(net.parameters()), lr=T.lr_encoder, weight_decay=T.weight_decay,  # noqa: E731
+                                          lr_mult=mult, zoom=zoom)
+    return (mk(net_encoder, T.lr_mult_encoder, False), mk(net_decoder, T.lr_mult_decoder, False),
+            mk(net_saliency, T.lr_mult_saliency, True), mk(net_compress, T.lr_mult_compress, True))
+
+
+def adjust_learning_rate(optimizers, cur_iter, cfg, epoch=None):
+    """train_deform_semantic.py:302-350 under scale_by_iter=False, fov_scale_lr=''."""
+    T = cfg.TRAIN
+    scale_running_lr = (1.0 - float(cur_iter) / T.max_iters) ** T.lr_pow
+    T.running_lr_encoder = T.lr_encoder * scale_running_lr
+    T.running_lr_decoder = T.lr_decoder * scale_running_lr
+    T.running_lr_foveater = T.lr_foveater * scale_running_lr
+    base_lr = 0.1
+    n_pre = T.deform_pretrain
+    if T.scale_by_iter:
+        raise NotImplementedError("TRAIN.scale_by_iter=True is not on the default path")
+    lr_idx = epoch
+    if T.deform_pretrain_bol or lr_idx < n_pre:
+        lr_class = base_lr * 0.1 ** (lr_idx // n_pre)
+        lr_zoom = base_lr * 0.1 ** (lr_idx // n_pre)
+    else:
+        lr_class = base_lr * 0.1 ** ((lr_idx - n_pre) // n_pre)
+        lr_zoom = base_lr * 0.1 ** (lr_idx // n_pre)
+    if T.fix_deform_aft_pretrain and T.fix_deform_start_epoch <= epoch <= T.fix_deform_end_epoch:
+        lr_zoom = 0.0
+    for opt in optimizers:
+        for group in opt.param_groups:
+            group["lr"] = group["lr_mult"] * (lr_zoom if group["zoom"] else lr_class)
+
+
+# ----------------------------------------------------------------------------------------------
+# data-parallel (one process per GPU, RCCL over xGMI)
+# ----------------------------------------------------------------------------------------------
+def ddp_setup(backend=None):
+    """train_deform_semantic.py:45-55, driven by torchrun's env instead of mp.spawn arguments."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    return rank, local_rank, world
+
+
+def broadcast_parameters(optimizers, module=None, src=0):
+    """DDP construction-time broadcast (train_deform_semantic.py:395): one collective per arena."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    for opt in optimizers:
+        dist.broadcast(opt.flat.data, src=src)
+    if module is not None:
+        for b in module.buffers():
+            if b.dtype.is_floating_point:
+                dist.broadcast(b, src=src)
+
+
+def allreduce_gradients(optimizers):
+    """Gradient average across ranks: one SUM all-reduce per arena; the 1/world is folded into Adam."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        for opt in optimizers:
+            opt.grad_scale = 1.0
+        return
+    world = dist.get_world_size()
+    for opt in optimizers:
+        dist.all_reduce(opt.flat.grad, op=dist.ReduceOp.SUM)
+        opt.grad_scale = 1.0 / world
+
+
+def shard_indices(n_samples, rank, world, epoch_seed=0, shuffle=True):
+    """DistributedSampler(num_replicas, rank, shuffle=True) sharding (train_deform_semantic.py:462);
+    set_epoch is never called in the reference, so the permutation is the same every epoch (seed 0)."""
+    g = torch.Generator().manual_seed(epoch_seed)
+    idx = torch.randperm(n_samples, generator=g).tolist() if shuffle else list(range(n_samples))
+    total = (n_samples + world - 1) // world * world
+    idx += idx[: total - len(idx)]
+    return idx[rank:total:world]
+
+
+# ----------------------------------------------------------------------------------------------
+# one optimisation step / one evaluation step
+# ----------------------------------------------------------------------------------------------
+def train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=0):
+    """train_deform_semantic.py:74-129 for one batch (X,F,Y,cls) already on the device."""
+    from .ops import DropoutState
+    X, Fp, Y, cls = batch
+    feed = {"img_data": X[:, :3], "seg_label": Y, "focus_point": Fp, "cls_label": cls}
+    for opt in optimizers:
+        opt.zero_grad()
+    adjust_learning_rate(optimizers, cur_iter, cfg, epoch=epoch)
+    DropoutState.step += 1
+    out = module(feed, epoch=epoch, cur_iter=cur_iter)
+    loss = out[0]
+    loss.mean().backward()
+    allreduce_gradients(optimizers)
+    for opt in optimizers:
+        opt.step()
+    return out
+
+
+@torch.no_grad()
+def eval_step(module, batch):
+    """eval.py:389-405 -- same forward with is_inference=True under no_grad (module.eval() by caller)."""
+    X, Fp, Y, cls = batch
+    feed = {"img_data": X[:, :3], "seg_label": Y, "focus_point": Fp, "cls_label": cls}
+    return module(feed, is_inference=True)
+
+
+def synthetic_batch(B, H, W, seed=1, device="cuda"):
+    """uniform RGB, gaze in [0.1,0.9), disc mask of radius 0.15 H at the gaze."""
+    g = torch.Generator().manual_seed(seed)
+    X = torch.rand(B, 3, H, W, generator=g)
+    Fp = torch.rand(B, 2, generator=g) * 0.8 + 0.1
+    cls = torch.randint(0, 50, (B, 1), generator=g)
+    ii = torch.arange(H, dtype=torch.float32)[None, :, None]
+    jj = torch.arange(W, dtype=torch.float32)[None, None, :]
+    cy = (Fp[:, 0] * (H - 1))[:, None, None]
+    cx = (Fp[:, 1] * (W - 1))[:, None, None]
+    Y = (((ii - cy) ** 2 + (jj - cx) ** 2) <= (0.15 * H) ** 2).float().unsqueeze(1)
+    return X.to(device), Fp.to(device), Y.to(device), cls.to(device)
+
+
+def build_module(cfg, device="cuda", init="name_keyed"):
+    from . import ModelBuilder, DeformSegmentationModule
+    from .weights import apply_name_keyed_init
+    M = cfg.MODEL
+    enc = ModelBuilder.build_encoder(M.arch_encoder, M.fc_dim, M.weights_encoder)
+    dec = ModelBuilder.build_decoder(M.arch_decoder, M.fc_dim, cfg.DATASET.num_class, M.weights_decoder)
+    sal = ModelBuilder.build_net_saliency(cfg, M.weights_net_saliency)
+    comp = ModelBuilder.build_net_compress(cfg, M.weights_net_compress)
+    module = DeformSegmentationModule(enc, dec, sal, comp, None, cfg)
+    if init == "name_keyed":
+        apply_name_keyed_init(module)
+    module.to(device)
+    nets = (module.encoder, module.decoder, None, module.localization, module.net_compress)
+    return module, nets

@@ -116,6 +116,12 @@ int fs_seg_loss_fwd(const float* pred, const long long* gt, int B, int K, int HW
 int fs_seg_loss_bwd(const float* pred, const long long* gt, const float* coef, const float* gout, float* dpred, int B, int K,
                     int HW, float gamma, fs_stream_t stream);
 
+/* ---- optimiser ------------------------------------------------------------------------------- */
+/* torch.optim.Adam(weight_decay) step over a flat fp32 arena of n (multiple of 4) elements; step >= 1;
+ * grad_scale multiplies the gradient first (1/world_size).  train_deform_semantic.py:115-123,271-288. */
+int fs_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, float grad_scale, fs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
