@@ -11,11 +11,24 @@
 // K-step 32 inside one filter tap; each wave owns 32 x 64 = two 32x32 accumulators.  Operands are
 // staged global -> registers -> LDS with the next stage's loads in flight under the MFMAs.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BM = 128, BN = 64, BK = 32;
 constexpr int A_LD = BK + 1;   // odd leading dimension: conflict-free ds_read_b32 of A[row][k]
+
+// Raw buffer descriptor: 32-bit byte offsets, hardware range check (out-of-range lanes read 0), so
+// padding taps / channel tails need no branch -- the lane just gets an offset past num_records.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
 
 struct ConvArgs {
   const float* src;   // fwd: X (B,Hs,Ws,Cs)      bwd-data: dY
@@ -27,6 +40,7 @@ struct ConvArgs {
   int transposed;     // 0 = forward, 1 = bwd-data
   float drop_scale;   // 1/(1-p)
   uint32_t drop_thresh, drop_key;   // thresh 0 = no dropout
+  hipStream_t stream_ = nullptr;    // host only
 };
 
 template <bool VEC>
@@ -200,6 +214,210 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Fast path ("affine"): forward at any stride and bwd-data at stride 1, channels multiple of 4.
+// The pixel of tap (r,s) is a fixed offset from the tap-(0,0) pixel, so every per-stage address is
+//   row_offset (per thread, hoisted) + uniform scalar;  validity of the 9 taps is a per-row bit mask.
+// LDS is double-buffered: one barrier per K-step; the next tile is written to the other buffer in
+// the middle of the MFMA block and the tile after that is requested from global right behind it.
+//   MT = 32-row MFMA tiles per wave along M: workgroup tile (128*MT) x 64.
+// ------------------------------------------------------------------------------------------
+struct AffArgs {
+  const float* src; const float* w; const float* bias; float* dst;
+  int B, Hs, Ws, Cs, Hd, Wd, Cd;
+  int R, S, stride, pad;
+  int transposed;
+  float drop_scale; uint32_t drop_thresh, drop_key;
+  unsigned src_bytes, w_bytes;
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
+  constexpr int TM = 128 * MT;                    // workgroup rows
+  constexpr int NR = 4 * MT;                      // A rows per thread
+  __shared__ float As[2][TM * A_LD];
+  __shared__ float Bs[2][BK * BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long M = (long)a.B * a.Hd * a.Wd;
+  const long m0 = (long)blockIdx.x * TM;
+  const int n0 = blockIdx.y * BN;
+  const int q = tid & 7, arow = tid >> 3;
+  const int sgn = a.transposed ? -1 : 1;
+  const int ntap = a.R * a.S;
+
+  // ---- hoisted per-row state: element offset of tap (0,0) and the tap validity mask -----------
+  int roff[NR];
+  uint32_t rmask[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const long m = m0 + arow + 32 * i;
+    roff[i] = 0; rmask[i] = 0u;
+    if (m < M) {
+      const int b = (int)(m / ((long)a.Hd * a.Wd));
+      const int rem = (int)(m - (long)b * a.Hd * a.Wd);
+      const int py = rem / a.Wd, px = rem - py * a.Wd;
+      const int iy0 = a.transposed ? py + a.pad : py * a.stride - a.pad;
+      const int ix0 = a.transposed ? px + a.pad : px * a.stride - a.pad;
+      roff[i] = ((b * a.Hs + iy0) * a.Ws + ix0) * a.Cs + 4 * q;
+      uint32_t mk = 0u;
+      for (int t = 0; t < ntap; ++t) {
+        const int tr = t / a.S, ts = t - tr * a.S;
+        const int iy = iy0 + sgn * tr, ix = ix0 + sgn * ts;
+        if (iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws) mk |= (1u << t);
+      }
+      rmask[i] = mk;
+    }
+  }
+  // ---- hoisted B state ---------------------------------------------------------------------
+  //   forward : tile [k][n]: n4 = tid&15, k = (tid>>4)+16*i ; element (tap*Cs + c0 + k)*Cd + n0 + 4*n4
+  //   bwd-data: tile [n][k]: k4 = tid&7,  n = (tid>>3)+32*i ; element (tap*Cd + n0 + n)*Cs + c0 + 4*k4
+  int boff[2];
+  bool bok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (!a.transposed) {
+      const int n = n0 + 4 * (tid & 15), k = (tid >> 4) + 16 * i;
+      boff[i] = k * a.Cd + n; bok[i] = n < a.Cd;
+    } else {
+      const int n = n0 + (tid >> 3) + 32 * i, k = 4 * (tid & 7);
+      boff[i] = n * a.Cs + k; bok[i] = n < a.Cd;
+    }
+  }
+  const int nchunk = (a.Cs + BK - 1) / BK;
+  const int nstage = ntap * nchunk;
+  const bool ktail = (a.Cs % BK) != 0;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(a.src, a.src_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.w, a.w_bytes);
+  f32x4 ra[NR], rb[2];
+  auto load_stage = [&](int st) {
+    const int tap = st / nchunk, c0 = (st - tap * nchunk) * BK;
+    const int tr = tap / a.S, ts = tap - tr * a.S;
+    const int aoff = sgn * (tr * a.Ws + ts) * a.Cs + c0;          // uniform
+    const bool aok = !ktail || (c0 + 4 * q < a.Cs);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const bool ok = ((rmask[i] >> tap) & 1u) && aok;
+      ra[i] = buf_load4(rsrc_a, ok ? (unsigned)(roff[i] + aoff) * 4u : OOB);
+    }
+    if (!a.transposed) {
+      const int wbase = (tap * a.Cs + c0) * a.Cd;                 // uniform
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool ok = bok[i] && (!ktail || (c0 + (tid >> 4) + 16 * i < a.Cs));
+        rb[i] = buf_load4(rsrc_w, ok ? (unsigned)(wbase + boff[i]) * 4u : OOB);
+      }
+    } else {
+      const int wbase = tap * a.Cd * a.Cs + c0;                   // uniform
+      const bool kok = !ktail || (c0 + 4 * (tid & 7) < a.Cs);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        rb[i] = buf_load4(rsrc_w, (bok[i] && kok) ? (unsigned)(wbase + boff[i]) * 4u : OOB);
+    }
+  };
+  auto store_stage = [&](int buf) {
+    float* A = As[buf];
+    float* Bm = Bs[buf];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      float* p = &A[(arow + 32 * i) * A_LD + 4 * q];
+      p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w;
+    }
+    if (!a.transposed) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<f32x4*>(&Bm[((tid >> 4) + 16 * i) * BN + 4 * (tid & 15)]) = rb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = (tid >> 3) + 32 * i, k = 4 * (tid & 7);
+        Bm[(k + 0) * BN + n] = rb[i].x;
+        Bm[(k + 1) * BN + n] = rb[i].y;
+        Bm[(k + 2) * BN + n] = rb[i].z;
+        Bm[(k + 3) * BN + n] = rb[i].w;
+      }
+    }
+  };
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) { acc[i][0] = f32x16{0}; acc[i][1] = f32x16{0}; }
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // Fragments are fetched a quarter-stage (4 k-pairs = 8*MT MFMAs) ahead of the MFMAs that use them,
+  // so the LDS latency sits under the previous quarter's matrix work instead of in front of each pair.
+  constexpr int QK = 4;                           // k-pairs per quarter
+  struct Frag { float a[MT][QK]; float b0[QK], b1[QK]; };
+  auto load_frag = [&](Frag& f, int buf, int qtr) {
+    const float* Ap = &As[buf][(wave * 32 * MT + l31) * A_LD + lh + 2 * QK * qtr];
+    const float* Bp = &Bs[buf][(lh + 2 * QK * qtr) * BN + l31];
+#pragma unroll
+    for (int kk = 0; kk < QK; ++kk) {
+      f.b0[kk] = Bp[2 * kk * BN];
+      f.b1[kk] = Bp[2 * kk * BN + 32];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) f.a[i][kk] = Ap[i * 32 * A_LD + 2 * kk];
+    }
+  };
+  auto mma_frag = [&](const Frag& f) {
+#pragma unroll
+    for (int kk = 0; kk < QK; ++kk)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][kk], f.b0[kk], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][kk], f.b1[kk], acc[i][1], 0, 0, 0);
+      }
+  };
+
+  load_stage(0);
+  store_stage(0);
+  if (nstage > 1) load_stage(1);
+  __syncthreads();
+  Frag f0, f1;
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    // sched_barrier(0) pins the order: hipcc otherwise sinks every ds_read next to its MFMA and
+    // waits lgkmcnt(0) in front of each pair (measured: 62 % MFMA-pipe utilisation).
+    load_frag(f0, buf, 0);
+    load_frag(f1, buf, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frag(f0, buf, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(f1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frag(f1, buf, 3);
+    if (st + 1 < nstage) {
+      store_stage(buf ^ 1);                       // waits for the loads issued one stage ago
+      if (st + 2 < nstage) load_stage(st + 2);    // lands under the next stage's first half
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma_frag(f0);
+    mma_frag(f1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int n = n0 + 32 * t + l31;
+      if (n >= a.Cd) continue;
+      const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wave * 32 * MT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= M) continue;
+        float v = acc[i][t][r] + bv;
+        const long e = m * a.Cd + n;
+        if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+        a.dst[e] = v;
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // bwd-weight: per tap GEMM  dW[tap][ci][co] += sum_{pix in split} X[pix+tap][ci] * dY[pix][co]
 // tile 64(ci) x 64(co), K-step 32 pixels, one 32x32 accumulator per wave, split-K over
 // blockIdx.z with fp32 atomic accumulation into a zeroed dW.
@@ -301,6 +519,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+int launch_affine(const ConvArgs& c, long M) {
+  AffArgs a{c.src, c.w, c.bias, c.dst, c.B, c.Hs, c.Ws, c.Cs, c.Hd, c.Wd, c.Cd, c.R, c.S, c.stride, c.pad, c.transposed,
+            c.drop_scale, c.drop_thresh, c.drop_key,
+            (unsigned)((size_t)c.B * c.Hs * c.Ws * c.Cs * 4), (unsigned)((size_t)c.R * c.S * c.Cs * c.Cd * 4)};
+  const int ny = cdiv(c.Cd, BN);
+  // MT=2 (256-row tiles) needs 84 KB of LDS = one workgroup per CU and measured 20-25 % slower.
+  hipLaunchKernelGGL(conv_igemm_affine_kernel<1>, dim3(cdiv(M, 128), ny), dim3(256), 0, c.stream_, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -313,12 +542,15 @@ int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, i
   FS_REQUIRE(Ho == (H + 2 * pad - R) / stride + 1 && Wo == (W + 2 * pad - S) / stride + 1);
   FS_REQUIRE(drop_p >= 0.f && drop_p < 1.f);
   ConvArgs a{x, w, bias, y, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, 0, 1.f, 0u, drop_key};
+  a.stream_ = stream;
   if (drop_p > 0.f) {
     a.drop_scale = 1.0f / (float)(1.0 - (double)drop_p);
     a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
   }
   const long M = (long)B * Ho * Wo;
   FS_REQUIRE(M * Cout < 4294967296L);
+  if ((Cin % 4 == 0) && (Cout % 4 == 0) && R * S <= 32 && (long)B * H * W * Cin < 2147483647L)
+    return launch_affine(a, M);
   dim3 grid(cdiv(M, BM), cdiv(Cout, BN));
   if ((Cin % 4 == 0) && (Cout % 4 == 0))
     hipLaunchKernelGGL(conv_igemm_kernel<true>, grid, dim3(256), 0, stream, a);
@@ -335,6 +567,9 @@ int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H,
   FS_REQUIRE(Ho == (H + 2 * pad - R) / stride + 1 && Wo == (W + 2 * pad - S) / stride + 1);
   ConvArgs a{dy, w, nullptr, dx, B, Ho, Wo, Cout, H, W, Cin, R, S, stride, pad, 1, 1.f, 0u, 0u};
   const long M = (long)B * H * W;
+  a.stream_ = stream;
+  if (stride == 1 && (Cin % 4 == 0) && (Cout % 4 == 0) && R * S <= 32 && (long)B * Ho * Wo * Cout < 2147483647L)
+    return launch_affine(a, M);
   dim3 grid(cdiv(M, BM), cdiv(Cin, BN));
   if ((Cin % 4 == 0) && (Cout % 4 == 0))
     hipLaunchKernelGGL(conv_igemm_kernel<true>, grid, dim3(256), 0, stream, a);
