@@ -74,6 +74,18 @@ def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, act, res=None, drop_p=0.
     return ops.ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, res, meta)
 
 
+PARALLEL_BRANCHES = True
+_SIDE = {}
+
+
+def _side_streams(device, n):
+    key = (device.type, device.index)
+    pool = _SIDE.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
 def to_nhwc(x_nchw: torch.Tensor) -> torch.Tensor:
     """(B,C,H,W) logical -> contiguous (B,H,W,C); free when x is already a channels-last view."""
     v = x_nchw.permute(0, 2, 3, 1)
@@ -216,9 +228,34 @@ class HighResolutionModule(nn.Module):
             rows.append(nn.ModuleList(row))
         self.fuse_layers = nn.ModuleList(rows)
 
+    def _run_branches(self, xs):
+        """The n resolution branches are independent until the fuse, so branches 1.. run on side HIP
+        streams: their workgroups fill the tail of each other's launches and the HBM-bound BatchNorm
+        passes of one branch overlap the MFMA-bound convolutions of another.  Autograd replays each
+        node's backward on the stream its forward ran on, so the backward overlaps the same way."""
+        n = len(self.chans)
+        if not (PARALLEL_BRANCHES and xs[0].is_cuda):
+            return [self.branches[i](xs[i]) for i in range(n)]
+        main = torch.cuda.current_stream()
+        side = _side_streams(xs[0].device, n - 1)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        outs = [None] * n
+        for i in range(1, n):
+            s = side[i - 1]
+            s.wait_event(fork)
+            xs[i].record_stream(s)
+            with torch.cuda.stream(s):
+                outs[i] = self.branches[i](xs[i])
+        outs[0] = self.branches[0](xs[0])
+        for i in range(1, n):
+            main.wait_stream(side[i - 1])
+            outs[i].record_stream(main)
+        return outs
+
     def forward(self, xs):
         n = len(self.chans)
-        xs = [self.branches[i](xs[i]) for i in range(n)]
+        xs = self._run_branches(xs)
         outs = []
         for i in range(n):
             terms = [xs[j] if j == i else self.fuse_layers[i][j](xs[j]) for j in range(n)]

@@ -103,7 +103,8 @@ def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0):
     assert Cin == Cin2, (x.shape, w.shape)
     Ho, Wo = _out_hw(H, W, R, S, stride, pad)
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
-    _launch("conv_igemm", 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd", hip.ptr(x), hip.ptr(rsck(w)), hip.ptr(bias),
+    kind = "conv_affine" if (Cin % 4 == 0 and Cout % 4 == 0) else "conv_generic"      # mirrors csrc/conv.hip dispatch
+    _launch(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd", hip.ptr(x), hip.ptr(rsck(w)), hip.ptr(bias),
             hip.ptr(y), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, float(drop_p), int(drop_key))
     return y
 
@@ -113,19 +114,34 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad):
     Cout, _, R, S = w.shape
     _, Ho, Wo, _ = dy.shape
     dx = torch.empty(B, H, W, Cin, device=dy.device, dtype=torch.float32)
-    _launch("conv_igemm", 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx),
+    kind = "conv_affine" if (Cin % 4 == 0 and Cout % 4 == 0 and stride == 1) else "conv_generic"
+    _launch(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx),
             B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad)
     return dx
 
 
-def conv2d_bwd_weight(x, dy, w_shape, stride, pad):
+# When True (set by train.create_optimizers), weight/affine gradients are written straight into the
+# pre-allocated `.grad` views of the flat gradient arena and the autograd function returns None for
+# them: no temporary, no AccumulateGrad add.  Valid because every parameter of this model is used
+# exactly once per backward and the arena is re-zeroed every step (train_step).
+DIRECT_GRAD = False
+
+
+def _direct_grad_target(p):
+    g = p.grad
+    if DIRECT_GRAD and g is not None and g.shape == p.shape and g.stride() == p.stride() and g.is_cuda:
+        return g
+    return None
+
+
+def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None):
     B, H, W, Cin = x.shape
     Cout, _, R, S = w_shape
     _, Ho, Wo, _ = dy.shape
-    dw = torch.empty(R, S, Cin, Cout, device=x.device, dtype=torch.float32)
+    dw = rsck(out) if out is not None else torch.empty(R, S, Cin, Cout, device=x.device, dtype=torch.float32)
     _launch("conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_bwd_weight", hip.ptr(x), hip.ptr(dy), hip.ptr(dw),
             B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad)
-    return dw.permute(3, 2, 0, 1)
+    return out if out is not None else dw.permute(3, 2, 0, 1)
 
 
 def colsum(x2d_rows, C):
@@ -165,6 +181,7 @@ class ConvBnAct(Function):
         ctx.meta = dict(stride=meta["stride"], pad=meta["pad"], act=meta["act"], training=training, drop_p=drop_p,
                         drop_key=meta["drop_key"], has_bias=bias is not None, has_res=res is not None)
         ctx.save_for_backward(x, w, gamma, y, z, mean, invstd)
+        ctx.beta_ref = beta
         return z
 
     @staticmethod
@@ -176,15 +193,22 @@ class ConvBnAct(Function):
         M = B * Ho * Wo
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if m["has_res"] else None
-        dgamma = torch.empty(C, device=y.device, dtype=torch.float32)
-        dbeta = torch.empty(C, device=y.device, dtype=torch.float32)
+        tg, tb = _direct_grad_target(gamma), _direct_grad_target(ctx.beta_ref)
+        direct_affine = tg is not None and tb is not None
+        dgamma = tg if direct_affine else torch.empty(C, device=y.device, dtype=torch.float32)
+        dbeta = tb if direct_affine else torch.empty(C, device=y.device, dtype=torch.float32)
         sums = torch.empty(2 * C, device=y.device, dtype=torch.float64)
         hip.call("fs_bn_act_bwd", hip.ptr(dz), hip.ptr(z), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), M, C,
                  m["act"], 1 if m["training"] else 0, float(m["drop_p"]), int(m["drop_key"]), hip.ptr(dy), hip.ptr(dres),
                  hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums))
         dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"]) if ctx.needs_input_grad[0] else None
-        dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"])
+        tgt = _direct_grad_target(w)
+        dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt)
+        if tgt is not None:
+            dw = None
         dbias = colsum(dy, C) if m["has_bias"] else None
+        if direct_affine:
+            dgamma = dbeta = None
         return dx, dw, dbias, dgamma, dbeta, dres, None
 
 
@@ -203,7 +227,10 @@ class ConvBias(Function):
         stride, pad, has_bias = ctx.sp
         dy = dy.contiguous()
         dx = conv2d_bwd_data(dy, w, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
-        dw = conv2d_bwd_weight(x, dy, w.shape, stride, pad)
+        tgt = _direct_grad_target(w)
+        dw = conv2d_bwd_weight(x, dy, w.shape, stride, pad, out=tgt)
+        if tgt is not None:
+            dw = None
         db = colsum(dy, dy.shape[-1]) if has_bias else None
         return dx, dw, db, None, None
 

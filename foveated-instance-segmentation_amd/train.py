@@ -107,6 +107,8 @@ def create_optimizers(nets, cfg):
     if cfg.TRAIN.optim.lower() != "adam":
         raise NotImplementedError("only TRAIN.optim='adam' is usable in the reference (the sgd branch returns undefined names)")
     T = cfg.TRAIN
+    from . import ops
+    ops.DIRECT_GRAD = True      # gradients land directly in the flat arenas (see ops.DIRECT_GRAD)
     mk = lambda net, mult, zoom: FlatAdam(list(net.parameters()), lr=T.lr_encoder, weight_decay=T.weight_decay,  # noqa: E731
                                           lr_mult=mult, zoom=zoom)
     return (mk(net_encoder, T.lr_mult_encoder, False), mk(net_decoder, T.lr_mult_decoder, False),
