@@ -228,7 +228,14 @@ struct AffArgs {
   int transposed;
   float drop_scale; uint32_t drop_thresh, drop_key;
   unsigned src_bytes, w_bytes;
+  // output sub-grid (stride>1 bwd-data is run as stride^2 dense sub-problems, one per output parity
+  // class, each with its own tap subset): loop grid Hq x Wq, dst pixel = (py*os+oy0, px*os+ox0),
+  // taps r = r0 + tstep*tr' (nR of them), s likewise; source row of tap' (0,0) = py + cy.
+  int Hq, Wq, os, oy0, ox0, r0, s0, tstep, nR, nS, cy, cx;
+  int nx, ny;     // tile grid (1-D launch, XCD-aware remap)
 };
+
+static thread_local hipStream_t a_stream = nullptr;   // host: stream of the launch being issued
 
 template <int MT>
 __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
@@ -238,12 +245,19 @@ __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
   __shared__ float Bs[2][BK * BN];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long M = (long)a.B * a.Hd * a.Wd;
-  const long m0 = (long)blockIdx.x * TM;
-  const int n0 = blockIdx.y * BN;
+  const long M = (long)a.B * a.Hq * a.Wq;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+  // contiguous range of tiles (neighbouring pixel tiles share halo rows, the ny channel tiles of one
+  // pixel tile share the whole A tile -> they meet in the same 4 MB L2).  Bijective for any count.
+  const int nwg = a.nx * a.ny;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd = nwg >> 3, rm = nwg & 7;
+  const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+  const long m0 = (long)(wg / a.ny) * TM;
+  const int n0 = (wg % a.ny) * BN;
   const int q = tid & 7, arow = tid >> 3;
   const int sgn = a.transposed ? -1 : 1;
-  const int ntap = a.R * a.S;
+  const int ntap = a.nR * a.nS;
 
   // ---- hoisted per-row state: element offset of tap (0,0) and the tap validity mask -----------
   int roff[NR];
@@ -253,15 +267,15 @@ __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
     const long m = m0 + arow + 32 * i;
     roff[i] = 0; rmask[i] = 0u;
     if (m < M) {
-      const int b = (int)(m / ((long)a.Hd * a.Wd));
-      const int rem = (int)(m - (long)b * a.Hd * a.Wd);
-      const int py = rem / a.Wd, px = rem - py * a.Wd;
-      const int iy0 = a.transposed ? py + a.pad : py * a.stride - a.pad;
-      const int ix0 = a.transposed ? px + a.pad : px * a.stride - a.pad;
+      const int b = (int)(m / ((long)a.Hq * a.Wq));
+      const int rem = (int)(m - (long)b * a.Hq * a.Wq);
+      const int py = rem / a.Wq, px = rem - py * a.Wq;
+      const int iy0 = a.transposed ? py + a.cy : py * a.stride - a.pad;
+      const int ix0 = a.transposed ? px + a.cx : px * a.stride - a.pad;
       roff[i] = ((b * a.Hs + iy0) * a.Ws + ix0) * a.Cs + 4 * q;
       uint32_t mk = 0u;
       for (int t = 0; t < ntap; ++t) {
-        const int tr = t / a.S, ts = t - tr * a.S;
+        const int tr = t / a.nS, ts = t - tr * a.nS;
         const int iy = iy0 + sgn * tr, ix = ix0 + sgn * ts;
         if (iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws) mk |= (1u << t);
       }
@@ -291,13 +305,14 @@ __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
   const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.w, a.w_bytes);
   f32x4 ra[NR], rb[2];
   auto load_stage = [&](int st) {
-    const int tap = st / nchunk, c0 = (st - tap * nchunk) * BK;
-    const int tr = tap / a.S, ts = tap - tr * a.S;
+    const int tapq = st / nchunk, c0 = (st - tapq * nchunk) * BK;
+    const int tr = tapq / a.nS, ts = tapq - tr * a.nS;
+    const int tap = (a.r0 + a.tstep * tr) * a.S + (a.s0 + a.tstep * ts);   // filter tap for the weights
     const int aoff = sgn * (tr * a.Ws + ts) * a.Cs + c0;          // uniform
     const bool aok = !ktail || (c0 + 4 * q < a.Cs);
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const bool ok = ((rmask[i] >> tap) & 1u) && aok;
+      const bool ok = ((rmask[i] >> tapq) & 1u) && aok;
       ra[i] = buf_load4(rsrc_a, ok ? (unsigned)(roff[i] + aoff) * 4u : OOB);
     }
     if (!a.transposed) {
@@ -369,8 +384,10 @@ __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
       }
   };
 
-  load_stage(0);
-  store_stage(0);
+  if (nstage > 0) {
+    load_stage(0);
+    store_stage(0);
+  }
   if (nstage > 1) load_stage(1);
   __syncthreads();
   Frag f0, f1;
@@ -410,7 +427,13 @@ __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
         const long m = m0 + wave * 32 * MT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m >= M) continue;
         float v = acc[i][t][r] + bv;
-        const long e = m * a.Cd + n;
+        long e = m * a.Cd + n;
+        if (a.os > 1) {                             // strided sub-grid -> scattered destination pixel
+          const int b = (int)(m / ((long)a.Hq * a.Wq));
+          const int rem = (int)(m - (long)b * a.Hq * a.Wq);
+          const int py = rem / a.Wq, px = rem - py * a.Wq;
+          e = (((long)b * a.Hd + py * a.os + a.oy0) * a.Wd + px * a.os + a.ox0) * a.Cd + n;
+        }
         if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
         a.dst[e] = v;
       }
@@ -429,6 +452,7 @@ struct WgradArgs {
   int B, H, W, Cin, Ho, Wo, Cout;
   int R, S, stride, pad;
   int pix_per_split;
+  int tiles, ntap, nsplit;
 };
 
 template <bool VEC>
@@ -437,11 +461,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   __shared__ float Bs[BK * 64];   // [pix][co]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_n = (a.Cout + 63) / 64;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  // Plain dispatch order (tile fastest, then tap, then pixel split).  An XCD-contiguous remap of the
+  // splits was measured 8-10 % SLOWER here (72 vs 79 TF on 64->64@80^2), so it is not applied.
+  const int wg = blockIdx.x;
+  const int split = wg / (a.tiles * a.ntap);
+  const int rest = wg - split * (a.tiles * a.ntap);
+  const int tap = rest / a.tiles, tile = rest - tap * a.tiles;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int ci0 = tm * 64, co0 = tn * 64;
-  const int tap = blockIdx.y, tr = tap / a.S, ts = tap - tr * a.S;
+  const int tr = tap / a.S, ts = tap - tr * a.S;
   const long P = (long)a.B * a.Ho * a.Wo;
-  const long p_begin = (long)blockIdx.z * a.pix_per_split;
+  const long p_begin = (long)split * a.pix_per_split;
   const long p_end = (p_begin + a.pix_per_split < P) ? p_begin + a.pix_per_split : P;
 
   const int c4 = 4 * (tid & 15), prow = tid >> 4;   // rows prow + 16*i, i<2
@@ -519,14 +549,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+int launch_affine_one(AffArgs& a) {
+  const long M = (long)a.B * a.Hq * a.Wq;
+  a.nx = cdiv(M, 128);
+  a.ny = cdiv(a.Cd, BN);
+  // MT=2 (256-row tiles) needs 84 KB of LDS = one workgroup per CU and measured 20-25 % slower.
+  hipLaunchKernelGGL(conv_igemm_affine_kernel<1>, dim3(a.nx * a.ny), dim3(256), 0, a_stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
 int launch_affine(const ConvArgs& c, long M) {
   AffArgs a{c.src, c.w, c.bias, c.dst, c.B, c.Hs, c.Ws, c.Cs, c.Hd, c.Wd, c.Cd, c.R, c.S, c.stride, c.pad, c.transposed,
             c.drop_scale, c.drop_thresh, c.drop_key,
-            (unsigned)((size_t)c.B * c.Hs * c.Ws * c.Cs * 4), (unsigned)((size_t)c.R * c.S * c.Cs * c.Cd * 4)};
-  const int ny = cdiv(c.Cd, BN);
-  // MT=2 (256-row tiles) needs 84 KB of LDS = one workgroup per CU and measured 20-25 % slower.
-  hipLaunchKernelGGL(conv_igemm_affine_kernel<1>, dim3(cdiv(M, 128), ny), dim3(256), 0, c.stream_, a);
-  FS_LAUNCH_CHECK();
+            (unsigned)((size_t)c.B * c.Hs * c.Ws * c.Cs * 4), (unsigned)((size_t)c.R * c.S * c.Cs * c.Cd * 4),
+            c.Hd, c.Wd, 1, 0, 0, 0, 0, 1, c.R, c.S, c.pad, c.pad, 0, 0};
+  a_stream = c.stream_;
+  (void)M;
+  if (!c.transposed || c.stride == 1) return launch_affine_one(a);
+  // stride>1 bwd-data: one dense sub-problem per output parity class (oy0, ox0).  dX pixel y receives
+  // tap r iff (y + pad - r) % stride == 0, i.e. r = r0 + stride*t with r0 = (oy0 + pad) % stride, and then
+  // reads dY row (y + pad - r)/stride = py + (oy0 + pad - r0)/stride - t.
+  const int st = c.stride;
+  for (int oy0 = 0; oy0 < st; ++oy0)
+    for (int ox0 = 0; ox0 < st; ++ox0) {
+      AffArgs b = a;
+      b.os = st; b.oy0 = oy0; b.ox0 = ox0; b.tstep = st;
+      b.Hq = (c.Hd - oy0 + st - 1) / st; b.Wq = (c.Wd - ox0 + st - 1) / st;
+      b.r0 = (oy0 + c.pad) % st; b.s0 = (ox0 + c.pad) % st;
+      b.nR = b.r0 < c.R ? (c.R - b.r0 + st - 1) / st : 0;
+      b.nS = b.s0 < c.S ? (c.S - b.s0 + st - 1) / st : 0;
+      if (b.nR == 0 || b.nS == 0) { b.nR = 0; b.nS = 0; }       // no tap reaches this class: writes zeros
+      b.cy = (oy0 + c.pad - b.r0) / st; b.cx = (ox0 + c.pad - b.s0) / st;
+      if (b.Hq <= 0 || b.Wq <= 0) continue;
+      int e = launch_affine_one(b);
+      if (e != FS_OK) return e;
+    }
   return FS_OK;
 }
 
@@ -568,7 +626,7 @@ int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H,
   ConvArgs a{dy, w, nullptr, dx, B, Ho, Wo, Cout, H, W, Cin, R, S, stride, pad, 1, 1.f, 0u, 0u};
   const long M = (long)B * H * W;
   a.stream_ = stream;
-  if (stride == 1 && (Cin % 4 == 0) && (Cout % 4 == 0) && R * S <= 32 && (long)B * Ho * Wo * Cout < 2147483647L)
+  if ((Cin % 4 == 0) && (Cout % 4 == 0) && R * S <= 32 && (long)B * Ho * Wo * Cout < 2147483647L)
     return launch_affine(a, M);
   dim3 grid(cdiv(M, BM), cdiv(Cin, BN));
   if ((Cin % 4 == 0) && (Cout % 4 == 0))
@@ -595,8 +653,8 @@ int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
   long pps = (P + nsplit - 1) / nsplit;
   pps = ((pps + BK - 1) / BK) * BK;
   nsplit = (P + pps - 1) / pps;
-  WgradArgs a{x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, (int)pps};
-  dim3 grid(tiles, R * S, (unsigned)nsplit);
+  WgradArgs a{x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, (int)pps, tiles, R * S, (int)nsplit};
+  dim3 grid((unsigned)(tiles * R * S * nsplit));
   if ((Cin % 4 == 0) && (Cout % 4 == 0))
     hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, stream, a);
   else

@@ -114,7 +114,7 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad):
     Cout, _, R, S = w.shape
     _, Ho, Wo, _ = dy.shape
     dx = torch.empty(B, H, W, Cin, device=dy.device, dtype=torch.float32)
-    kind = "conv_affine" if (Cin % 4 == 0 and Cout % 4 == 0 and stride == 1) else "conv_generic"
+    kind = "conv_affine" if (Cin % 4 == 0 and Cout % 4 == 0) else "conv_generic"
     _launch(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx),
             B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad)
     return dx
@@ -128,6 +128,8 @@ DIRECT_GRAD = False
 
 
 def _direct_grad_target(p):
+    if not p.is_leaf:
+        return None
     g = p.grad
     if DIRECT_GRAD and g is not None and g.shape == p.shape and g.stride() == p.stride() and g.is_cuda:
         return g

@@ -568,3 +568,65 @@ def test_full_size_properties():
     gr = ops.GaussGrid.apply(uni, g1d, 45)
     assert float((gr[:, :, :, 0] + gr[:, :, :, 0].flip(2)).abs().max()) <= 1e-6
     assert float((gr[:, :, :, 1] + gr[:, :, :, 1].flip(1)).abs().max()) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser + full training step
+# ------------------------------------------------------------------------------------------------
+def test_flat_adam_matches_torch_adam():
+    from fovealseg import train
+    g = torch.Generator().manual_seed(21)
+    shapes = [(8, 4, 3, 3), (5,), (7, 3)]
+    cpu = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    dev = []
+    for p in cpu:
+        if p.dim() == 4:
+            t = ops.new_rsck_weight(*p.shape, device=DEV)
+            t.copy_(p.detach())
+        else:
+            t = p.detach().clone().to(DEV)
+        dev.append(torch.nn.Parameter(t))
+    ref = torch.optim.Adam(cpu, lr=1e-2, weight_decay=1e-4)
+    opt = train.FlatAdam(dev, lr=1e-2, weight_decay=1e-4, lr_mult=1.0, zoom=False)
+    for step in range(3):
+        opt.zero_grad()
+        for pc, pd in zip(cpu, dev):
+            gr = torch.randn(pc.shape, generator=g)
+            pc.grad = gr.clone()
+            pd.grad.copy_(gr)
+        ref.step()
+        opt.step()
+    for pc, pd in zip(cpu, dev):
+        assert pd.permute(2, 3, 1, 0).is_contiguous() if pd.dim() == 4 else True
+        assert np.abs(pd.detach().cpu().numpy() - pc.detach().numpy()).max() <= 2e-6
+
+
+def test_train_and_eval_step_end_to_end():
+    """Two optimisation steps + one eval step through fovealseg.train on a small batch: finite losses,
+    parameters move, BN running stats update, eval returns the reference's 6-tuple."""
+    from fovealseg import train
+    cfg = fovealseg.lvis50_cfg()
+    module, nets = train.build_module(cfg, device=DEV)
+    module.train()
+    opts = train.create_optimizers(nets, cfg)
+    try:
+        batch = train.synthetic_batch(2, 128, 128, seed=5, device=DEV)
+        w0 = module.encoder.conv1.weight.detach().clone()
+        rm0 = module.encoder.bn1.running_mean.clone()
+        losses = []
+        for it in range(2):
+            out = train.train_step(module, opts, batch, cfg, epoch=1, cur_iter=it)
+            assert len(out) == 3
+            losses.append(float(out[0].detach()))
+        assert all(np.isfinite(losses))
+        assert opts[0].param_groups[0]["lr"] == 0.001 * 0.1
+        assert float((module.encoder.conv1.weight.detach() - w0).abs().max()) > 0
+        assert float((module.encoder.bn1.running_mean - rm0).abs().max()) > 0
+        assert int(module.state_dict()["encoder.bn1.num_batches_tracked"]) == 2
+        g = module.encoder.conv1.weight.grad
+        assert g.data_ptr() >= opts[0].flat.grad.data_ptr() and bool(torch.isfinite(g).all())
+        module.eval()
+        outs = train.eval_step(module, batch)
+        assert len(outs) == 6 and all(np.isfinite(float(o)) for o in outs)
+    finally:
+        ops.DIRECT_GRAD = False
