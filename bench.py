@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--serial-streams", action="store_true", help="run the HRNet branches on one stream (profiling)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
 
     import fovealseg
@@ -67,9 +68,9 @@ def main():
     from fovealseg import ops
 
     fovealseg.hip.load()       # fail loudly if the HIP library is missing
-    rank, local_rank, world = T.ddp_setup()
+    rank, local_rank, world = T.ddp_setup(backend=args.backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     cfg = fovealseg.lvis50_cfg()

@@ -153,11 +153,11 @@ def ddp_setup(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
     return rank, local_rank, world
 
 
