@@ -24,6 +24,19 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP
 PEAK_HBM_GBS = 8000.0
 
 
+def _profiled_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this same command
+    (profiles/r01/hbm_traffic_serial.json; FETCH_SIZE doubled per the gfx950 correction).  PMC counters
+    cannot be read from inside the benchmark process, so this is the offline measurement, or None."""
+    path = os.path.join(ROOT, "profiles", "r01", "hbm_traffic_serial.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)[kernel]
+        return {"hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "source": "profiles/r01/hbm_traffic_serial.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+    except Exception:
+        return None
+
+
 def cpu_baseline(batch=4, H=1024, threads=None):
     """The CPU oracle (port of the reference algorithm) timed on this host: B=4, 1024^2, one warm-up and
     one timed train-mode forward+backward (BASELINE.json configs[0])."""
@@ -106,7 +119,7 @@ def main():
     # therefore repeated with the branch streams serialised and every conv launch bracketed by HIP
     # events on the launch stream (this pass is NOT part of `value`).
     timer = None
-    if not args.no_kernel_timer and rank == 0:
+    if not args.no_kernel_timer and world == 1:      # single-GPU only: the step contains collectives
         saved = Mods.PARALLEL_BRANCHES
         Mods.PARALLEL_BRANCHES = False
         timer = ops.KernelTimer()
@@ -145,7 +158,7 @@ def main():
                 line["roofline"] = {
                     "kernel": "conv_igemm_affine_kernel<1> (fwd + stride-1 bwd-data implicit GEMM, fp32 MFMA 32x32x2)",
                     "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": _profiled_traffic("conv_igemm_affine_kernel<1>"),
                     "launches_per_step": k["launches"] // args.steps,
                     "avg_launch_us": round(1000.0 * k["total_ms"] / k["launches"], 2),
                     "gflop_per_launch": round(k["flops"] / k["launches"] / 1e9, 3),
@@ -155,7 +168,7 @@ def main():
             w = summ.get("conv_wgrad")
             if w:
                 line["roofline_wgrad"] = {
-                    "kernel": "conv_wgrad_kernel<true>", "bound": "mfma",
+                    "kernel": "conv_wgrad_taps_kernel<3|9> + conv_wgrad_kernel (bwd-weight, fp32 MFMA)", "bound": "mfma",
                     "achieved": round(w["flops"] / (w["total_ms"] * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(w["flops"] / (w["total_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                     "avg_launch_us": round(1000.0 * w["total_ms"] / w["launches"], 2),

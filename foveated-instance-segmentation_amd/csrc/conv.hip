@@ -41,6 +41,7 @@ struct ConvArgs {
   float drop_scale;   // 1/(1-p)
   uint32_t drop_thresh, drop_key;   // thresh 0 = no dropout
   hipStream_t stream_ = nullptr;    // host only
+  float* stats_ = nullptr;          // host only: BN partial-sum slab (affine forward)
 };
 
 template <bool VEC>
@@ -233,6 +234,7 @@ struct AffArgs {
   // taps r = r0 + tstep*tr' (nR of them), s likewise; source row of tap' (0,0) = py + cy.
   int Hq, Wq, os, oy0, ox0, r0, s0, tstep, nR, nS, cy, cx;
   int nx, ny;     // tile grid (1-D launch, XCD-aware remap)
+  float* stats;   // optional [nx][Cd][2] per-workgroup column sums / sums of squares of the STORED values
 };
 
 static thread_local hipStream_t a_stream = nullptr;   // host: stream of the launch being issued
@@ -415,6 +417,7 @@ __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
     __syncthreads();
   }
 
+  float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};     // BatchNorm statistics of this lane's 2 columns
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -436,8 +439,27 @@ __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
         }
         if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
         a.dst[e] = v;
+        csum[t] += v; csq[t] += v * v;
       }
     }
+  if (a.stats != nullptr) {
+    // lanes l and l+32 hold the same columns (rows +4): combine, then the 4 waves through LDS
+    __syncthreads();                                  // all MFMA-stage LDS reads are finished
+    float* red = &As[0][0];                           // [4 waves][64 cols][2]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float s1 = csum[t] + __shfl_xor(csum[t], 32, 64), s2 = csq[t] + __shfl_xor(csq[t], 32, 64);
+      if (lh == 0) { red[(wave * 64 + 32 * t + l31) * 2] = s1; red[(wave * 64 + 32 * t + l31) * 2 + 1] = s2; }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int col = tid >> 1, which = tid & 1;
+      const float v = red[(0 * 64 + col) * 2 + which] + red[(1 * 64 + col) * 2 + which] + red[(2 * 64 + col) * 2 + which] +
+                      red[(3 * 64 + col) * 2 + which];
+      const int n = n0 + col;
+      if (n < a.Cd) a.stats[((long)(wg / a.ny) * a.Cd + n) * 2 + which] = v;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -676,7 +698,7 @@ int launch_affine(const ConvArgs& c, long M) {
   AffArgs a{c.src, c.w, c.bias, c.dst, c.B, c.Hs, c.Ws, c.Cs, c.Hd, c.Wd, c.Cd, c.R, c.S, c.stride, c.pad, c.transposed,
             c.drop_scale, c.drop_thresh, c.drop_key,
             (unsigned)((size_t)c.B * c.Hs * c.Ws * c.Cs * 4), (unsigned)((size_t)c.R * c.S * c.Cs * c.Cd * 4),
-            c.Hd, c.Wd, 1, 0, 0, 0, 0, 1, c.R, c.S, c.pad, c.pad, 0, 0};
+            c.Hd, c.Wd, 1, 0, 0, 0, 0, 1, c.R, c.S, c.pad, c.pad, 0, 0, c.stats_};
   a_stream = c.stream_;
   (void)M;
   if (!c.transposed || c.stride == 1) return launch_affine_one(a);
@@ -729,6 +751,27 @@ int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, i
     hipLaunchKernelGGL(conv_igemm_kernel<false>, grid, dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;
+}
+
+// include/fovealseg.h: fs_conv2d_fwd_stats -- forward conv that also emits per-workgroup BatchNorm partials.
+// stats = [ceil(B*Ho*Wo/128)][Cout][2] floats.  Requires Cin%4==0 && Cout%4==0 (the affine kernel).
+int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* stats, int B, int H, int W, int Cin,
+                        int Ho, int Wo, int Cout, int R, int S, int stride, int pad, float drop_p, uint32_t drop_key,
+                        hipStream_t stream) {
+  FS_REQUIRE(x && w && y && stats && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
+  FS_REQUIRE(Ho == (H + 2 * pad - R) / stride + 1 && Wo == (W + 2 * pad - S) / stride + 1);
+  FS_REQUIRE(drop_p >= 0.f && drop_p < 1.f);
+  FS_REQUIRE((Cin % 4 == 0) && (Cout % 4 == 0) && R * S <= 32 && (long)B * H * W * Cin < 2147483647L);
+  ConvArgs a{x, w, bias, y, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, 0, 1.f, 0u, drop_key};
+  a.stream_ = stream;
+  a.stats_ = stats;
+  if (drop_p > 0.f) {
+    a.drop_scale = 1.0f / (float)(1.0 - (double)drop_p);
+    a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
+  }
+  const long M = (long)B * Ho * Wo;
+  FS_REQUIRE(M * Cout < 4294967296L);
+  return launch_affine(a, M);
 }
 
 // include/fovealseg.h: fs_conv2d_bwd_data   (dX has the forward input's shape B,H,W,Cin)

@@ -65,6 +65,34 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, long M, int 
   }
 }
 
+// one block per channel: reduce the per-workgroup partials written by the conv epilogue (double tree),
+// then the same finalisation as bn_finalize_kernel
+__global__ __launch_bounds__(256) void bn_finalize_slab_kernel(const float* __restrict__ slab, int nwg, long M, int C,
+                                                               float momentum, float eps, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, float* __restrict__ mean,
+                                                               float* __restrict__ invstd) {
+  __shared__ double red[16];
+  const int c = blockIdx.x;
+  double s = 0.0, ss = 0.0;
+  for (int i = threadIdx.x; i < nwg; i += blockDim.x) {
+    s += (double)slab[((long)i * C + c) * 2];
+    ss += (double)slab[((long)i * C + c) * 2 + 1];
+  }
+  s = block_sum<double>(s, red);
+  ss = block_sum<double>(ss, red);
+  if (threadIdx.x != 0) return;
+  const double mu = s / (double)M;
+  double var = ss / (double)M - mu * mu;
+  if (var < 0) var = 0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {
+    const float unbiased = (float)(var * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+    running_mean[c] = momentum * (float)mu + (1.f - momentum) * running_mean[c];
+    running_var[c] = momentum * unbiased + (1.f - momentum) * running_var[c];
+  }
+}
+
 __global__ void bn_eval_prepare_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
                                        int C, float eps, float* __restrict__ mean, float* __restrict__ invstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -367,6 +395,16 @@ int fs_bn_stats(const float* y, long M, int C, float momentum, float eps, float*
   FS_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, sums, M, C, momentum, eps,
                      running_mean, running_var, mean, invstd);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// Finalise training-mode statistics from the conv epilogue's partial slab ([nwg][C][2] floats).
+int fs_bn_finalize_slab(const float* slab, int nwg, long M, int C, float momentum, float eps, float* running_mean,
+                        float* running_var, float* mean, float* invstd, hipStream_t stream) {
+  FS_REQUIRE(slab && mean && invstd && nwg > 0 && M > 0 && C > 0);
+  hipLaunchKernelGGL(bn_finalize_slab_kernel, dim3(C), dim3(256), 0, stream, slab, nwg, M, C, momentum, eps, running_mean,
+                     running_var, mean, invstd);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

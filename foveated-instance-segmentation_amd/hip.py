@@ -30,9 +30,11 @@ SIGNATURES = {
     "fs_grid_sample_bwd_input": "pppiiiiiii",
     "fs_inverse_index_maps": "ppplii",
     "fs_conv2d_fwd": "ppppiiiiiiiiiiifu",
+    "fs_conv2d_fwd_stats": "pppppiiiiiiiiiiifu",
     "fs_conv2d_bwd_data": "pppiiiiiiiiiii",
     "fs_conv2d_bwd_weight": "pppiiiiiiiiiii",
     "fs_bn_stats": "pliffppppp",
+    "fs_bn_finalize_slab": "piliffpppp",
     "fs_bn_eval_prepare": "ppifpp",
     "fs_bn_act_fwd": "ppppppplii",
     "fs_bn_act_bwd": "ppppppliiifuppppp",

@@ -109,6 +109,23 @@ def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0):
     return y
 
 
+FUSE_BN_STATS = True     # BatchNorm batch statistics come out of the conv epilogue (fs_conv2d_fwd_stats)
+
+
+def conv2d_fwd_stats(x, w, bias, stride, pad, drop_p=0.0, drop_key=0):
+    """Forward conv + per-workgroup BatchNorm partial sums (slab [nwg][Cout][2])."""
+    B, H, W, Cin = x.shape
+    Cout, Cin2, R, S = w.shape
+    assert Cin == Cin2, (x.shape, w.shape)
+    Ho, Wo = _out_hw(H, W, R, S, stride, pad)
+    y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
+    nwg = (B * Ho * Wo + 127) // 128
+    slab = torch.empty(nwg * Cout * 2, device=x.device, dtype=torch.float32)
+    _launch("conv_affine", 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd_stats", hip.ptr(x), hip.ptr(rsck(w)),
+            hip.ptr(bias), hip.ptr(y), hip.ptr(slab), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, float(drop_p), int(drop_key))
+    return y, slab, nwg
+
+
 def conv2d_bwd_data(dy, w, x_shape, stride, pad):
     B, H, W, Cin = x_shape
     Cout, _, R, S = w.shape
@@ -164,12 +181,21 @@ class ConvBnAct(Function):
     def forward(ctx, x, w, bias, gamma, beta, res, meta):
         training = meta["training"]
         drop_p = meta["drop_p"] if training else 0.0
-        y = conv2d_fwd(x, w, bias, meta["stride"], meta["pad"], drop_p, meta["drop_key"])
+        Cout, Cin = w.shape[0], w.shape[1]
+        fused_stats = training and FUSE_BN_STATS and Cin % 4 == 0 and Cout % 4 == 0
+        if fused_stats:
+            y, slab, nwg = conv2d_fwd_stats(x, w, bias, meta["stride"], meta["pad"], drop_p, meta["drop_key"])
+        else:
+            y = conv2d_fwd(x, w, bias, meta["stride"], meta["pad"], drop_p, meta["drop_key"])
         B, Ho, Wo, C = y.shape
         M = B * Ho * Wo
         mean = torch.empty(C, device=y.device, dtype=torch.float32)
         invstd = torch.empty(C, device=y.device, dtype=torch.float32)
-        if training:
+        if fused_stats:
+            hip.call("fs_bn_finalize_slab", hip.ptr(slab), nwg, M, C, float(meta["momentum"]), BN_EPS,
+                     hip.ptr(meta["running_mean"]), hip.ptr(meta["running_var"]), hip.ptr(mean), hip.ptr(invstd))
+            meta["num_batches_tracked"].add_(1)
+        elif training:
             sums = torch.empty(2 * C, device=y.device, dtype=torch.float64)
             hip.call("fs_bn_stats", hip.ptr(y), M, C, float(meta["momentum"]), BN_EPS, hip.ptr(meta["running_mean"]),
                      hip.ptr(meta["running_var"]), hip.ptr(mean), hip.ptr(invstd), hip.ptr(sums))

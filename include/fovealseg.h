@@ -64,6 +64,12 @@ int fs_inverse_index_maps(const float* grid, long long* u, long long* v, long n,
  * models/hrnetv2_nodownsp.py:49-50,54-55 and every nn.Conv2d on the path. */
 int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Ho, int Wo,
                   int Cout, int R, int S, int stride, int pad, float drop_p, uint32_t drop_key, fs_stream_t stream);
+/* Same forward conv, additionally writing per-workgroup BatchNorm partial sums of the stored output into
+ * stats = [ceil(B*Ho*Wo/128)][Cout][2] floats (needs Cin%4==0 && Cout%4==0); finalise with fs_bn_finalize_slab.
+ * Fuses the statistics pass of F.batch_norm(training=True) (lib/nn/modules/batchnorm.py:58-61) into the conv. */
+int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* stats, int B, int H, int W, int Cin,
+                        int Ho, int Wo, int Cout, int R, int S, int stride, int pad, float drop_p, uint32_t drop_key,
+                        fs_stream_t stream);
 /* convolution_backward: input gradient / weight gradient (dw overwritten). */
 int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R,
                        int S, int stride, int pad, fs_stream_t stream);
@@ -75,6 +81,8 @@ int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
  * lib/nn/modules/batchnorm.py:56-61.  sums = 2*C doubles scratch. */
 int fs_bn_stats(const float* y, long M, int C, float momentum, float eps, float* running_mean, float* running_var, float* mean,
                 float* invstd, double* sums, fs_stream_t stream);
+int fs_bn_finalize_slab(const float* slab, int nwg, long M, int C, float momentum, float eps, float* running_mean,
+                        float* running_var, float* mean, float* invstd, fs_stream_t stream);
 int fs_bn_eval_prepare(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* invstd,
                        fs_stream_t stream);
 /* out = act((y-mean)*invstd*gamma + beta [+ res]).  models/hrnetv2_nodownsp.py:51-52,56-62. */
