@@ -36,7 +36,7 @@ struct ConvArgs {
   const float* bias;  // fwd only, may be null
   float* dst;         // fwd: Y (B,Hd,Wd,Cd)      bwd-data: dX
   int B, Hs, Ws, Cs, Hd, Wd, Cd;
-  int R, S, stride, pad;
+  int R, S, stride, pad, dil;
   int transposed;     // 0 = forward, 1 = bwd-data
   float drop_scale;   // 1/(1-p)
   uint32_t drop_thresh, drop_key;   // thresh 0 = no dropout
@@ -86,11 +86,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         int iy, ix;
         bool ok;
         if (!a.transposed) {
-          iy = py[i] * a.stride - a.pad + tr;
-          ix = px[i] * a.stride - a.pad + ts;
+          iy = py[i] * a.stride - a.pad + tr * a.dil;
+          ix = px[i] * a.stride - a.pad + ts * a.dil;
           ok = (iy >= 0) & (iy < a.Hs) & (ix >= 0) & (ix < a.Ws);
         } else {
-          int ty = py[i] + a.pad - tr, tx = px[i] + a.pad - ts;
+          int ty = py[i] + a.pad - tr * a.dil, tx = px[i] + a.pad - ts * a.dil;
           ok = (ty >= 0) & (tx >= 0);
           if (a.stride > 1) {
             ok = ok & (ty % a.stride == 0) & (tx % a.stride == 0);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 struct AffArgs {
   const float* src; const float* w; const float* bias; float* dst;
   int B, Hs, Ws, Cs, Hd, Wd, Cd;
-  int R, S, stride, pad;
+  int R, S, stride, pad, dil;
   int transposed;
   float drop_scale; uint32_t drop_thresh, drop_key;
   unsigned src_bytes, w_bytes;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
       uint32_t mk = 0u;
       for (int t = 0; t < ntap; ++t) {
         const int tr = t / a.nS, ts = t - tr * a.nS;
-        const int iy = iy0 + sgn * tr, ix = ix0 + sgn * ts;
+        const int iy = iy0 + sgn * tr * a.dil, ix = ix0 + sgn * ts * a.dil;
         if (iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws) mk |= (1u << t);
       }
       rmask[i] = mk;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
     const int tapq = st / nchunk, c0 = (st - tapq * nchunk) * BK;
     const int tr = tapq / a.nS, ts = tapq - tr * a.nS;
     const int tap = (a.r0 + a.tstep * tr) * a.S + (a.s0 + a.tstep * ts);   // filter tap for the weights
-    const int aoff = sgn * (tr * a.Ws + ts) * a.Cs + c0;          // uniform
+    const int aoff = sgn * a.dil * (tr * a.Ws + ts) * a.Cs + c0;  // uniform
     const bool aok = !ktail || (c0 + 4 * q < a.Cs);
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -472,7 +472,7 @@ struct WgradArgs {
   const float* dy;   // (B,Ho,Wo,Cout)
   float* dw;         // [R][S][Cin][Cout], zero-initialised
   int B, H, W, Cin, Ho, Wo, Cout;
-  int R, S, stride, pad;
+  int R, S, stride, pad, dil;
   int pix_per_split;
   int tiles, ntap, nsplit;
 };
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         const int b = (int)(p / ((long)a.Ho * a.Wo));
         const int rem = (int)(p - (long)b * a.Ho * a.Wo);
         const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-        const int iy = oy * a.stride - a.pad + tr, ix = ox * a.stride - a.pad + ts;
+        const int iy = oy * a.stride - a.pad + tr * a.dil, ix = ox * a.stride - a.pad + ts * a.dil;
         if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
           const int c = ci0 + c4;
           const float* q = a.x + (((long)b * a.H + iy) * a.W + ix) * a.Cin + c;
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(WgradArgs a) {
         uint32_t mk = 0u;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+          const int iy = iy0 + (t / 3) * a.dil, ix = ix0 + (t % 3) * a.dil;
           if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) mk |= 1u << t;
         }
         xmask[i] = xc_ok ? mk : 0u;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(WgradArgs a) {
       }
     }
     auto load_x = [&](int tap, f32x4* r) {
-      const int toff = ((tap / 3) * a.W + (tap % 3)) * a.Cin;
+      const int toff = a.dil * ((tap / 3) * a.W + (tap % 3)) * a.Cin;
 #pragma unroll
       for (int i = 0; i < 2; ++i) r[i] = buf_load4(rx, ((xmask[i] >> tap) & 1u) ? (unsigned)(xoff[i] + toff) * 4u : OOB);
     };
@@ -695,7 +695,7 @@ int launch_affine_one(AffArgs& a) {
 }
 
 int launch_affine(const ConvArgs& c, long M) {
-  AffArgs a{c.src, c.w, c.bias, c.dst, c.B, c.Hs, c.Ws, c.Cs, c.Hd, c.Wd, c.Cd, c.R, c.S, c.stride, c.pad, c.transposed,
+  AffArgs a{c.src, c.w, c.bias, c.dst, c.B, c.Hs, c.Ws, c.Cs, c.Hd, c.Wd, c.Cd, c.R, c.S, c.stride, c.pad, c.dil, c.transposed,
             c.drop_scale, c.drop_thresh, c.drop_key,
             (unsigned)((size_t)c.B * c.Hs * c.Ws * c.Cs * 4), (unsigned)((size_t)c.R * c.S * c.Cs * c.Cd * 4),
             c.Hd, c.Wd, 1, 0, 0, 0, 0, 1, c.R, c.S, c.pad, c.pad, 0, 0, c.stats_};
@@ -729,12 +729,12 @@ extern "C" {
 
 // include/fovealseg.h: fs_conv2d_fwd
 int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
-                  int Ho, int Wo, int Cout, int R, int S, int stride, int pad, float drop_p, uint32_t drop_key,
+                  int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key,
                   hipStream_t stream) {
   FS_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
-  FS_REQUIRE(Ho == (H + 2 * pad - R) / stride + 1 && Wo == (W + 2 * pad - S) / stride + 1);
+  FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
   FS_REQUIRE(drop_p >= 0.f && drop_p < 1.f);
-  ConvArgs a{x, w, bias, y, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, 0, 1.f, 0u, drop_key};
+  ConvArgs a{x, w, bias, y, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0, 1.f, 0u, drop_key};
   a.stream_ = stream;
   if (drop_p > 0.f) {
     a.drop_scale = 1.0f / (float)(1.0 - (double)drop_p);
@@ -756,13 +756,13 @@ int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, i
 // include/fovealseg.h: fs_conv2d_fwd_stats -- forward conv that also emits per-workgroup BatchNorm partials.
 // stats = [ceil(B*Ho*Wo/128)][Cout][2] floats.  Requires Cin%4==0 && Cout%4==0 (the affine kernel).
 int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* stats, int B, int H, int W, int Cin,
-                        int Ho, int Wo, int Cout, int R, int S, int stride, int pad, float drop_p, uint32_t drop_key,
+                        int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key,
                         hipStream_t stream) {
   FS_REQUIRE(x && w && y && stats && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
-  FS_REQUIRE(Ho == (H + 2 * pad - R) / stride + 1 && Wo == (W + 2 * pad - S) / stride + 1);
+  FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
   FS_REQUIRE(drop_p >= 0.f && drop_p < 1.f);
   FS_REQUIRE((Cin % 4 == 0) && (Cout % 4 == 0) && R * S <= 32 && (long)B * H * W * Cin < 2147483647L);
-  ConvArgs a{x, w, bias, y, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, 0, 1.f, 0u, drop_key};
+  ConvArgs a{x, w, bias, y, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0, 1.f, 0u, drop_key};
   a.stream_ = stream;
   a.stats_ = stats;
   if (drop_p > 0.f) {
@@ -776,10 +776,11 @@ int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float
 
 // include/fovealseg.h: fs_conv2d_bwd_data   (dX has the forward input's shape B,H,W,Cin)
 int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
-                       int Cout, int R, int S, int stride, int pad, hipStream_t stream) {
+                       int Cout, int R, int S, int stride, int pad, int dil, hipStream_t stream) {
   FS_REQUIRE(dy && w && dx && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
-  FS_REQUIRE(Ho == (H + 2 * pad - R) / stride + 1 && Wo == (W + 2 * pad - S) / stride + 1);
-  ConvArgs a{dy, w, nullptr, dx, B, Ho, Wo, Cout, H, W, Cin, R, S, stride, pad, 1, 1.f, 0u, 0u};
+  FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
+  ConvArgs a{dy, w, nullptr, dx, B, Ho, Wo, Cout, H, W, Cin, R, S, stride, pad, dil, 1, 1.f, 0u, 0u};
+  FS_REQUIRE(stride == 1 || dil == 1);
   const long M = (long)B * H * W;
   a.stream_ = stream;
   if ((Cin % 4 == 0) && (Cout % 4 == 0) && R * S <= 32 && (long)B * Ho * Wo * Cout < 2147483647L)
@@ -795,9 +796,9 @@ int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H,
 
 // include/fovealseg.h: fs_conv2d_bwd_weight   (dw is overwritten)
 int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo,
-                         int Cout, int R, int S, int stride, int pad, hipStream_t stream) {
+                         int Cout, int R, int S, int stride, int pad, int dil, hipStream_t stream) {
   FS_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
-  FS_REQUIRE(Ho == (H + 2 * pad - R) / stride + 1 && Wo == (W + 2 * pad - S) / stride + 1);
+  FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
   hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)R * S * Cin * Cout, stream);
   if (e != hipSuccess) return (int)e;
   const long P = (long)B * Ho * Wo;
@@ -816,7 +817,7 @@ int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
     long pp = (P + ns - 1) / ns;
     pp = ((pp + BK - 1) / BK) * BK;
     ns = (P + pp - 1) / pp;
-    WgradArgs a{x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, (int)pp, tiles, 9, (int)ns};
+    WgradArgs a{x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, (int)pp, tiles, 9, (int)ns};
     dim3 grid((unsigned)(tiles * ng * ns));
     if (wg_mode == 3) hipLaunchKernelGGL(conv_wgrad_taps_kernel<3>, grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(conv_wgrad_taps_kernel<9>, grid, dim3(256), 0, stream, a);
@@ -830,7 +831,7 @@ int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
   long pps = (P + nsplit - 1) / nsplit;
   pps = ((pps + BK - 1) / BK) * BK;
   nsplit = (P + pps - 1) / pps;
-  WgradArgs a{x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, (int)pps, tiles, R * S, (int)nsplit};
+  WgradArgs a{x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, (int)pps, tiles, R * S, (int)nsplit};
   dim3 grid((unsigned)(tiles * R * S * nsplit));
   if ((Cin % 4 == 0) && (Cout % 4 == 0))
     hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, stream, a);

@@ -365,6 +365,60 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ dout, int B, int HW
   dx[i] = dout[b * C + c] / (float)HW;
 }
 
+// ---- max pooling (NHWC), argmax kept as the flat input pixel index for the backward ------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          int* __restrict__ arg, int B, int H, int W, int C, int Ho, int Wo,
+                                                          int k, int stride, int pad) {
+  const long total = (long)B * Ho * Wo * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long pix = i / C;
+    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+    float best = -INFINITY; int bi = -1;
+    for (int r = 0; r < k; ++r) {
+      const int iy = oy * stride - pad + r;
+      if (iy < 0 || iy >= H) continue;
+      for (int q = 0; q < k; ++q) {
+        const int ix = ox * stride - pad + q;
+        if (ix < 0 || ix >= W) continue;
+        const float v = x[(((long)b * H + iy) * W + ix) * C + c];
+        if (v > best || bi < 0 || v != v) { best = v; bi = iy * W + ix; }
+      }
+    }
+    out[i] = best; arg[i] = bi;
+  }
+}
+// gather form of the scatter: every input pixel looks at the (<= ceil(k/stride)^2) windows covering it
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ arg,
+                                                          float* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo,
+                                                          int k, int stride, int pad) {
+  const long total = (long)B * H * W * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long pix = i / C;
+    const int ix = (int)(pix % W), iy = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+    const int me = iy * W + ix;
+    int oy_lo = (iy + pad - k + stride) / stride; if (iy + pad - k + 1 < 0) oy_lo = 0;
+    int ox_lo = (ix + pad - k + stride) / stride; if (ix + pad - k + 1 < 0) ox_lo = 0;
+    int oy_hi = (iy + pad) / stride; if (oy_hi > Ho - 1) oy_hi = Ho - 1;
+    int ox_hi = (ix + pad) / stride; if (ox_hi > Wo - 1) ox_hi = Wo - 1;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const long o = (((long)b * Ho + oy) * Wo + ox) * C + c;
+        if (arg[o] == me) acc += dout[o];
+      }
+    dx[i] = acc;
+  }
+}
+
+// ---- stand-alone Dropout (ASPP projection): out = keep ? x/(1-p) : 0, same hash as the conv epilogue ----
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, long n,
+                                                      float scale, uint32_t thresh, uint32_t key) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = fs_dropout_keep((uint32_t)i, key, thresh) ? x[i] * scale : 0.f;
+}
+
 int rows_per_block_for(long M, int C) {
   const int cw = C / 4;
   int rpi = 256 / cw; if (rpi < 1) rpi = 1;
@@ -492,6 +546,34 @@ int fs_upsample_slice_bwd(const float* g, int B, int Ho, int Wo, int Cg, int cof
   const long total = (long)B * th * tw * (C / 4);
   int blocks = cdiv(total, 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(upsample_slice_bwd_kernel, dim3(blocks), dim3(256), 0, stream, g, B, Ho, Wo, Cg, coff, dsrc, th, tw, C);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_maxpool_fwd(const float* x, float* out, int* arg, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad,
+                   hipStream_t stream) {
+  FS_REQUIRE(x && out && arg && B > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && pad < k);
+  FS_REQUIRE(Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1 && (long)H * W < 2147483647L);
+  int blocks = cdiv((long)B * Ho * Wo * C, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, out, arg, B, H, W, C, Ho, Wo, k, stride, pad);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+int fs_maxpool_bwd(const float* dout, const int* arg, float* dx, int B, int H, int W, int C, int Ho, int Wo, int k, int stride,
+                   int pad, hipStream_t stream) {
+  FS_REQUIRE(dout && arg && dx && B > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && pad < k);
+  int blocks = cdiv((long)B * H * W * C, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dout, arg, dx, B, H, W, C, Ho, Wo, k, stride, pad);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+// forward and backward are the same map (the mask depends only on the element index)
+int fs_dropout(const float* x, float* out, long n, float drop_p, uint32_t drop_key, hipStream_t stream) {
+  FS_REQUIRE(x && out && n > 0 && n < 4294967296L && drop_p > 0.f && drop_p < 1.f);
+  const float scale = 1.0f / (float)(1.0 - (double)drop_p);
+  const uint32_t thresh = (uint32_t)((double)drop_p * 4294967296.0);
+  int blocks = cdiv(n, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, stream, x, out, n, scale, thresh, drop_key);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -29,10 +29,10 @@ SIGNATURES = {
     "fs_grid_sample_bwd_grid": "ppppiiiiiii",
     "fs_grid_sample_bwd_input": "pppiiiiiii",
     "fs_inverse_index_maps": "ppplii",
-    "fs_conv2d_fwd": "ppppiiiiiiiiiiifu",
-    "fs_conv2d_fwd_stats": "pppppiiiiiiiiiiifu",
-    "fs_conv2d_bwd_data": "pppiiiiiiiiiii",
-    "fs_conv2d_bwd_weight": "pppiiiiiiiiiii",
+    "fs_conv2d_fwd": "ppppiiiiiiiiiiiifu",
+    "fs_conv2d_fwd_stats": "pppppiiiiiiiiiiiifu",
+    "fs_conv2d_bwd_data": "pppiiiiiiiiiiii",
+    "fs_conv2d_bwd_weight": "pppiiiiiiiiiiii",
     "fs_bn_stats": "pliffppppp",
     "fs_bn_finalize_slab": "piliffpppp",
     "fs_bn_eval_prepare": "ppifpp",
@@ -43,6 +43,9 @@ SIGNATURES = {
     "fs_upsample_slice_fwd": "piiiipiiii",
     "fs_upsample_slice_bwd": "piiiiipiii",
     "fs_colsum": "plip",
+    "fs_maxpool_fwd": "pppiiiiiiiii",
+    "fs_maxpool_bwd": "pppiiiiiiiii",
+    "fs_dropout": "pplfu",
     "fs_avgpool_fwd": "piiip",
     "fs_avgpool_bwd": "piiip",
     "fs_mask_head_fwd": "ppppli",

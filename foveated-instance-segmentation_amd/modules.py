@@ -19,9 +19,9 @@ from .ops import ACT_NONE, ACT_RELU, ACT_RELU6
 class HipConv2d(nn.Module):
     """Holds `weight` (logical (Cout,Cin,R,S), RSCK storage) and optional `bias`."""
 
-    def __init__(self, cin, cout, k, stride=1, padding=0, bias=False):
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=False, dilation=1):
         super().__init__()
-        self.cin, self.cout, self.k, self.stride, self.padding = cin, cout, k, stride, padding
+        self.cin, self.cout, self.k, self.stride, self.padding, self.dilation = cin, cout, k, stride, padding, dilation
         w = ops.new_rsck_weight(cout, cin, k, k)
         nn.init.kaiming_normal_(w)
         self.weight = nn.Parameter(w)
@@ -68,7 +68,7 @@ class _NbtCounter:
 
 def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, act, res=None, drop_p=0.0, layer_id=0):
     training = bn.training
-    meta = dict(stride=conv.stride, pad=conv.padding, act=act, training=training, momentum=bn.momentum,
+    meta = dict(stride=conv.stride, pad=conv.padding, dil=conv.dilation, act=act, training=training, momentum=bn.momentum,
                 drop_p=drop_p, drop_key=ops.DropoutState.key(layer_id) if (training and drop_p > 0) else 0,
                 running_mean=bn.running_mean, running_var=bn.running_var, num_batches_tracked=_NbtCounter(bn))
     return ops.ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, res, meta)

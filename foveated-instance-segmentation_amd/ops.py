@@ -59,8 +59,8 @@ def new_rsck_weight(cout, cin, r, s, device=None) -> torch.Tensor:
     return torch.empty(r, s, cin, cout, device=device, dtype=torch.float32).permute(3, 2, 0, 1)
 
 
-def _out_hw(h, w, r, s, stride, pad):
-    return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
+def _out_hw(h, w, r, s, stride, pad, dil=1):
+    return (h + 2 * pad - dil * (r - 1) - 1) // stride + 1, (w + 2 * pad - dil * (s - 1) - 1) // stride + 1
 
 
 class KernelTimer:
@@ -97,43 +97,43 @@ def _launch(kind, flops, name, *args):
         TIMER.launch(kind, flops, lambda: hip.call(name, *args))
 
 
-def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0):
+def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1):
     B, H, W, Cin = x.shape
     Cout, Cin2, R, S = w.shape
     assert Cin == Cin2, (x.shape, w.shape)
-    Ho, Wo = _out_hw(H, W, R, S, stride, pad)
+    Ho, Wo = _out_hw(H, W, R, S, stride, pad, dil)
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
     kind = "conv_affine" if (Cin % 4 == 0 and Cout % 4 == 0) else "conv_generic"      # mirrors csrc/conv.hip dispatch
     _launch(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd", hip.ptr(x), hip.ptr(rsck(w)), hip.ptr(bias),
-            hip.ptr(y), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, float(drop_p), int(drop_key))
+            hip.ptr(y), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, float(drop_p), int(drop_key))
     return y
 
 
 FUSE_BN_STATS = True     # BatchNorm batch statistics come out of the conv epilogue (fs_conv2d_fwd_stats)
 
 
-def conv2d_fwd_stats(x, w, bias, stride, pad, drop_p=0.0, drop_key=0):
+def conv2d_fwd_stats(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1):
     """Forward conv + per-workgroup BatchNorm partial sums (slab [nwg][Cout][2])."""
     B, H, W, Cin = x.shape
     Cout, Cin2, R, S = w.shape
     assert Cin == Cin2, (x.shape, w.shape)
-    Ho, Wo = _out_hw(H, W, R, S, stride, pad)
+    Ho, Wo = _out_hw(H, W, R, S, stride, pad, dil)
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
     nwg = (B * Ho * Wo + 127) // 128
     slab = torch.empty(nwg * Cout * 2, device=x.device, dtype=torch.float32)
     _launch("conv_affine", 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd_stats", hip.ptr(x), hip.ptr(rsck(w)),
-            hip.ptr(bias), hip.ptr(y), hip.ptr(slab), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, float(drop_p), int(drop_key))
+            hip.ptr(bias), hip.ptr(y), hip.ptr(slab), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, float(drop_p), int(drop_key))
     return y, slab, nwg
 
 
-def conv2d_bwd_data(dy, w, x_shape, stride, pad):
+def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1):
     B, H, W, Cin = x_shape
     Cout, _, R, S = w.shape
     _, Ho, Wo, _ = dy.shape
     dx = torch.empty(B, H, W, Cin, device=dy.device, dtype=torch.float32)
     kind = "conv_affine" if (Cin % 4 == 0 and Cout % 4 == 0) else "conv_generic"
     _launch(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx),
-            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad)
+            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)
     return dx
 
 
@@ -153,13 +153,13 @@ def _direct_grad_target(p):
     return None
 
 
-def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None):
+def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None, dil=1):
     B, H, W, Cin = x.shape
     Cout, _, R, S = w_shape
     _, Ho, Wo, _ = dy.shape
     dw = rsck(out) if out is not None else torch.empty(R, S, Cin, Cout, device=x.device, dtype=torch.float32)
     _launch("conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_bwd_weight", hip.ptr(x), hip.ptr(dy), hip.ptr(dw),
-            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad)
+            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)
     return out if out is not None else dw.permute(3, 2, 0, 1)
 
 
@@ -183,10 +183,11 @@ class ConvBnAct(Function):
         drop_p = meta["drop_p"] if training else 0.0
         Cout, Cin = w.shape[0], w.shape[1]
         fused_stats = training and FUSE_BN_STATS and Cin % 4 == 0 and Cout % 4 == 0
+        dil = meta.get("dil", 1)
         if fused_stats:
-            y, slab, nwg = conv2d_fwd_stats(x, w, bias, meta["stride"], meta["pad"], drop_p, meta["drop_key"])
+            y, slab, nwg = conv2d_fwd_stats(x, w, bias, meta["stride"], meta["pad"], drop_p, meta["drop_key"], dil)
         else:
-            y = conv2d_fwd(x, w, bias, meta["stride"], meta["pad"], drop_p, meta["drop_key"])
+            y = conv2d_fwd(x, w, bias, meta["stride"], meta["pad"], drop_p, meta["drop_key"], dil)
         B, Ho, Wo, C = y.shape
         M = B * Ho * Wo
         mean = torch.empty(C, device=y.device, dtype=torch.float32)
@@ -206,7 +207,7 @@ class ConvBnAct(Function):
         z = torch.empty_like(y)
         hip.call("fs_bn_act_fwd", hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(beta), hip.ptr(res),
                  hip.ptr(z), M, C, meta["act"])
-        ctx.meta = dict(stride=meta["stride"], pad=meta["pad"], act=meta["act"], training=training, drop_p=drop_p,
+        ctx.meta = dict(stride=meta["stride"], pad=meta["pad"], dil=dil, act=meta["act"], training=training, drop_p=drop_p,
                         drop_key=meta["drop_key"], has_bias=bias is not None, has_res=res is not None)
         ctx.save_for_backward(x, w, gamma, y, z, mean, invstd)
         ctx.beta_ref = beta
@@ -229,9 +230,9 @@ class ConvBnAct(Function):
         hip.call("fs_bn_act_bwd", hip.ptr(dz), hip.ptr(z), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), M, C,
                  m["act"], 1 if m["training"] else 0, float(m["drop_p"]), int(m["drop_key"]), hip.ptr(dy), hip.ptr(dres),
                  hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums))
-        dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"]) if ctx.needs_input_grad[0] else None
+        dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"]) if ctx.needs_input_grad[0] else None
         tgt = _direct_grad_target(w)
-        dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt)
+        dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"])
         if tgt is not None:
             dw = None
         dbias = colsum(dy, C) if m["has_bias"] else None
@@ -356,6 +357,47 @@ class MaskHead(Function):
         hip.call("fs_mask_head_bwd", hip.ptr(dm), hip.ptr(m), hip.ptr(x), hip.ptr(w), hip.ptr(dx), hip.ptr(dw), hip.ptr(db),
                  m.numel(), C)
         return dx, dw, db
+
+
+class MaxPool(Function):
+    """nn.MaxPool2d(k, stride, pad) on NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        B, H, W, C = x.shape
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        out = torch.empty(B, Ho, Wo, C, device=x.device, dtype=torch.float32)
+        arg = torch.empty(B, Ho, Wo, C, device=x.device, dtype=torch.int32)
+        hip.call("fs_maxpool_fwd", hip.ptr(x), hip.ptr(out), hip.ptr(arg), B, H, W, C, Ho, Wo, k, stride, pad)
+        ctx.save_for_backward(arg)
+        ctx.cfg = (B, H, W, C, Ho, Wo, k, stride, pad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        B, H, W, C, Ho, Wo, k, stride, pad = ctx.cfg
+        dx = torch.empty(B, H, W, C, device=g.device, dtype=torch.float32)
+        hip.call("fs_maxpool_bwd", hip.ptr(g.contiguous()), hip.ptr(arg), hip.ptr(dx), B, H, W, C, Ho, Wo, k, stride, pad)
+        return dx, None, None, None
+
+
+class Dropout(Function):
+    """Stand-alone nn.Dropout(p) with the replayable hash mask (identity when p == 0)."""
+
+    @staticmethod
+    def forward(ctx, x, p, key):
+        ctx.pk = (float(p), int(key))
+        out = torch.empty_like(x)
+        hip.call("fs_dropout", hip.ptr(x), hip.ptr(out), x.numel(), float(p), int(key))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, key = ctx.pk
+        out = torch.empty_like(g)
+        hip.call("fs_dropout", hip.ptr(g.contiguous()), hip.ptr(out), g.numel(), p, key)
+        return out, None, None
 
 
 class AvgPoolHW(Function):

@@ -60,21 +60,21 @@ int fs_grid_sample_bwd_input(const float* gout, const float* grid, float* dx, in
 int fs_inverse_index_maps(const float* grid, long long* u, long long* v, long n, int H, int W, fs_stream_t stream);
 
 /* ---- convolution engine (fp32 MFMA implicit GEMM) --------------------------------------------- */
-/* F.conv2d(x, w, bias, stride, pad) [+ Dropout(drop_p) keyed by drop_key when drop_p > 0].
+/* F.conv2d(x, w, bias, stride, pad, dilation=dil) [+ Dropout(drop_p) keyed by drop_key when drop_p > 0].
  * models/hrnetv2_nodownsp.py:49-50,54-55 and every nn.Conv2d on the path. */
 int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Ho, int Wo,
-                  int Cout, int R, int S, int stride, int pad, float drop_p, uint32_t drop_key, fs_stream_t stream);
+                  int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key, fs_stream_t stream);
 /* Same forward conv, additionally writing per-workgroup BatchNorm partial sums of the stored output into
  * stats = [ceil(B*Ho*Wo/128)][Cout][2] floats (needs Cin%4==0 && Cout%4==0); finalise with fs_bn_finalize_slab.
  * Fuses the statistics pass of F.batch_norm(training=True) (lib/nn/modules/batchnorm.py:58-61) into the conv. */
 int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* stats, int B, int H, int W, int Cin,
-                        int Ho, int Wo, int Cout, int R, int S, int stride, int pad, float drop_p, uint32_t drop_key,
+                        int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key,
                         fs_stream_t stream);
 /* convolution_backward: input gradient / weight gradient (dw overwritten). */
 int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R,
-                       int S, int stride, int pad, fs_stream_t stream);
+                       int S, int stride, int pad, int dil, fs_stream_t stream);
 int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                         int R, int S, int stride, int pad, fs_stream_t stream);
+                         int R, int S, int stride, int pad, int dil, fs_stream_t stream);
 
 /* ---- BatchNorm / activation / residual ------------------------------------------------------ */
 /* F.batch_norm(training=True) statistics over M rows; running stats updated in place (nullable).
@@ -104,6 +104,14 @@ int fs_upsample_slice_fwd(const float* src, int B, int th, int tw, int C, float*
 int fs_upsample_slice_bwd(const float* g, int B, int Ho, int Wo, int Cg, int coff, float* dsrc, int th, int tw, int C,
                           fs_stream_t stream);
 int fs_colsum(const float* x, long M, int C, float* out, fs_stream_t stream);
+/* nn.MaxPool2d(k, stride, pad) on NHWC; arg = flat input pixel index of the maximum (int32), used by the backward.
+ * torchvision ResNet stem behind models/deeplab.py:15. */
+int fs_maxpool_fwd(const float* x, float* out, int* arg, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad,
+                   fs_stream_t stream);
+int fs_maxpool_bwd(const float* dout, const int* arg, float* dx, int B, int H, int W, int C, int Ho, int Wo, int k, int stride,
+                   int pad, fs_stream_t stream);
+/* nn.Dropout(p) as a stand-alone pass (same call for forward and backward); hash mask keyed by drop_key. */
+int fs_dropout(const float* x, float* out, long n, float drop_p, uint32_t drop_key, fs_stream_t stream);
 /* AvgPool2d((10,10)) on a 10x10 map.  models/model_utils.py:254,272. */
 int fs_avgpool_fwd(const float* x, int B, int HW, int C, float* out, fs_stream_t stream);
 int fs_avgpool_bwd(const float* dout, int B, int HW, int C, float* dx, fs_stream_t stream);

@@ -55,33 +55,59 @@ CONV_CASES = [
     (2, 20, 20, 96, 64, 1, 4, True),       # 1x1 stride 4 downsample
     (5, 1, 1, 512, 51, 1, 1, True),        # FC as 1x1 conv, scalar path
     (1, 10, 10, 512, 512, 3, 1, False),
+    (2, 10, 10, 64, 64, 3, 1, False, 2),    # dilation 2 (DeepLab layer3)
+    (1, 10, 10, 128, 64, 3, 1, False, 12),  # ASPP rate 12: only the centre tap is in range
+    (2, 23, 17, 3, 64, 7, 2, False),        # ResNet stem 7x7 stride 2 (generic kernel)
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_bwd(case):
-    B, H, W, Ci, Co, k, s, has_bias = case
+    B, H, W, Ci, Co, k, s, has_bias = case[:8]
+    dil = case[8] if len(case) > 8 else 1
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
     x = torch.randn(B, Ci, H, W, generator=g)
     w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
     b = torch.randn(Co, generator=g) if has_bias else None
-    pad = k // 2
+    pad = dil * (k // 2)
     xr = x.clone().requires_grad_(True)
     wr = w.clone().requires_grad_(True)
-    y_ref = F.conv2d(xr, wr, b, s, pad)
+    y_ref = F.conv2d(xr, wr, b, s, pad, dil)
     cot = torch.randn(y_ref.shape, generator=g)
     y_ref.backward(cot)
 
     xd, wd = nhwc(x), rsck_param(w)
     bd = b.to(DEV) if has_bias else None
-    y = ops.conv2d_fwd(xd, wd, bd, s, pad)
+    y = ops.conv2d_fwd(xd, wd, bd, s, pad, dil=dil)
     assert relerr(nchw(y), y_ref.detach()) <= 2e-5
     dyd = nhwc(cot)
-    dx = ops.conv2d_bwd_data(dyd, wd, xd.shape, s, pad)
+    dx = ops.conv2d_bwd_data(dyd, wd, xd.shape, s, pad, dil)
     assert relerr(nchw(dx), xr.grad) <= 2e-5
-    dw = ops.conv2d_bwd_weight(xd, dyd, w.shape, s, pad)
+    dw = ops.conv2d_bwd_weight(xd, dyd, w.shape, s, pad, dil=dil)
     assert dw.shape == w.shape
     assert relerr(dw.cpu(), wr.grad) <= 5e-5
+
+
+def test_maxpool_and_dropout():
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 16, 13, 11, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot)
+    xd = nhwc(x).requires_grad_(True)
+    out = ops.MaxPool.apply(xd, 3, 2, 1)
+    out.backward(nhwc(cot))
+    assert torch.equal(nchw(out), ref.detach())
+    assert relerr(nchw(xd.grad), xr.grad) <= 1e-6
+    key = ops.layer_key(9, 99)
+    v = torch.randn(3, 5, 7, 8, generator=g)
+    vd = v.to(DEV).requires_grad_(True)
+    o = ops.Dropout.apply(vd, 0.5, key)
+    o.backward(torch.ones_like(o))
+    keep = torch.from_numpy(O.dropout_keep_mask_nhwc(v.numel(), key, 0.5)).view(v.shape)
+    assert torch.equal(o.detach().cpu(), torch.where(keep, v * 2.0, torch.zeros(())))
+    assert torch.equal(vd.grad.cpu(), keep.float() * 2.0)
 
 
 def test_conv_rejects_bad_shapes():
@@ -89,7 +115,7 @@ def test_conv_rejects_bad_shapes():
     w = ops.new_rsck_weight(4, 4, 3, 3, device=DEV)
     y = torch.zeros(1, 5, 5, 4, device=DEV)       # wrong output size
     with pytest.raises(fovealseg.hip.HipLibraryError):
-        fovealseg.hip.call("fs_conv2d_fwd", x.data_ptr(), ops.rsck(w).data_ptr(), None, y.data_ptr(), 1, 4, 4, 4, 5, 5, 4, 3, 3, 1, 1, 0.0, 0)
+        fovealseg.hip.call("fs_conv2d_fwd", x.data_ptr(), ops.rsck(w).data_ptr(), None, y.data_ptr(), 1, 4, 4, 4, 5, 5, 4, 3, 3, 1, 1, 1, 0.0, 0)
     with pytest.raises(fovealseg.hip.HipLibraryError):
         ops.conv2d_fwd(torch.zeros(1, 4, 4, 4), w, None, 1, 1)   # CPU tensor: no fallback
 
