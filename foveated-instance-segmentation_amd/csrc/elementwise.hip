@@ -22,8 +22,10 @@ struct RowWalk {
 };
 
 // ---- BN statistics: per-channel sum and sum of squares (double accumulators) --------------
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, long M, int C, int rows_per_block,
-                                                       double* __restrict__ sums /* [2][C] */) {
+// All BN kernels work on a channel window [c0, c0+C) of rows with leading dimension ld (C <= 1024 per
+// launch; wider layers are covered by several launches); per-channel pointers arrive offset by c0.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, long M, int C, int ld, int Ctot,
+                                                       int rows_per_block, double* __restrict__ sums /* [2][Ctot] + c0 */) {
   extern __shared__ double sm[];   // [rpi][C][2] partials
   RowWalk w(C);
   const long rb = (long)blockIdx.x * rows_per_block;
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
   if (w.active())
     for (long r = rb + w.r0; r < re; r += w.rpi) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + 4 * w.col);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * ld + 4 * w.col);
       s += v; ss += v * v;
     }
   if (w.active()) {
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     double a = 0, b = 0;
     for (int r = 0; r < w.rpi; ++r) { a += sm[((long)r * C + c) * 2]; b += sm[((long)r * C + c) * 2 + 1]; }
     atomicAdd(&sums[c], a);
-    atomicAdd(&sums[C + c], b);
+    atomicAdd(&sums[Ctot + c], b);
   }
 }
 
@@ -105,7 +107,8 @@ __global__ void bn_eval_prepare_kernel(const float* __restrict__ running_mean, c
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ res,
-                                                         float* __restrict__ out, long M, int C, int rows_per_block, int act) {
+                                                         float* __restrict__ out, long M, int C, int ld, int rows_per_block,
+                                                         int act) {
   RowWalk w(C);
   if (!w.active()) return;
   const int c = 4 * w.col;
@@ -118,20 +121,21 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   const long rb = (long)blockIdx.x * rows_per_block;
   long re = rb + rows_per_block; if (re > M) re = M;
   for (long r = rb + w.r0; r < re; r += w.rpi) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + c);
+    f32x4 v = *reinterpret_cast<const f32x4*>(y + r * ld + c);
     v = v * sc + sh;
-    if (res != nullptr) v += *reinterpret_cast<const f32x4*>(res + r * C + c);
+    if (res != nullptr) v += *reinterpret_cast<const f32x4*>(res + r * ld + c);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = fs_act(v[j], act);
-    *reinterpret_cast<f32x4*>(out + r * C + c) = v;
+    *reinterpret_cast<f32x4*>(out + r * ld + c) = v;
   }
 }
 
 // ---- BN backward pass 1: sum(g), sum(g*xhat), g = dz * act'(z) --------------------------------
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                                             const float* __restrict__ y, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, long M, int C,
-                                                            int rows_per_block, int act, double* __restrict__ sums) {
+                                                            const float* __restrict__ invstd, long M, int C, int ld,
+                                                            int Ctot, int rows_per_block, int act,
+                                                            double* __restrict__ sums) {
   extern __shared__ double sm[];
   RowWalk w(C);
   const int c = 4 * w.col;
@@ -143,13 +147,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const long rb = (long)blockIdx.x * rows_per_block;
     long re = rb + rows_per_block; if (re > M) re = M;
     for (long r = rb + w.r0; r < re; r += w.rpi) {
-      f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * C + c);
+      f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * ld + c);
       if (act != FS_ACT_NONE) {
-        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * C + c);
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * ld + c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[j] *= fs_act_mask(zz[j], act);
       }
-      const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + r * C + c) - mu) * is;
+      const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + r * ld + c) - mu) * is;
       s += g; sx += g * xh;
     }
     double* p = sm + ((long)w.r0 * C + c) * 2;
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     double a = 0, b = 0;
     for (int r = 0; r < w.rpi; ++r) { a += sm[((long)r * C + cc) * 2]; b += sm[((long)r * C + cc) * 2 + 1]; }
     atomicAdd(&sums[cc], a);
-    atomicAdd(&sums[C + cc], b);
+    atomicAdd(&sums[Ctot + cc], b);
   }
 }
 
@@ -168,15 +172,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           const double* __restrict__ sums, long M, int C, int rows_per_block,
-                                                           int act, int training, float drop_scale, uint32_t drop_thresh,
+                                                           const double* __restrict__ sums, long M, int C, int ld, int Ctot,
+                                                           int c0, int rows_per_block, int act, int training,
+                                                           float drop_scale, uint32_t drop_thresh,
                                                            uint32_t drop_key, float* __restrict__ dy, float* __restrict__ dres,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
   RowWalk w(C);
   if (blockIdx.x == 0 && dgamma != nullptr)
     for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
       dbeta[cc] = (float)sums[cc];
-      dgamma[cc] = (float)sums[C + cc];
+      dgamma[cc] = (float)sums[Ctot + cc];
     }
   if (!w.active()) return;
   const int c = 4 * w.col;
@@ -185,26 +190,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   for (int j = 0; j < 4; ++j) {
     mu[j] = mean[c + j]; is[j] = invstd[c + j]; ga[j] = gamma[c + j] * is[j];
     mg[j] = training ? (float)(sums[c + j] / (double)M) : 0.f;
-    mgx[j] = training ? (float)(sums[C + c + j] / (double)M) : 0.f;
+    mgx[j] = training ? (float)(sums[Ctot + c + j] / (double)M) : 0.f;
   }
   const long rb = (long)blockIdx.x * rows_per_block;
   long re = rb + rows_per_block; if (re > M) re = M;
   for (long r = rb + w.r0; r < re; r += w.rpi) {
-    f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * C + c);
+    f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * ld + c);
     if (act != FS_ACT_NONE) {
-      const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * C + c);
+      const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * ld + c);
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] *= fs_act_mask(zz[j], act);
     }
-    if (dres != nullptr) *reinterpret_cast<f32x4*>(dres + r * C + c) = g;
-    const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + r * C + c) - mu) * is;
+    if (dres != nullptr) *reinterpret_cast<f32x4*>(dres + r * ld + c) = g;
+    const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + r * ld + c) - mu) * is;
     f32x4 d = ga * (g - mg - xh * mgx);
     if (drop_thresh != 0u) {
-      const uint32_t e = (uint32_t)(r * C + c);
+      const uint32_t e = (uint32_t)(r * ld + c0 + c);
 #pragma unroll
       for (int j = 0; j < 4; ++j) d[j] = fs_dropout_keep(e + j, drop_key, drop_thresh) ? d[j] * drop_scale : 0.f;
     }
-    *reinterpret_cast<f32x4*>(dy + r * C + c) = d;
+    *reinterpret_cast<f32x4*>(dy + r * ld + c) = d;
   }
 }
 
@@ -441,12 +446,15 @@ extern "C" {
 // place with `momentum` (unbiased variance), `sums` = 2*C doubles of scratch.
 int fs_bn_stats(const float* y, long M, int C, float momentum, float eps, float* running_mean, float* running_var,
                 float* mean, float* invstd, double* sums, hipStream_t stream) {
-  FS_REQUIRE(y && mean && invstd && sums && M > 0 && C > 0 && C % 4 == 0 && C <= 1024);
+  FS_REQUIRE(y && mean && invstd && sums && M > 0 && C > 0 && C % 4 == 0);
   hipError_t e = hipMemsetAsync(sums, 0, 2 * C * sizeof(double), stream);
   if (e != hipSuccess) return (int)e;
-  const int rpb = rows_per_block_for(M, C);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(M, rpb)), dim3(256), stats_smem(C), stream, y, M, C, rpb, sums);
-  FS_LAUNCH_CHECK();
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    const int Cc = C - c0 < 1024 ? C - c0 : 1024;
+    const int rpb = rows_per_block_for(M, Cc);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(M, rpb)), dim3(256), stats_smem(Cc), stream, y + c0, M, Cc, C, C, rpb, sums + c0);
+    FS_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, sums, M, C, momentum, eps,
                      running_mean, running_var, mean, invstd);
   FS_LAUNCH_CHECK();
@@ -474,11 +482,14 @@ int fs_bn_eval_prepare(const float* running_mean, const float* running_var, int 
 
 int fs_bn_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                   const float* res, float* out, long M, int C, int act, hipStream_t stream) {
-  FS_REQUIRE(y && mean && invstd && gamma && beta && out && M > 0 && C > 0 && C % 4 == 0 && C <= 1024);
-  const int rpb = rows_per_block_for(M, C);
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, stream, y, mean, invstd, gamma, beta, res, out,
-                     M, C, rpb, act);
-  FS_LAUNCH_CHECK();
+  FS_REQUIRE(y && mean && invstd && gamma && beta && out && M > 0 && C > 0 && C % 4 == 0);
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    const int Cc = C - c0 < 1024 ? C - c0 : 1024;
+    const int rpb = rows_per_block_for(M, Cc);
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, stream, y + c0, mean + c0, invstd + c0, gamma + c0,
+                       beta + c0, res ? res + c0 : nullptr, out + c0, M, Cc, C, rpb, act);
+    FS_LAUNCH_CHECK();
+  }
   return FS_OK;
 }
 
@@ -488,19 +499,23 @@ int fs_bn_act_fwd(const float* y, const float* mean, const float* invstd, const 
 int fs_bn_act_bwd(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
                   const float* gamma, long M, int C, int act, int training, float drop_p, uint32_t drop_key, float* dy,
                   float* dres, float* dgamma, float* dbeta, double* sums, hipStream_t stream) {
-  FS_REQUIRE(dz && y && mean && invstd && gamma && dy && dgamma && dbeta && sums && M > 0 && C % 4 == 0 && C <= 1024);
+  FS_REQUIRE(dz && y && mean && invstd && gamma && dy && dgamma && dbeta && sums && M > 0 && C % 4 == 0);
   FS_REQUIRE(act == FS_ACT_NONE || z != nullptr);
   hipError_t e = hipMemsetAsync(sums, 0, 2 * C * sizeof(double), stream);
   if (e != hipSuccess) return (int)e;
-  const int rpb = rows_per_block_for(M, C);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(M, rpb)), dim3(256), stats_smem(C), stream, dz, z, y, mean, invstd, M,
-                     C, rpb, act, sums);
-  FS_LAUNCH_CHECK();
   float scale = 1.f; uint32_t thresh = 0u;
   if (drop_p > 0.f) { scale = 1.0f / (float)(1.0 - (double)drop_p); thresh = (uint32_t)((double)drop_p * 4294967296.0); }
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, stream, dz, z, y, mean, invstd, gamma, sums, M,
-                     C, rpb, act, training, scale, thresh, drop_key, dy, dres, dgamma, dbeta);
-  FS_LAUNCH_CHECK();
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    const int Cc = C - c0 < 1024 ? C - c0 : 1024;
+    const int rpb = rows_per_block_for(M, Cc);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(M, rpb)), dim3(256), stats_smem(Cc), stream, dz + c0, z ? z + c0 : nullptr,
+                       y + c0, mean + c0, invstd + c0, M, Cc, C, C, rpb, act, sums + c0);
+    FS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, stream, dz + c0, z ? z + c0 : nullptr, y + c0,
+                       mean + c0, invstd + c0, gamma + c0, sums + c0, M, Cc, C, C, c0, rpb, act, training, scale, thresh, drop_key,
+                       dy + c0, dres ? dres + c0 : nullptr, dgamma + c0, dbeta + c0);
+    FS_LAUNCH_CHECK();
+  }
   return FS_OK;
 }
 

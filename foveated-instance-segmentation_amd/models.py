@@ -42,8 +42,11 @@ class ModelBuilder:
         arch = arch.lower()
         if arch == "hrnetv2_nodownsp":
             net = M.hrnetv2_nodownsp(pretrained=False)
-        elif arch in ("segformer", "deeplab"):
-            raise NotImplementedError(f"encoder '{arch}' is a later SURVEY §8 row (A22/A23); only hrnetv2_nodownsp is built")
+        elif arch == "deeplab":
+            from . import deeplab as _dl
+            net = _dl.deeplab(pretrained=False)
+        elif arch == "segformer":
+            raise NotImplementedError("encoder 'segformer' (SURVEY §8 A22) is not built yet")
         else:
             raise Exception("Architecture undefined!")
         return ModelBuilder._load(net, weights)

@@ -303,6 +303,25 @@ class HrFuse(Function):
         return (None, None, *grads)
 
 
+class UpsampleTo(Function):
+    """F.interpolate(x, size=(Ho,Wo), mode='bilinear', align_corners=False) on NHWC (integer factors)."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        B, h, w, C = x.shape
+        out = torch.empty(B, Ho, Wo, C, device=x.device, dtype=torch.float32)
+        hip.call("fs_upsample_slice_fwd", hip.ptr(x), B, h, w, C, hip.ptr(out), Ho, Wo, C, 0)
+        ctx.shape = (B, h, w, C, Ho, Wo)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, h, w, C, Ho, Wo = ctx.shape
+        d = torch.empty(B, h, w, C, device=g.device, dtype=torch.float32)
+        hip.call("fs_upsample_slice_bwd", hip.ptr(g.contiguous()), B, Ho, Wo, C, 0, hip.ptr(d), h, w, C)
+        return d, None, None
+
+
 class UpsampleConcat(Function):
     """cat([x0, up(x1), up(x2), up(x3)], channel) written straight into one NHWC buffer."""
 

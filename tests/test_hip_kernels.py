@@ -656,3 +656,127 @@ def test_train_and_eval_step_end_to_end():
         assert len(outs) == 6 and all(np.isfinite(float(o)) for o in outs)
     finally:
         ops.DIRECT_GRAD = False
+
+
+# ------------------------------------------------------------------------------------------------
+# DeepLab encoder plugin -- against this repo's oracle restatement ("parity unpinned"
+# w.r.t. torchvision, which is absent)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_deeplab_encoder_vs_oracle(mode):
+    import deeplab_oracle as DO
+    from fovealseg import deeplab as D
+    o = DO.OracleDeepLab()
+    fovealseg.weights.apply_name_keyed_init(o)
+    m = D.deeplab()
+    m.load_state_dict(o.state_dict(), strict=True)
+    m.to(DEV)
+    o.train(mode == "train")
+    m.train(mode == "train")
+    ops.DropoutState.seed, ops.DropoutState.step = 3, 11
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand(4, 3, 80, 80, generator=g)
+
+    def drop_fn(t):                       # replay the kernel's hash mask (Dropout(0.5) of the ASPP projection)
+        if mode != "train":
+            return t
+        B, C, H, W = t.shape
+        key = ops.DropoutState.key(ops.layer_id_from_name("deeplab.classifier.0.project.3"))
+        keep = O.dropout_keep_mask_nhwc(t.numel(), key, 0.5).reshape(B, H, W, C)
+        return t * torch.from_numpy(keep).permute(0, 3, 1, 2).float() * 2.0
+    xr = x.clone().requires_grad_(True)
+    ref = o(xr, drop_fn=drop_fn)[0]
+    cot = torch.randn(ref.shape, generator=g) * 0.01
+    o.zero_grad()
+    ref.backward(cot)
+    xd = x.to(DEV).requires_grad_(True)
+    out = m(xd)[0]
+    assert out.shape == (4, 960, 80, 80)
+    m.zero_grad()
+    out.backward(cot.to(DEV))
+    # train mode at B=4 normalises the ASPP image-pooling branch over FOUR samples (and 10x10 maps over 400):
+    # batch statistics of so few values amplify rounding differences, hence the looser train tolerances; the
+    # pooling-branch conv gradient (BatchNorm over 4 values, analytically near-cancelling) is checked in eval only
+    # (measured: the oracle's own fp32 and fp64 runs differ by 7e-4 in the output and 5-13 % in these gradients
+    #  in train mode -- ~100 stacked batch-stat BNs over 400 samples are chaotic; tight train-mode checks are
+    #  done per block in test_deeplab_blocks_train)
+    tol_out, tol_grad = (1e-4, 2e-3) if mode == "eval" else (2e-3, 0.25)
+    assert relerr(out.detach().cpu(), ref.detach()) <= tol_out
+    assert relerr(xd.grad.cpu(), xr.grad) <= tol_grad
+    po, pm = dict(o.named_parameters()), dict(m.named_parameters())
+    for k in ("deeplab.backbone.conv1.weight", "deeplab.backbone.layer3.7.conv2.weight", "deeplab.classifier.0.convs.2.0.weight",
+              "deeplab.classifier.0.convs.4.1.weight", "deeplab.classifier.4.bias", "deeplab.classifier.1.weight",
+              "deeplab.backbone.layer4.2.bn3.weight"):
+        if mode == "train" and "convs.4" in k:
+            continue
+        assert relerr(pm[k].grad.cpu(), po[k].grad) <= tol_grad, k
+
+
+def test_deeplab_blocks_train():
+    """Train-mode (batch statistics, Dropout(0.5) replayed) parity of the DeepLab-specific blocks in isolation:
+    a dilated bottleneck and the ASPP head, where the comparison is well conditioned."""
+    import deeplab_oracle as DO
+    from fovealseg import deeplab as D
+    o = DO.OracleDeepLab()
+    fovealseg.weights.apply_name_keyed_init(o)
+    m = D.deeplab()
+    m.load_state_dict(o.state_dict(), strict=True)
+    m.to(DEV)
+    o.train()
+    m.train()
+    g = torch.Generator().manual_seed(29)
+    # dilated bottleneck (layer3[7]: dilation 2)
+    x = torch.randn(2, 1024, 10, 10, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ob, mb = o.deeplab.backbone.layer3[7], m.deeplab.backbone.layer3[7]
+    ref = ob(xr)
+    cot = torch.randn(ref.shape, generator=g)
+    ob.zero_grad()
+    ref.backward(cot)
+    xd = nhwc(x).requires_grad_(True)
+    out = mb(xd)
+    mb.zero_grad()
+    out.backward(nhwc(cot))
+    assert relerr(nchw(out), ref.detach()) <= 2e-5
+    assert relerr(nchw(xd.grad), xr.grad) <= 2e-4
+    assert relerr(mb.conv2.weight.grad.cpu(), ob.conv2.weight.grad) <= 5e-4
+    # ASPP head; the image-pooling BN normalises over B values only -> kept in eval mode on both sides
+    oh, mh = o.deeplab.classifier, m.deeplab.classifier
+    oh[0].convs[4][2].eval()
+    mh[0].convs[4][2].eval()
+    ops.DropoutState.seed, ops.DropoutState.step = 4, 2
+    f = torch.randn(4, 2048, 10, 10, generator=g) * 0.5
+    fr = f.clone().requires_grad_(True)
+
+    def drop_fn(t):
+        B, C, H, W = t.shape
+        key = ops.DropoutState.key(ops.layer_id_from_name("deeplab.classifier.0.project.3"))
+        keep = O.dropout_keep_mask_nhwc(t.numel(), key, 0.5).reshape(B, H, W, C)
+        return t * torch.from_numpy(keep).permute(0, 3, 1, 2).float() * 2.0
+    ref = oh[4](oh[3](oh[2](oh[1](oh[0](fr, drop_fn)))))
+    cot = torch.randn(ref.shape, generator=g) * 0.1
+    oh.zero_grad()
+    ref.backward(cot)
+    fd = nhwc(f).requires_grad_(True)
+    out = mh(fd)
+    mh.zero_grad()
+    out.backward(nhwc(cot))
+    assert relerr(nchw(out), ref.detach()) <= 5e-5
+    assert relerr(nchw(fd.grad), fr.grad) <= 1e-3
+    # ("1.bias" is omitted: a conv bias in front of a batch-stat BN has an analytically zero gradient)
+    for k in ("0.convs.2.0.weight", "0.convs.4.1.weight", "0.project.0.weight", "1.weight", "4.weight", "4.bias", "2.weight"):
+        po, pm = dict(oh.named_parameters())[k], dict(mh.named_parameters())[k]
+        assert relerr(pm.grad.cpu(), po.grad) <= 1e-3, k
+
+
+def test_deeplab_through_module_surface():
+    cfg = fovealseg.lvis50_cfg()
+    cfg.MODEL.arch_encoder = "deeplab"
+    from fovealseg import train
+    module, nets = train.build_module(cfg, device=DEV)
+    module.train()
+    batch = train.synthetic_batch(2, 128, 128, seed=9, device=DEV)
+    feed = {"img_data": batch[0], "seg_label": batch[2], "focus_point": batch[1], "cls_label": batch[3]}
+    loss, acc, edge = module(feed)
+    loss.mean().backward()
+    assert np.isfinite(float(loss.detach())) and module.encoder.deeplab.backbone.conv1.weight.grad is not None

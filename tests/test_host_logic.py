@@ -52,6 +52,8 @@ def test_builder_errors_match_reference():
         MB.build_decoder("upernet")
     with pytest.raises(NotImplementedError):
         MB.build_encoder("segformer")
+    enc = MB.build_encoder("deeplab", fc_dim=960)
+    assert "deeplab.classifier.0.convs.4.1.weight" in enc.state_dict() and len(enc.state_dict()) == 669
 
 
 def test_state_dict_keys_match_oracle():
