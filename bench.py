@@ -44,8 +44,12 @@ def cpu_baseline(batch=4, H=1024, threads=None):
     import fovealseg_oracle as O
     from fovealseg.weights import apply_name_keyed_init
     from fovealseg.train import synthetic_batch
-    if threads:
-        torch.set_num_threads(threads)
+    if threads is None:          # the GPU box exposes 128 logical CPUs but grants a 16-core share
+        try:
+            threads = min(16, len(os.sched_getaffinity(0)))
+        except AttributeError:
+            threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     o = O.OracleDeformSeg()
     apply_name_keyed_init(o)
     o.train()

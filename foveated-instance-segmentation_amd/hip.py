@@ -55,6 +55,15 @@ SIGNATURES = {
     "fs_seg_loss_fwd": "ppiiiffppp",
     "fs_seg_loss_bwd": "pppppiiif",
     "fs_adam_step": "pppplfffffif",
+    "fs_layernorm_fwd": "pppppplif",
+    "fs_layernorm_bwd": "ppppppppli",
+    "fs_gelu_fwd": "ppl",
+    "fs_gelu_bwd": "pppl",
+    "fs_dwconv3_fwd": "ppppiiiii",
+    "fs_dwconv3_bwd_weight": "pppiiii",
+    "fs_residual_droppath": "pppllfu",
+    "fs_attention_fwd": "pppppiiiiffu",
+    "fs_attention_bwd": "ppppppppiiiiffu",
 }
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 

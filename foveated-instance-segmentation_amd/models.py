@@ -46,7 +46,8 @@ class ModelBuilder:
             from . import deeplab as _dl
             net = _dl.deeplab(pretrained=False)
         elif arch == "segformer":
-            raise NotImplementedError("encoder 'segformer' (SURVEY §8 A22) is not built yet")
+            from . import segformer as _sf
+            net = _sf.segformer(pretrained=False)
         else:
             raise Exception("Architecture undefined!")
         return ModelBuilder._load(net, weights)

@@ -612,3 +612,121 @@ def inverse_index_maps(grid, H, W):
     v = torch.empty_like(u)
     hip.call("fs_inverse_index_maps", hip.ptr(grid), hip.ptr(u), hip.ptr(v), n, H, W)
     return u, v
+
+
+# ----------------------------------------------------------------------------------------------
+# SegFormer pieces (tokens = NHWC rows)
+# ----------------------------------------------------------------------------------------------
+class LayerNorm(Function):
+    """nn.LayerNorm over the last dimension."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        hip.call("fs_layernorm_fwd", hip.ptr(x), hip.ptr(gamma), hip.ptr(beta), hip.ptr(y), hip.ptr(mean), hip.ptr(rstd), M, C, float(eps))
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        C = x.shape[-1]
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        hip.call("fs_layernorm_bwd", hip.ptr(g.contiguous()), hip.ptr(x), hip.ptr(gamma), hip.ptr(mean), hip.ptr(rstd), hip.ptr(dx),
+                 hip.ptr(dgamma), hip.ptr(dbeta), x.numel() // C, C)
+        return dx, dgamma, dbeta, None
+
+
+class Gelu(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty_like(x)
+        hip.call("fs_gelu_fwd", hip.ptr(x), hip.ptr(y), x.numel())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        hip.call("fs_gelu_bwd", hip.ptr(g.contiguous()), hip.ptr(x), hip.ptr(dx), x.numel())
+        return dx
+
+
+class DwConv3(Function):
+    """Depthwise Conv2d(C,C,3,1,1,groups=C) + bias on NHWC; w logical (C,1,3,3)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        B, H, W, C = x.shape
+        y = torch.empty_like(x)
+        hip.call("fs_dwconv3_fwd", hip.ptr(x), hip.ptr(w), hip.ptr(bias), hip.ptr(y), B, H, W, C, 0)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        B, H, W, C = x.shape
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        hip.call("fs_dwconv3_fwd", hip.ptr(g), hip.ptr(w), None, hip.ptr(dx), B, H, W, C, 1)
+        dw = torch.empty_like(w)
+        hip.call("fs_dwconv3_bwd_weight", hip.ptr(x), hip.ptr(g), hip.ptr(dw), B, H, W, C)
+        db = colsum(g, C) if ctx.has_bias else None
+        return dx, dw, db
+
+
+class ResidualDropPath(Function):
+    """out = x + DropPath_p(y): per-sample keep from the hash (p = 0: plain residual add)."""
+
+    @staticmethod
+    def forward(ctx, x, y, p, key):
+        out = torch.empty_like(x)
+        per = x.numel() // x.shape[0]
+        hip.call("fs_residual_droppath", hip.ptr(x), hip.ptr(y), hip.ptr(out), x.numel(), per, float(p), int(key))
+        ctx.cfg = (float(p), int(key), per)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, key, per = ctx.cfg
+        g = g.contiguous()
+        if p == 0.0:
+            return g, g, None, None
+        dy = torch.empty_like(g)
+        hip.call("fs_residual_droppath", None, hip.ptr(g), hip.ptr(dy), g.numel(), per, p, key)
+        return g, dy, None, None
+
+
+class Attention(Function):
+    """softmax(q k^T / sqrt(64)) (dropout p) v per head; q (B,N,C), k/v (B,Nk,C), C = heads*64, Nk <= 128."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, p, key):
+        B, N, C = q.shape
+        Nk = k.shape[1]
+        assert C == heads * 64, "head_dim must be 64"
+        o = torch.empty_like(q)
+        lse = torch.empty(B * heads * N, device=q.device, dtype=torch.float32)
+        hip.call("fs_attention_fwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o), hip.ptr(lse), B, N, Nk, heads, 0.125, float(p), int(key))
+        ctx.save_for_backward(q, k, v, lse)
+        ctx.cfg = (heads, float(p), int(key))
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, lse = ctx.saved_tensors
+        heads, p, key = ctx.cfg
+        B, N, C = q.shape
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        hip.call("fs_attention_bwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(go.contiguous()), hip.ptr(lse), hip.ptr(dq), hip.ptr(dk),
+                 hip.ptr(dv), B, N, k.shape[1], heads, 0.125, p, key)
+        return dq, dk, dv, None, None, None

@@ -132,6 +132,29 @@ int fs_seg_loss_fwd(const float* pred, const long long* gt, int B, int K, int HW
 int fs_seg_loss_bwd(const float* pred, const long long* gt, const float* coef, const float* gout, float* dpred, int B, int K,
                     int HW, float gamma, fs_stream_t stream);
 
+/* ---- SegFormer (Mix-Transformer) encoder pieces; tokens are NHWC rows (B, N=H*W, C) ------------------------
+ * third-party transformers==4.46.2 modeling_segformer behind models/segformer.py:9-60,87-105 */
+/* nn.LayerNorm(C, eps) over the last dim of M rows; mean/rstd (M floats each) kept for the backward. */
+int fs_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long M, int C,
+                     float eps, fs_stream_t stream);
+int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                     float* dgamma, float* dbeta, long M, int C, fs_stream_t stream);
+/* exact (erf) GELU. */
+int fs_gelu_fwd(const float* x, float* y, long n, fs_stream_t stream);
+int fs_gelu_bwd(const float* g, const float* x, float* dx, long n, fs_stream_t stream);
+/* depthwise Conv2d(C, C, 3, 1, 1, groups=C) on NHWC, weight (C,1,3,3); flip=1 gives the input gradient. */
+int fs_dwconv3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int flip,
+                   fs_stream_t stream);
+int fs_dwconv3_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int C, fs_stream_t stream);
+/* out = x + DropPath_p(y) (per-sample keep, hash keyed); x NULL -> out = scaled y (the backward of the y branch). */
+int fs_residual_droppath(const float* x, const float* y, float* out, long n, long per_sample, float drop_p, uint32_t key,
+                         fs_stream_t stream);
+/* softmax(q k^T * scale) (dropout p) v per head; head_dim 64, Nk <= 128 reduced key/value tokens; lse = B*heads*N floats. */
+int fs_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int N, int Nk, int heads,
+                     float scale, float drop_p, uint32_t key, fs_stream_t stream);
+int fs_attention_bwd(const float* q, const float* k, const float* v, const float* go, const float* lse, float* dq, float* dk,
+                     float* dv, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key, fs_stream_t stream);
+
 /* ---- optimiser ------------------------------------------------------------------------------- */
 /* torch.optim.Adam(weight_decay) step over a flat fp32 arena of n (multiple of 4) elements; step >= 1;
  * grad_scale multiplies the gradient first (1/world_size).  train_deform_semantic.py:115-123,271-288. */

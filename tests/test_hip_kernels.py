@@ -780,3 +780,179 @@ def test_deeplab_through_module_surface():
     loss, acc, edge = module(feed)
     loss.mean().backward()
     assert np.isfinite(float(loss.detach())) and module.encoder.deeplab.backbone.conv1.weight.grad is not None
+
+
+# ------------------------------------------------------------------------------------------------
+# SegFormer encoder plugin: kernels vs torch, encoder vs oracle / transformers-5.15 golden
+# ------------------------------------------------------------------------------------------------
+def test_layernorm_gelu_dwconv_droppath():
+    g = torch.Generator().manual_seed(41)
+    for C in (64, 320, 2048):
+        x = torch.randn(3, 37, C, generator=g)
+        w, b = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ref = F.layer_norm(xr, (C,), wr, br, 1e-6)
+        cot = torch.randn(ref.shape, generator=g)
+        ref.backward(cot)
+        xd, wd, bd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        out = ops.LayerNorm.apply(xd, wd, bd, 1e-6)
+        out.backward(cot.to(DEV))
+        assert relerr(out.detach().cpu(), ref.detach()) <= 1e-5
+        assert relerr(xd.grad.cpu(), xr.grad) <= 1e-4
+        assert relerr(wd.grad.cpu(), wr.grad) <= 1e-4 and relerr(bd.grad.cpu(), br.grad) <= 1e-4
+    x = torch.randn(2, 9, 7, 256, generator=g) * 2
+    xr = x.clone().requires_grad_(True)
+    ref = F.gelu(xr)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot)
+    xd = x.to(DEV).requires_grad_(True)
+    out = ops.Gelu.apply(xd)
+    out.backward(cot.to(DEV))
+    assert relerr(out.detach().cpu(), ref.detach()) <= 1e-6 and relerr(xd.grad.cpu(), xr.grad) <= 1e-5
+    # depthwise 3x3
+    C = 256
+    xi = torch.randn(2, C, 11, 13, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) * 0.3
+    b = torch.randn(C, generator=g) * 0.1
+    xr, wr, br = xi.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, 1, 1, 1, C)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot)
+    xd, wd, bd = nhwc(xi).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    out = ops.DwConv3.apply(xd, wd, bd)
+    out.backward(nhwc(cot))
+    assert relerr(nchw(out), ref.detach()) <= 1e-5 and relerr(nchw(xd.grad), xr.grad) <= 1e-5
+    assert relerr(wd.grad.cpu(), wr.grad) <= 1e-4 and relerr(bd.grad.cpu(), br.grad) <= 1e-4
+    # residual + DropPath replay
+    key = ops.layer_key(2, 5)
+    a, y = torch.randn(6, 10, 64, generator=g), torch.randn(6, 10, 64, generator=g)
+    keep = torch.from_numpy(O.dropout_keep_mask_nhwc(6, key, 0.25)).float().view(6, 1, 1)
+    ad, yd = a.to(DEV).requires_grad_(True), y.to(DEV).requires_grad_(True)
+    out = ops.ResidualDropPath.apply(ad, yd, 0.25, key)
+    out.backward(torch.ones_like(out))
+    assert relerr(out.detach().cpu(), a + y * keep / 0.75) <= 1e-6
+    assert torch.equal(ad.grad.cpu(), torch.ones(6, 10, 64)) and relerr(yd.grad.cpu(), (keep / 0.75).expand(6, 10, 64)) <= 1e-6
+
+
+@pytest.mark.parametrize("heads,N,Nk,p", [(1, 200, 100, 0.0), (5, 77, 100, 0.2), (2, 130, 25, 0.2)])
+def test_attention_vs_torch(heads, N, Nk, p):
+    g = torch.Generator().manual_seed(43)
+    B, C = 2, heads * 64
+    q, k, v = (torch.randn(B, n, C, generator=g) for n in (N, Nk, Nk))
+    key = ops.layer_key(7, 70)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    qh, kh, vh = (t.view(B, -1, heads, 64).transpose(1, 2) for t in (qr, kr, vr))
+    probs = torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, -1)
+    if p > 0:
+        keep = torch.from_numpy(O.dropout_keep_mask_nhwc(B * heads * N * Nk, key, p)).view(B, heads, N, Nk).float()
+        probs = probs * keep * np.float32(1.0 / (1.0 - p))
+    ref = (probs @ vh).transpose(1, 2).reshape(B, N, C)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = ops.Attention.apply(qd, kd, vd, heads, p, key)
+    out.backward(cot.to(DEV))
+    assert relerr(out.detach().cpu(), ref.detach()) <= 1e-5
+    assert relerr(qd.grad.cpu(), qr.grad) <= 1e-4
+    assert relerr(kd.grad.cpu(), kr.grad) <= 1e-4
+    assert relerr(vd.grad.cpu(), vr.grad) <= 1e-4
+
+
+def _segformer_pair():
+    import segformer_oracle as SO
+    from fovealseg import segformer as S
+    o = SO.OracleSegformer()
+    fovealseg.weights.apply_name_keyed_init(o)
+    m = S.segformer()
+    m.load_state_dict(o.state_dict(), strict=True)
+    return o, m.to(DEV), SO
+
+
+def test_segformer_eval_vs_golden_and_oracle(golden):
+    g = golden("g13_segformer")
+    o, m, SO = _segformer_pair()
+    o.eval()
+    m.eval()
+    x = T(g["x"])
+    xd = x.to(DEV).requires_grad_(True)
+    out = m(xd)[0]
+    assert out.shape == (1, 1024, 80, 80)
+    oc = out.detach().cpu()
+    assert np.abs(oc[0, :, 32:48, 32:48].numpy() - g["crop"]).max() <= 2e-4          # transformers 5.15.0 golden
+    assert np.abs(oc.mean(dim=(0, 2, 3)).numpy() - g["chan_mean"]).max() <= 2e-4
+    xr = x.clone().requires_grad_(True)
+    ref = o(xr)[0]
+    cot = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3)) * 0.01
+    o.zero_grad()
+    ref.backward(cot)
+    m.zero_grad()
+    out.backward(cot.to(DEV))
+    assert relerr(oc, ref.detach()) <= 1e-4
+    assert relerr(xd.grad.cpu(), xr.grad) <= 2e-3
+    po, pm = dict(o.named_parameters()), dict(m.named_parameters())
+    for k in ("segformer.encoder.patch_embeddings.0.proj.weight", "segformer.encoder.block.0.1.attention.self.sr.weight",
+              "segformer.encoder.block.2.17.attention.self.key.weight", "segformer.encoder.block.1.3.mlp.dwconv.dwconv.weight",
+              "segformer.encoder.block.3.2.mlp.dense2.bias", "segformer.encoder.block.2.39.layer_norm_2.weight",
+              "segformer.encoder.layer_norm.1.bias"):
+        assert relerr(pm[k].grad.cpu(), po[k].grad) <= 2e-3, k
+
+
+def test_segformer_layer_train_replay():
+    """One stage-2 transformer block in train mode: hidden/attention dropout and DropPath replayed from the hash."""
+    o, m, SO = _segformer_pair()
+    o.train()
+    m.train()
+    ops.DropoutState.seed, ops.DropoutState.step = 8, 1
+    i, j = 1, 4
+    ob, mb = o.segformer.encoder.block[i][j], m.segformer.encoder.block[i][j]
+    base = f"segformer.encoder.block.{i}.{j}"
+
+    def key_of(path):
+        return ops.DropoutState.key(ops.layer_id_from_name(path))
+
+    class H(SO.Hooks):
+        def dropout(self, path, x, p, training):
+            # module paths: <base>.attention.output.dropout, <base>.mlp.dropout1/2 (elements in (B,N,C) order)
+            keep = torch.from_numpy(O.dropout_keep_mask_nhwc(x.numel(), key_of(path), p)).view(x.shape).float()
+            return x * keep * np.float32(1.0 / (1.0 - p))
+
+        def attn_dropout(self, path, probs, p, training):
+            keep = torch.from_numpy(O.dropout_keep_mask_nhwc(probs.numel(), key_of(path), p)).view(probs.shape).float()
+            return probs * keep * np.float32(1.0 / (1.0 - p))
+
+        def drop_path(self, path, y, p, training):
+            keep = torch.from_numpy(O.dropout_keep_mask_nhwc(y.shape[0], key_of(path), p)).float().view(-1, 1, 1)
+            return y * keep * np.float32(1.0 / (1.0 - p))
+    g = torch.Generator().manual_seed(47)
+    B, h, w, C = 4, 12, 12, 128
+    x = torch.randn(B, h * w, C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = ob(xr, h, w, H(), base, True)
+    cot = torch.randn(ref.shape, generator=g)
+    ob.zero_grad()
+    ref.backward(cot)
+    xd = x.view(B, h, w, C).to(DEV).requires_grad_(True)
+    out = mb(xd)
+    mb.zero_grad()
+    out.backward(cot.view(B, h, w, C).to(DEV))
+    assert relerr(out.detach().cpu().view(B, h * w, C), ref.detach()) <= 2e-5
+    assert relerr(xd.grad.cpu().view(B, h * w, C), xr.grad) <= 2e-4
+    po, pm = dict(ob.named_parameters()), dict(mb.named_parameters())
+    for k in po:
+        if k.endswith("self.key.bias"):      # analytically zero: a constant added to every key leaves the softmax unchanged
+            continue
+        assert relerr(pm[k].grad.cpu(), po[k].grad) <= 5e-4, k
+
+
+def test_segformer_through_module_surface():
+    cfg = fovealseg.lvis50_cfg()
+    cfg.MODEL.arch_encoder, cfg.MODEL.fc_dim = "segformer", 1024
+    from fovealseg import train
+    module, nets = train.build_module(cfg, device=DEV)
+    module.train()
+    batch = train.synthetic_batch(2, 128, 128, seed=9, device=DEV)
+    feed = {"img_data": batch[0], "seg_label": batch[2], "focus_point": batch[1], "cls_label": batch[3]}
+    loss, acc, edge = module(feed)
+    loss.mean().backward()
+    assert np.isfinite(float(loss.detach()))
+    assert module.encoder.segformer.encoder.block[2][20].mlp.dense1.weight.grad is not None

@@ -50,8 +50,8 @@ def test_builder_errors_match_reference():
         MB.build_encoder("resnet50")
     with pytest.raises(Exception, match="Architecture undefined!"):
         MB.build_decoder("upernet")
-    with pytest.raises(NotImplementedError):
-        MB.build_encoder("segformer")
+    sf = MB.build_encoder("segformer", fc_dim=1024)
+    assert len(sf.state_dict()) == 1172 and "segformer.encoder.block.2.39.mlp.dwconv.dwconv.weight" in sf.state_dict()
     enc = MB.build_encoder("deeplab", fc_dim=960)
     assert "deeplab.classifier.0.convs.4.1.weight" in enc.state_dict() and len(enc.state_dict()) == 669
 

@@ -235,3 +235,19 @@ def test_g12_lr(golden):
         ep = int(row[0])
         for lr in row[1:]:
             assert lr == O.lr_for_epoch(ep)
+
+
+def test_g13_segformer_oracle_vs_transformers(golden):
+    """oracle/segformer_oracle.py against transformers 5.15.0 SegformerModel (tests/golden/make_segformer_golden.py)."""
+    import segformer_oracle as SO
+    g = golden("g13_segformer")
+    o = SO.OracleSegformer()
+    apply_name_keyed_init(o)
+    o.eval()
+    with torch.no_grad():
+        outs = o.stages(T(g["x"]))
+        cat = o(T(g["x"]))[0]
+    assert cat.shape == (1, 1024, 80, 80)
+    assert np.abs(outs[3][0].numpy() - g["stage3"]).max() <= 1e-4
+    assert np.abs(cat[0, :, 32:48, 32:48].numpy() - g["crop"]).max() <= 1e-4
+    assert np.abs(cat.mean(dim=(0, 2, 3)).numpy() - g["chan_mean"]).max() <= 1e-4
