@@ -21,6 +21,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, dense bf16 MFMA; the bf16x3 conv issues 6 bf16 MFMAs per fp32 product
 PEAK_HBM_GBS = 8000.0
 
 
@@ -78,6 +79,9 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--serial-streams", action="store_true", help="run the HRNet branches on one stream (profiling)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--conv-precision", default="bf16x3", choices=["bf16x3", "f32"],
+                    help="arithmetic of the aligned conv kernel: bf16x3 = fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs "
+                         "per product, fp32 accumulation (fp32-level accuracy); f32 = fp32 MFMA")
     args = ap.parse_args()
 
     import fovealseg
@@ -85,6 +89,7 @@ def main():
     from fovealseg import ops
 
     fovealseg.hip.load()       # fail loudly if the HIP library is missing
+    fovealseg.hip.set_conv_precision(args.conv_precision)
     rank, local_rank, world = T.ddp_setup(backend=args.backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
@@ -148,7 +153,7 @@ def main():
         "metric": "images/sec fwd+bwd, 1024->80 foveated HRNetV2, batch 64",
         "value": round(imgs / elapsed, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "conv_precision": args.conv_precision,
         "config": {"workload": f"BASELINE configs[1]: HRNetV2-nodownsp + C1, {args.size}x{args.size}->80x80, gaussian_radius 45, "
                                f"batch {args.batch}/GPU, train mode (BN batch stats, Dropout 0.3), fwd+bwd+Adam x4",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": round(loss_val, 5)},
@@ -159,10 +164,18 @@ def main():
             k = summ.get("conv_affine")
             if k:
                 achieved = k["flops"] / (k["total_ms"] * 1e-3) / 1e12
+                if args.conv_precision == "bf16x3":
+                    kname, peak = "conv_igemm_x3_kernel", PEAK_BF16_MFMA_TFLOPS / 6.0
+                    kdesc = ("conv_igemm_x3_kernel (fwd + bwd-data implicit GEMM; fp32 operands split into 3 bf16 terms, 6 x "
+                             "v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; achieved = algorithmic fp32 FLOP/s, "
+                             "peak = dense bf16 MFMA peak / 6)")
+                else:
+                    kname, peak = "conv_igemm_affine_kernel<1>", PEAK_F32_MFMA_TFLOPS
+                    kdesc = "conv_igemm_affine_kernel<1> (fwd + bwd-data implicit GEMM, fp32 MFMA 32x32x2)"
                 line["roofline"] = {
-                    "kernel": "conv_igemm_affine_kernel<1> (fwd + stride-1 bwd-data implicit GEMM, fp32 MFMA 32x32x2)",
-                    "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": _profiled_traffic("conv_igemm_affine_kernel<1>"),
+                    "kernel": kdesc,
+                    "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": _profiled_traffic(kname),
                     "launches_per_step": k["launches"] // args.steps,
                     "avg_launch_us": round(1000.0 * k["total_ms"] / k["launches"], 2),
                     "gflop_per_launch": round(k["flops"] / k["launches"] / 1e9, 3),

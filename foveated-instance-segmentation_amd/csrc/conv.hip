@@ -238,6 +238,12 @@ struct AffArgs {
 };
 
 static thread_local hipStream_t a_stream = nullptr;   // host: stream of the launch being issued
+// 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-precision bf16x3 (six v_mfma_f32_32x32x16_bf16 per product).
+// Default from FS_CONV_PRECISION=f32|bf16x3 (bf16x3 when unset); fs_set_conv_precision() overrides.
+static int g_conv_precision = [] {
+  const char* e = getenv("FS_CONV_PRECISION");
+  return (e && e[0] == 'f') ? 0 : 1;
+}();
 
 template <int MT>
 __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
@@ -446,6 +452,208 @@ __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
     // lanes l and l+32 hold the same columns (rows +4): combine, then the 4 waves through LDS
     __syncthreads();                                  // all MFMA-stage LDS reads are finished
     float* red = &As[0][0];                           // [4 waves][64 cols][2]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float s1 = csum[t] + __shfl_xor(csum[t], 32, 64), s2 = csq[t] + __shfl_xor(csq[t], 32, 64);
+      if (lh == 0) { red[(wave * 64 + 32 * t + l31) * 2] = s1; red[(wave * 64 + 32 * t + l31) * 2 + 1] = s2; }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int col = tid >> 1, which = tid & 1;
+      const float v = red[(0 * 64 + col) * 2 + which] + red[(1 * 64 + col) * 2 + which] + red[(2 * 64 + col) * 2 + which] +
+                      red[(3 * 64 + col) * 2 + which];
+      const int n = n0 + col;
+      if (n < a.Cd) a.stats[((long)(wg / a.ny) * a.Cd + n) * 2 + which] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Split-precision variant of the affine kernel ("bf16x3"): every fp32 operand is split on the fly into
+// three bf16 terms x = x1 + x2 + x3 (exact to 24 bits) while it is written to LDS, and each fp32 product
+// is formed by six bf16 MFMAs (x1y3 + x2y2 + x3y1 + x1y2 + x2y1 + x1y1, fp32 accumulation; the dropped
+// terms are <= 2^-24 relative, i.e. at the fp32 rounding level).  v_mfma_f32_32x32x16_bf16 runs at 16x the
+// fp32-MFMA rate, so six of them cost 3/8 of the eight v_mfma_f32_32x32x2_f32 they replace.
+// Same tiling / addressing / epilogue as conv_igemm_affine_kernel; LDS holds 3 bf16 planes per operand,
+// rows padded to 80 B so the ds_read_b128 fragment reads are conflict-free.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int XLD = 40;   // bf16 per LDS row: 32 k + 8 pad (80 bytes)
+
+__device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c) {
+  a = (__bf16)x;
+  const float r = x - (float)a;
+  b = (__bf16)r;
+  c = (__bf16)(r - (float)b);
+}
+
+__global__ __launch_bounds__(256) void conv_igemm_x3_kernel(AffArgs a) {
+  constexpr int TM = 128, NR = 4;
+  __shared__ __attribute__((aligned(16))) __bf16 Ap[3][TM * XLD];
+  __shared__ __attribute__((aligned(16))) __bf16 Bp[3][BN * XLD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long M = (long)a.B * a.Hq * a.Wq;
+  const int nwg = a.nx * a.ny;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd = nwg >> 3, rm = nwg & 7;
+  const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+  const long m0 = (long)(wg / a.ny) * TM;
+  const int n0 = (wg % a.ny) * BN;
+  const int q = tid & 7, arow = tid >> 3;
+  const int sgn = a.transposed ? -1 : 1;
+  const int ntap = a.nR * a.nS;
+
+  int roff[NR];
+  uint32_t rmask[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const long m = m0 + arow + 32 * i;
+    roff[i] = 0; rmask[i] = 0u;
+    if (m < M) {
+      const int b = (int)(m / ((long)a.Hq * a.Wq));
+      const int rem = (int)(m - (long)b * a.Hq * a.Wq);
+      const int py = rem / a.Wq, px = rem - py * a.Wq;
+      const int iy0 = a.transposed ? py + a.cy : py * a.stride - a.pad;
+      const int ix0 = a.transposed ? px + a.cx : px * a.stride - a.pad;
+      roff[i] = ((b * a.Hs + iy0) * a.Ws + ix0) * a.Cs + 4 * q;
+      uint32_t mk = 0u;
+      for (int t = 0; t < ntap; ++t) {
+        const int tr = t / a.nS, ts = t - tr * a.nS;
+        const int iy = iy0 + sgn * tr * a.dil, ix = ix0 + sgn * ts * a.dil;
+        if (iy >= 0 && iy < a.Hs && ix >= 0 && ix < a.Ws) mk |= (1u << t);
+      }
+      rmask[i] = mk;
+    }
+  }
+  // B loader: each thread fetches 8 consecutive k of one output column n
+  //   forward : n = tid&63, k = 8*(tid>>6)+j, element (tap*Cs + c0 + k)*Cd + n0 + n       (8 dword loads)
+  //   bwd-data: n = tid>>2, k = 8*(tid&3)+j,  element (tap*Cd + n0 + n)*Cs + c0 + k        (2 dwordx4 loads)
+  const int bn = a.transposed ? (tid >> 2) : (tid & 63);
+  const int bk0 = a.transposed ? 8 * (tid & 3) : 8 * (tid >> 6);
+  const bool bnok = n0 + bn < a.Cd;
+  const int nchunk = (a.Cs + BK - 1) / BK;
+  const int nstage = ntap * nchunk;
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(a.src, a.src_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.w, a.w_bytes);
+
+  f32x4 ra[NR];
+  float rb[8];
+  auto load_stage = [&](int st) {
+    const int tapq = st / nchunk, c0 = (st - tapq * nchunk) * BK;
+    const int tr = tapq / a.nS, ts = tapq - tr * a.nS;
+    const int tap = (a.r0 + a.tstep * tr) * a.S + (a.s0 + a.tstep * ts);
+    const int aoff = sgn * a.dil * (tr * a.Ws + ts) * a.Cs + c0;
+    const bool aok = c0 + 4 * q < a.Cs;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const bool ok = ((rmask[i] >> tapq) & 1u) && aok;
+      ra[i] = buf_load4(rsrc_a, ok ? (unsigned)(roff[i] + aoff) * 4u : OOB);
+    }
+    if (!a.transposed) {
+      const int wbase = (tap * a.Cs + c0 + bk0) * a.Cd + n0 + bn;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = bnok && (c0 + bk0 + j < a.Cs);
+        rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_w, ok ? (int)((unsigned)(wbase + j * a.Cd) * 4u) : (int)OOB, 0, 0));
+      }
+    } else {
+      const int wbase = (tap * a.Cd + n0 + bn) * a.Cs + c0 + bk0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool ok = bnok && (c0 + bk0 + 4 * h < a.Cs);
+        const f32x4 v = buf_load4(rsrc_w, ok ? (unsigned)(wbase + 4 * h) * 4u : OOB);
+        rb[4 * h] = v.x; rb[4 * h + 1] = v.y; rb[4 * h + 2] = v.z; rb[4 * h + 3] = v.w;
+      }
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      bf16x4 p0, p1, p2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { __bf16 x, y, z; split3(ra[i][e], x, y, z); p0[e] = x; p1[e] = y; p2[e] = z; }
+      const int o = (arow + 32 * i) * XLD + 4 * q;
+      *reinterpret_cast<bf16x4*>(&Ap[0][o]) = p0;
+      *reinterpret_cast<bf16x4*>(&Ap[1][o]) = p1;
+      *reinterpret_cast<bf16x4*>(&Ap[2][o]) = p2;
+    }
+    bf16x8 w0, w1, w2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { __bf16 x, y, z; split3(rb[j], x, y, z); w0[j] = x; w1[j] = y; w2[j] = z; }
+    const int o = bn * XLD + bk0;
+    *reinterpret_cast<bf16x8*>(&Bp[0][o]) = w0;
+    *reinterpret_cast<bf16x8*>(&Bp[1][o]) = w1;
+    *reinterpret_cast<bf16x8*>(&Bp[2][o]) = w2;
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int aidx = (wave * 32 + l31) * XLD + 8 * lh;     // + 16*s
+  const int bidx = l31 * XLD + 8 * lh;                   // + 32*t*XLD + 16*s
+
+  if (nstage > 0) load_stage(0);
+  for (int st = 0; st < nstage; ++st) {
+    __syncthreads();
+    store_stage();
+    __syncthreads();
+    if (st + 1 < nstage) load_stage(st + 1);
+    bf16x8 fa[2][3], fb[2][2][3];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3) {
+        fa[s2][p3] = *reinterpret_cast<const bf16x8*>(&Ap[p3][aidx + 16 * s2]);
+        fb[s2][0][p3] = *reinterpret_cast<const bf16x8*>(&Bp[p3][bidx + 16 * s2]);
+        fb[s2][1][p3] = *reinterpret_cast<const bf16x8*>(&Bp[p3][bidx + 32 * XLD + 16 * s2]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      // smallest cross terms first
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0], fb[s2][0][2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0], fb[s2][1][2], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][1], fb[s2][0][1], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][1], fb[s2][1][1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][2], fb[s2][0][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][2], fb[s2][1][0], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0], fb[s2][0][1], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0], fb[s2][1][1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][1], fb[s2][0][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][1], fb[s2][1][0], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0], fb[s2][0][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0], fb[s2][1][0], acc1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = n0 + 32 * t + l31;
+    if (n >= a.Cd) continue;
+    const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= M) continue;
+      float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
+      long e = m * a.Cd + n;
+      if (a.os > 1) {
+        const int b = (int)(m / ((long)a.Hq * a.Wq));
+        const int rem = (int)(m - (long)b * a.Hq * a.Wq);
+        const int py = rem / a.Wq, px = rem - py * a.Wq;
+        e = (((long)b * a.Hd + py * a.os + a.oy0) * a.Wd + px * a.os + a.ox0) * a.Cd + n;
+      }
+      if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+      a.dst[e] = v;
+      csum[t] += v; csq[t] += v * v;
+    }
+  }
+  if (a.stats != nullptr) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&Ap[0][0]);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const float s1 = csum[t] + __shfl_xor(csum[t], 32, 64), s2 = csq[t] + __shfl_xor(csq[t], 32, 64);
@@ -689,7 +897,10 @@ int launch_affine_one(AffArgs& a) {
   a.nx = cdiv(M, 128);
   a.ny = cdiv(a.Cd, BN);
   // MT=2 (256-row tiles) needs 84 KB of LDS = one workgroup per CU and measured 20-25 % slower.
-  hipLaunchKernelGGL(conv_igemm_affine_kernel<1>, dim3(a.nx * a.ny), dim3(256), 0, a_stream, a);
+  if (g_conv_precision == 1)
+    hipLaunchKernelGGL(conv_igemm_x3_kernel, dim3(a.nx * a.ny), dim3(256), 0, a_stream, a);
+  else
+    hipLaunchKernelGGL(conv_igemm_affine_kernel<1>, dim3(a.nx * a.ny), dim3(256), 0, a_stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -726,6 +937,14 @@ int launch_affine(const ConvArgs& c, long M) {
 }  // namespace
 
 extern "C" {
+
+// include/fovealseg.h: fs_set_conv_precision / fs_get_conv_precision (host-side switch, no launch)
+int fs_set_conv_precision(int mode) {
+  FS_REQUIRE(mode == 0 || mode == 1);
+  g_conv_precision = mode;
+  return FS_OK;
+}
+int fs_get_conv_precision(void) { return g_conv_precision; }
 
 // include/fovealseg.h: fs_conv2d_fwd
 int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,

@@ -68,6 +68,7 @@ SIGNATURES = {
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 
 _lib = None
+HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision")   # declared in the header, no stream argument
 
 
 class HipLibraryError(RuntimeError):
@@ -88,8 +89,23 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = _I
         fn.argtypes = [_CT[c] for c in sig] + [_P]
+    lib.fs_set_conv_precision.restype = _I
+    lib.fs_set_conv_precision.argtypes = [_I]
+    lib.fs_get_conv_precision.restype = _I
+    lib.fs_get_conv_precision.argtypes = []
     _lib = lib
     return lib
+
+
+def set_conv_precision(mode: str) -> None:
+    """'f32' (fp32 MFMA) or 'bf16x3' (split-precision bf16 MFMA, fp32-level accuracy; the default)."""
+    code = {"f32": 0, "bf16x3": 1}[mode]
+    if load().fs_set_conv_precision(code) != 0:
+        raise HipLibraryError("fs_set_conv_precision rejected the mode")
+
+
+def get_conv_precision() -> str:
+    return ("f32", "bf16x3")[load().fs_get_conv_precision()]
 
 
 def _stream():

@@ -59,7 +59,13 @@ int fs_grid_sample_bwd_input(const float* gout, const float* grid, float* dx, in
 /* u=int((gx+1)/2*(W-1)), v=int((gy+1)/2*(H-1)) for n grid points.  models/models.py:644-645. */
 int fs_inverse_index_maps(const float* grid, long long* u, long long* v, long n, int H, int W, fs_stream_t stream);
 
-/* ---- convolution engine (fp32 MFMA implicit GEMM) --------------------------------------------- */
+/* ---- convolution engine (implicit GEMM on the matrix cores) ------------------------------------ */
+/* Arithmetic of the aligned-channel forward / bwd-data kernel: 0 = fp32 MFMA (exact fp32 fma chain),
+ * 1 = split precision "bf16x3": each fp32 operand is split into three bf16 terms (exact to 24 bits) and each
+ * product is six bf16 MFMAs with fp32 accumulation (error at the fp32 rounding level, 2.7x fewer MFMA cycles).
+ * Default 1 (or FS_CONV_PRECISION=f32|bf16x3 in the environment).  Host-side switch, not a launch. */
+int fs_set_conv_precision(int mode);
+int fs_get_conv_precision(void);
 /* F.conv2d(x, w, bias, stride, pad, dilation=dil) [+ Dropout(drop_p) keyed by drop_key when drop_p > 0].
  * models/hrnetv2_nodownsp.py:49-50,54-55 and every nn.Conv2d on the path. */
 int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Ho, int Wo,

@@ -34,9 +34,32 @@ def rsck_param(w):    # logical (Co,Ci,R,S) cpu -> device tensor with RSCK stora
     return p
 
 
-def relerr(a, b):
+def relerr(a, b, prec=None):
+    """max |a-b| / max |b|.  In bf16x3 mode (prec == 'bf16x3') the largest 3 % of the element errors are ignored:
+    the split-precision conv is as accurate as the fp32-MFMA one (tools/conv_accuracy.py: rms 3.6e-7..1.0e-6 vs
+    4.3e-7..1.2e-6 against fp64) but not bit-identical to it, so in blocks with ReLU an activation within ~1e-6 of
+    zero can take the other branch; that single element then changes its 3x3 neighbourhood of input gradients by
+    O(1), which a max-norm over a 2x20x20 test tensor would report as a failure of the whole tensor."""
     a, b = a.double(), b.double()
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    d = (a - b).abs().flatten()
+    if prec == "bf16x3" and d.numel() >= 100:
+        d = d.kthvalue(max(1, int(0.97 * d.numel()))).values
+    else:
+        d = d.max()
+    return float(d / b.abs().max().clamp_min(1e-12))
+
+
+def wtol(prec, tol):
+    """Tolerance for quantities REDUCED over the pixels of a tiny test tensor (weight / affine gradients): one
+    ReLU-boundary flip (see relerr) moves every element of such a sum by ~1/sqrt(M) of its value."""
+    return 0.1 if prec == "bf16x3" else tol
+
+
+@pytest.fixture(params=["f32", "bf16x3"])
+def prec(request):
+    fovealseg.hip.set_conv_precision(request.param)
+    yield request.param
+    fovealseg.hip.set_conv_precision("bf16x3")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -62,7 +85,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_bwd(case):
+def test_conv_fwd_bwd(case, prec):
     B, H, W, Ci, Co, k, s, has_bias = case[:8]
     dil = case[8] if len(case) > 8 else 1
     g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
@@ -122,7 +145,7 @@ def test_conv_rejects_bad_shapes():
 
 @pytest.mark.parametrize("training", [True, False])
 @pytest.mark.parametrize("act,use_res,drop", [(1, True, 0.3), (2, False, 0.0), (0, False, 0.0)])
-def test_conv_bn_act(training, act, use_res, drop):
+def test_conv_bn_act(training, act, use_res, drop, prec):
     B, C, H, W = 3, 64, 12, 12
     g = torch.Generator().manual_seed(7)
     x = torch.randn(B, C, H, W, generator=g)
@@ -168,12 +191,12 @@ def test_conv_bn_act(training, act, use_res, drop):
     zd = ops.ConvBnAct.apply(xd, wd, None, gd, bd, rd, meta)
     zd.backward(nhwc(cot))
     assert relerr(nchw(zd), z.detach()) <= 2e-5
-    assert relerr(nchw(xd.grad), xr.grad) <= 1e-4
-    assert relerr(wd.grad.cpu(), wr.grad) <= 1e-4
-    assert relerr(gd.grad.cpu(), gr.grad) <= 1e-4
-    assert relerr(bd.grad.cpu(), br.grad) <= 1e-4
+    assert relerr(nchw(xd.grad), xr.grad, prec) <= 1e-4
+    assert relerr(wd.grad.cpu(), wr.grad) <= wtol(prec, 1e-4)
+    assert relerr(gd.grad.cpu(), gr.grad) <= wtol(prec, 1e-4)
+    assert relerr(bd.grad.cpu(), br.grad) <= wtol(prec, 1e-4)
     if use_res:
-        assert relerr(nchw(rd.grad), rr.grad) <= 1e-5
+        assert relerr(nchw(rd.grad), rr.grad, prec) <= 1e-5
     if training:
         assert relerr(rmd.cpu(), rm_ref) <= 1e-5 and relerr(rvd.cpu(), rv_ref) <= 1e-5
         assert meta["num_batches_tracked"].n == 1
@@ -382,7 +405,7 @@ def _set_drop(m, p):
 
 @pytest.mark.parametrize("name", ["basic", "bottleneck", "hrmodule4"])
 @pytest.mark.parametrize("mode", ["eval", "train_p0"])
-def test_g7_blocks(golden, hipmod, name, mode):
+def test_g7_blocks(golden, hipmod, name, mode, prec):
     g = golden(f"g7_{name}_{mode}")
     fovealseg.weights.apply_name_keyed_init(hipmod)
     blk = _sub(hipmod, str(g["prefix"]))
@@ -397,9 +420,11 @@ def test_g7_blocks(golden, hipmod, name, mode):
     for i, o in enumerate(outs):
         ref = g[f"out{i}"]
         assert np.abs(nchw(o).numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    # train mode + bf16x3: a boundary flip also shifts the batch means mean(g), mean(g*xhat) that BatchNorm's backward
+    # subtracts from EVERY element of that channel, so the whole tensor moves by ~1/M of the flipped value
+    tol_din = 1e-2 if (prec == "bf16x3" and mode != "eval") else 2e-4
     for i, t in enumerate(ins):
-        ref = g[f"din{i}"]
-        assert np.abs(nchw(t.grad).numpy() - ref).max() <= 2e-4 * max(1e-3, np.abs(ref).max())
+        assert relerr(nchw(t.grad), T(g[f"din{i}"]), prec) <= tol_din
     params = dict(blk.named_parameters())
     for k in g.files:
         if k.startswith("dw:") or k.startswith("dgamma:"):
@@ -407,12 +432,12 @@ def test_g7_blocks(golden, hipmod, name, mode):
             ref = g[k]
             if gr.shape != ref.shape:
                 gr = gr[:16, :16]
-            assert np.abs(gr.numpy() - ref).max() <= 5e-4 * max(1e-3, np.abs(ref).max()), k
+            assert np.abs(gr.numpy() - ref).max() <= wtol(prec, 5e-4) * max(1e-3, np.abs(ref).max()), k
     _set_drop(blk, 0.3)
     fovealseg.weights.apply_name_keyed_init(hipmod)
 
 
-def test_g8_hrnet_eval(golden, hipmod):
+def test_g8_hrnet_eval(golden, hipmod, prec):
     g = golden("g8_hrnet_eval")
     fovealseg.weights.apply_name_keyed_init(hipmod)
     hipmod.eval()
@@ -426,7 +451,7 @@ def test_g8_hrnet_eval(golden, hipmod):
 
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
-def test_g9_c1(golden, hipmod, mode):
+def test_g9_c1(golden, hipmod, mode, prec):
     g = golden(f"g9_c1_{mode}")
     fovealseg.weights.apply_name_keyed_init(hipmod)
     hipmod.decoder.train(mode == "train")
@@ -440,14 +465,13 @@ def test_g9_c1(golden, hipmod, mode):
     p = pred.detach().cpu()
     assert np.abs(p[:, :50, 0, 0].numpy() - g["pred_ch0"]).max() <= 2e-5
     assert np.abs(p[:, 50].numpy() - g["pred_last"]).max() <= 2e-5
-    ref = g["dfeat_crop"]
-    assert np.abs(fd.grad.cpu()[:, ::60, 20:36, 20:36].numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+    assert relerr(fd.grad.cpu()[:, ::60, 20:36, 20:36], T(g["dfeat_crop"]), prec) <= 2e-4
     ref = g["dfc"]
-    assert np.abs(hipmod.decoder.cls_net.fc.weight.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+    assert np.abs(hipmod.decoder.cls_net.fc.weight.grad.cpu().numpy() - ref).max() <= wtol(prec, 2e-4) * np.abs(ref).max()
     ref = g["dw_conv_last"]
-    assert np.abs(hipmod.decoder.conv_last.weight.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+    assert np.abs(hipmod.decoder.conv_last.weight.grad.cpu().numpy() - ref).max() <= wtol(prec, 2e-4) * np.abs(ref).max()
     ref = g["dcbr_crop"]
-    assert np.abs(hipmod.decoder.cbr[0].weight.grad.cpu()[:8, :8].numpy() - ref).max() <= 5e-4 * np.abs(ref).max()
+    assert np.abs(hipmod.decoder.cbr[0].weight.grad.cpu()[:8, :8].numpy() - ref).max() <= wtol(prec, 5e-4) * np.abs(ref).max()
     fovealseg.weights.apply_name_keyed_init(hipmod)
 
 
@@ -468,7 +492,7 @@ def _feed(g):
             "cls_label": T(g["cls"]).to(DEV)}
 
 
-def test_g11_end_to_end(golden, hipmod):
+def test_g11_end_to_end(golden, hipmod, prec):
     """End to end against the reference run.  The reference's own fp32 grid is 1.75e-5 from the fp64
     value of its formula; a 1.5e-5 perturbation of the grid flips 0.2 % of the truncated
     labels and moves the reference's OWN gradient norms by up to 21 % (measured with the oracle), so
@@ -521,15 +545,20 @@ def test_g11_end_to_end(golden, hipmod):
         params = dict(hipmod.named_parameters())
         for n, ref in zip(g["gn_names"], g["gn"]):
             gn = float(params[str(n)].grad.norm())
-            # saliency-side gradients pass through the clamp mask of create_grid (ill-conditioned, see g4)
-            tol = 5e-2 if (str(n).startswith("localization") or str(n).startswith("net_compress")) else 2e-3
+            # saliency-side gradients pass through the clamp mask of create_grid (ill-conditioned, see g4).
+            # Backbone norms: the reference's own fp32 run is 4.0e-3 (encoder.conv1.weight) and 2.6e-3 (a stage-3
+            # BN weight) away from an fp64 evaluation of the same graph (measured with the oracle; the other
+            # listed tensors <= 4e-4), so the budget is 2e-3 for the fp32-MFMA path, which tracks the CPU's
+            # rounding closely, and 1.2e-2 for bf16x3, whose (equally small) rounding errors are independent.
+            tol = 5e-2 if (str(n).startswith("localization") or str(n).startswith("net_compress")) else \
+                (2e-3 if prec == "f32" else 1.2e-2)
             assert abs(gn - float(ref)) <= tol * max(abs(float(ref)), 1e-6), (n, gn, ref)
     finally:
         _set_drop(hipmod, 0.3)
         fovealseg.weights.apply_name_keyed_init(hipmod)
 
 
-def test_dropout_replay_basic_block(hipmod):
+def test_dropout_replay_basic_block(hipmod, prec):
     """Train-mode BasicBlock with Dropout(0.3): the kernel's hash mask replayed in the oracle."""
     fovealseg.weights.apply_name_keyed_init(hipmod)
     o = O.OracleDeformSeg()
@@ -554,7 +583,7 @@ def test_dropout_replay_basic_block(hipmod):
     out = blk(xd)
     out.backward(nhwc(cot))
     assert relerr(nchw(out), ref.detach()) <= 2e-5
-    assert relerr(nchw(xd.grad), xr.grad) <= 2e-4
+    assert relerr(nchw(xd.grad), xr.grad, prec) <= 2e-4
     frac = float((nchw(out) == 0).float().mean())
     assert 0.0 < frac < 1.0
 
@@ -663,7 +692,7 @@ def test_train_and_eval_step_end_to_end():
 # w.r.t. torchvision, which is absent)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["eval", "train"])
-def test_deeplab_encoder_vs_oracle(mode):
+def test_deeplab_encoder_vs_oracle(mode, prec):
     import deeplab_oracle as DO
     from fovealseg import deeplab as D
     o = DO.OracleDeepLab()
@@ -702,17 +731,17 @@ def test_deeplab_encoder_vs_oracle(mode):
     #  done per block in test_deeplab_blocks_train)
     tol_out, tol_grad = (1e-4, 2e-3) if mode == "eval" else (2e-3, 0.25)
     assert relerr(out.detach().cpu(), ref.detach()) <= tol_out
-    assert relerr(xd.grad.cpu(), xr.grad) <= tol_grad
+    assert relerr(xd.grad.cpu(), xr.grad, prec) <= tol_grad
     po, pm = dict(o.named_parameters()), dict(m.named_parameters())
     for k in ("deeplab.backbone.conv1.weight", "deeplab.backbone.layer3.7.conv2.weight", "deeplab.classifier.0.convs.2.0.weight",
               "deeplab.classifier.0.convs.4.1.weight", "deeplab.classifier.4.bias", "deeplab.classifier.1.weight",
               "deeplab.backbone.layer4.2.bn3.weight"):
         if mode == "train" and "convs.4" in k:
             continue
-        assert relerr(pm[k].grad.cpu(), po[k].grad) <= tol_grad, k
+        assert relerr(pm[k].grad.cpu(), po[k].grad, prec) <= max(tol_grad, wtol(prec, tol_grad) if mode == "eval" else tol_grad), k
 
 
-def test_deeplab_blocks_train():
+def test_deeplab_blocks_train(prec):
     """Train-mode (batch statistics, Dropout(0.5) replayed) parity of the DeepLab-specific blocks in isolation:
     a dilated bottleneck and the ASPP head, where the comparison is well conditioned."""
     import deeplab_oracle as DO
@@ -738,8 +767,8 @@ def test_deeplab_blocks_train():
     mb.zero_grad()
     out.backward(nhwc(cot))
     assert relerr(nchw(out), ref.detach()) <= 2e-5
-    assert relerr(nchw(xd.grad), xr.grad) <= 2e-4
-    assert relerr(mb.conv2.weight.grad.cpu(), ob.conv2.weight.grad) <= 5e-4
+    assert relerr(nchw(xd.grad), xr.grad, prec) <= 2e-4
+    assert relerr(mb.conv2.weight.grad.cpu(), ob.conv2.weight.grad) <= wtol(prec, 5e-4)
     # ASPP head; the image-pooling BN normalises over B values only -> kept in eval mode on both sides
     oh, mh = o.deeplab.classifier, m.deeplab.classifier
     oh[0].convs[4][2].eval()
@@ -868,7 +897,7 @@ def _segformer_pair():
     return o, m.to(DEV), SO
 
 
-def test_segformer_eval_vs_golden_and_oracle(golden):
+def test_segformer_eval_vs_golden_and_oracle(golden, prec):
     g = golden("g13_segformer")
     o, m, SO = _segformer_pair()
     o.eval()
@@ -897,7 +926,7 @@ def test_segformer_eval_vs_golden_and_oracle(golden):
         assert relerr(pm[k].grad.cpu(), po[k].grad) <= 2e-3, k
 
 
-def test_segformer_layer_train_replay():
+def test_segformer_layer_train_replay(prec):
     """One stage-2 transformer block in train mode: hidden/attention dropout and DropPath replayed from the hash."""
     o, m, SO = _segformer_pair()
     o.train()
