@@ -11,6 +11,7 @@
 // K-step 32 inside one filter tap; each wave owns 32 x 64 = two 32x32 accumulators.  Operands are
 // staged global -> registers -> LDS with the next stage's loads in flight under the MFMAs.
 #include "common.h"
+#include "conv_halo.h"
 #include <stdlib.h>
 
 namespace {
@@ -42,6 +43,8 @@ struct ConvArgs {
   uint32_t drop_thresh, drop_key;   // thresh 0 = no dropout
   hipStream_t stream_ = nullptr;    // host only
   float* stats_ = nullptr;          // host only: BN partial-sum slab (affine forward)
+  void* ws_ = nullptr;              // host only: caller's scratch for the pre-split weight pack (may be null)
+  long ws_bytes_ = 0;
 };
 
 template <bool VEC>
@@ -905,6 +908,13 @@ int launch_affine_one(AffArgs& a) {
   return FS_OK;
 }
 
+// The halo-tiled 3x3 kernel (conv_halo.hip) runs when the split-precision mode is on, the shape qualifies and the
+// caller handed over enough scratch for the weight pack.
+bool use_halo(const ConvArgs& c) {
+  return g_conv_precision == 1 && c.ws_ != nullptr && fs_halo_eligible(c.Hd, c.Wd, c.Cs, c.Cd, c.R, c.S, c.stride, c.pad, c.dil) &&
+         c.Hs == c.Hd && c.Ws == c.Wd && c.ws_bytes_ >= fs_halo_pack_bytes(c.Cs, c.Cd);
+}
+
 int launch_affine(const ConvArgs& c, long M) {
   AffArgs a{c.src, c.w, c.bias, c.dst, c.B, c.Hs, c.Ws, c.Cs, c.Hd, c.Wd, c.Cd, c.R, c.S, c.stride, c.pad, c.dil, c.transposed,
             c.drop_scale, c.drop_thresh, c.drop_key,
@@ -912,6 +922,9 @@ int launch_affine(const ConvArgs& c, long M) {
             c.Hd, c.Wd, 1, 0, 0, 0, 0, 1, c.R, c.S, c.pad, c.pad, 0, 0, c.stats_};
   a_stream = c.stream_;
   (void)M;
+  if (use_halo(c))
+    return fs_halo_conv3x3(c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.B, c.Hd, c.Wd, c.Cs, c.Cd, c.transposed ? c.Cd : c.Cs,
+                           c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key, c.stream_);
   if (!c.transposed || c.stride == 1) return launch_affine_one(a);
   // stride>1 bwd-data: one dense sub-problem per output parity class (oy0, ox0).  dX pixel y receives
   // tap r iff (y + pad - r) % stride == 0, i.e. r = r0 + stride*t with r0 = (oy0 + pad) % stride, and then
@@ -946,15 +959,34 @@ int fs_set_conv_precision(int mode) {
 }
 int fs_get_conv_precision(void) { return g_conv_precision; }
 
+// include/fovealseg.h: fs_conv2d_workspace_bytes -- scratch the conv entry points can use for this shape (0 = none).
+// transposed = 0 for fs_conv2d_fwd / fs_conv2d_fwd_stats, 1 for fs_conv2d_bwd_data.
+long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, int transposed) {
+  if (g_conv_precision != 1 || H != Ho || W != Wo) return 0;
+  const int Cs = transposed ? Cout : Cin, Cd = transposed ? Cin : Cout;
+  if (!fs_halo_eligible(H, W, Cs, Cd, R, S, stride, pad, dil)) return 0;
+  return fs_halo_pack_bytes(Cs, Cd);
+}
+
+// include/fovealseg.h: fs_conv2d_stats_slabs -- number of [Cout][2] partial-sum slabs fs_conv2d_fwd_stats writes for
+// this shape when called with ws_bytes of scratch (depends on which kernel it selects).
+int fs_conv2d_stats_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                          long ws_bytes) {
+  const long need = fs_conv2d_workspace_bytes(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0);
+  if (need > 0 && ws_bytes >= need) return fs_halo_stats_slabs(B, Ho, Wo);
+  return cdiv((long)B * Ho * Wo, 128);
+}
+
 // include/fovealseg.h: fs_conv2d_fwd
 int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
                   int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key,
-                  hipStream_t stream) {
+                  void* ws, long ws_bytes, hipStream_t stream) {
   FS_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
   FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
   FS_REQUIRE(drop_p >= 0.f && drop_p < 1.f);
   ConvArgs a{x, w, bias, y, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0, 1.f, 0u, drop_key};
   a.stream_ = stream;
+  a.ws_ = ws; a.ws_bytes_ = ws_bytes;
   if (drop_p > 0.f) {
     a.drop_scale = 1.0f / (float)(1.0 - (double)drop_p);
     a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
@@ -976,7 +1008,7 @@ int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, i
 // stats = [ceil(B*Ho*Wo/128)][Cout][2] floats.  Requires Cin%4==0 && Cout%4==0 (the affine kernel).
 int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* stats, int B, int H, int W, int Cin,
                         int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key,
-                        hipStream_t stream) {
+                        void* ws, long ws_bytes, hipStream_t stream) {
   FS_REQUIRE(x && w && y && stats && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
   FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
   FS_REQUIRE(drop_p >= 0.f && drop_p < 1.f);
@@ -984,6 +1016,7 @@ int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float
   ConvArgs a{x, w, bias, y, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0, 1.f, 0u, drop_key};
   a.stream_ = stream;
   a.stats_ = stats;
+  a.ws_ = ws; a.ws_bytes_ = ws_bytes;
   if (drop_p > 0.f) {
     a.drop_scale = 1.0f / (float)(1.0 - (double)drop_p);
     a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
@@ -995,13 +1028,14 @@ int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float
 
 // include/fovealseg.h: fs_conv2d_bwd_data   (dX has the forward input's shape B,H,W,Cin)
 int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
-                       int Cout, int R, int S, int stride, int pad, int dil, hipStream_t stream) {
+                       int Cout, int R, int S, int stride, int pad, int dil, void* ws, long ws_bytes, hipStream_t stream) {
   FS_REQUIRE(dy && w && dx && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
   FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
   ConvArgs a{dy, w, nullptr, dx, B, Ho, Wo, Cout, H, W, Cin, R, S, stride, pad, dil, 1, 1.f, 0u, 0u};
   FS_REQUIRE(stride == 1 || dil == 1);
   const long M = (long)B * H * W;
   a.stream_ = stream;
+  a.ws_ = ws; a.ws_bytes_ = ws_bytes;
   if ((Cin % 4 == 0) && (Cout % 4 == 0) && R * S <= 32 && (long)B * Ho * Wo * Cout < 2147483647L)
     return launch_affine(a, M);
   dim3 grid(cdiv(M, BM), cdiv(Cin, BN));

@@ -1,0 +1,17 @@
+// Internal interface between conv.hip (C-ABI entry points, kernel selection) and conv_halo.hip
+// (halo-tiled split-precision 3x3 kernel + weight pack).  Not part of include/fovealseg.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// 3x3, stride 1, pad 1, dilation 1, channel counts multiples of 4, K >= 32
+bool fs_halo_eligible(int H, int W, int Cs, int Cd, int R, int S, int stride, int pad, int dil);
+// bytes of the pre-split weight pack for K = Cs source channels and N = Cd destination channels
+long fs_halo_pack_bytes(int Cs, int Cd);
+// number of pixel tiles (= BatchNorm partial-sum slabs) the halo kernel uses for a (B,H,W) output
+int fs_halo_stats_slabs(int B, int H, int W);
+// pack w (RSCK fp32, logical Cin x Cout) into ws, then run the conv.  transposed = 1: bwd-data (src = dY with
+// Cs = Cout channels, dst = dX with Cd = Cin channels).  stats may be null.
+int fs_halo_conv3x3(const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, int B, int H, int W,
+                    int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,
+                    hipStream_t stream);

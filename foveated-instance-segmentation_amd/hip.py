@@ -29,9 +29,9 @@ SIGNATURES = {
     "fs_grid_sample_bwd_grid": "ppppiiiiiii",
     "fs_grid_sample_bwd_input": "pppiiiiiii",
     "fs_inverse_index_maps": "ppplii",
-    "fs_conv2d_fwd": "ppppiiiiiiiiiiiifu",
-    "fs_conv2d_fwd_stats": "pppppiiiiiiiiiiiifu",
-    "fs_conv2d_bwd_data": "pppiiiiiiiiiiii",
+    "fs_conv2d_fwd": "ppppiiiiiiiiiiiifupl",
+    "fs_conv2d_fwd_stats": "pppppiiiiiiiiiiiifupl",
+    "fs_conv2d_bwd_data": "pppiiiiiiiiiiiipl",
     "fs_conv2d_bwd_weight": "pppiiiiiiiiiiii",
     "fs_bn_stats": "pliffppppp",
     "fs_bn_finalize_slab": "piliffpppp",
@@ -68,7 +68,8 @@ SIGNATURES = {
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 
 _lib = None
-HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision")   # declared in the header, no stream argument
+# declared in the header, host-side only (no stream argument)
+HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs")
 
 
 class HipLibraryError(RuntimeError):
@@ -93,6 +94,10 @@ def load():
     lib.fs_set_conv_precision.argtypes = [_I]
     lib.fs_get_conv_precision.restype = _I
     lib.fs_get_conv_precision.argtypes = []
+    lib.fs_conv2d_workspace_bytes.restype = _L
+    lib.fs_conv2d_workspace_bytes.argtypes = [_I] * 12
+    lib.fs_conv2d_stats_slabs.restype = _I
+    lib.fs_conv2d_stats_slabs.argtypes = [_I] * 12 + [_L]
     _lib = lib
     return lib
 
@@ -102,6 +107,27 @@ def set_conv_precision(mode: str) -> None:
     code = {"f32": 0, "bf16x3": 1}[mode]
     if load().fs_set_conv_precision(code) != 0:
         raise HipLibraryError("fs_set_conv_precision rejected the mode")
+    _ws_cache.clear()
+
+
+_ws_cache = {}
+
+
+def conv_workspace_bytes(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed):
+    """Scratch bytes the conv entry points can use for this shape under the current precision mode (cached)."""
+    key = (H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed)
+    v = _ws_cache.get(key)
+    if v is None:
+        v = _ws_cache[key] = int(load().fs_conv2d_workspace_bytes(*key))
+    return v
+
+
+def conv_stats_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes):
+    key = ("slabs", B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes)
+    v = _ws_cache.get(key)
+    if v is None:
+        v = _ws_cache[key] = int(load().fs_conv2d_stats_slabs(*key[1:]))
+    return v
 
 
 def get_conv_precision() -> str:

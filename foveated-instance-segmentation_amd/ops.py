@@ -69,14 +69,25 @@ class KernelTimer:
 
     def __init__(self):
         self.records = {}          # kind -> list of (start_event, stop_event, flops)
+        self.tags = {}             # kind -> list of (entry point, leading integer arguments) per record
 
-    def launch(self, kind, flops, fn):
+    def launch(self, kind, flops, fn, tag=None):
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
         self.records.setdefault(kind, []).append((s, e, flops))
+        self.tags.setdefault(kind, []).append(tag)
+
+    def by_shape(self):
+        """{(entry point, int args...): [launches, total_ms, flops]} over all recorded launches."""
+        out = {}
+        for kind, recs in self.records.items():
+            for (s, e, f), tag in zip(recs, self.tags[kind]):
+                d = out.setdefault(tag, [0, 0.0, 0.0])
+                d[0] += 1; d[1] += s.elapsed_time(e); d[2] += f
+        return out
 
     def summary(self):
         out = {}
@@ -94,7 +105,7 @@ def _launch(kind, flops, name, *args):
     if TIMER is None:
         hip.call(name, *args)
     else:
-        TIMER.launch(kind, flops, lambda: hip.call(name, *args))
+        TIMER.launch(kind, flops, lambda: hip.call(name, *args), tag=(name,) + tuple(a for a in args if type(a) is int and a < (1 << 20)))
 
 
 def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1):
@@ -104,9 +115,18 @@ def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1):
     Ho, Wo = _out_hw(H, W, R, S, stride, pad, dil)
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
     kind = "conv_affine" if (Cin % 4 == 0 and Cout % 4 == 0) else "conv_generic"      # mirrors csrc/conv.hip dispatch
+    ws, ws_bytes = _conv_workspace(x.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0)
     _launch(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd", hip.ptr(x), hip.ptr(rsck(w)), hip.ptr(bias),
-            hip.ptr(y), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, float(drop_p), int(drop_key))
+            hip.ptr(y), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, float(drop_p), int(drop_key), hip.ptr(ws), ws_bytes)
     return y
+
+
+def _conv_workspace(device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed):
+    """Scratch for the pre-split weight pack of the halo-tiled 3x3 kernel (None, 0 when the shape does not use it)."""
+    n = hip.conv_workspace_bytes(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed)
+    if n == 0:
+        return None, 0
+    return torch.empty(n, device=device, dtype=torch.uint8), n
 
 
 FUSE_BN_STATS = True     # BatchNorm batch statistics come out of the conv epilogue (fs_conv2d_fwd_stats)
@@ -119,10 +139,12 @@ def conv2d_fwd_stats(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1):
     assert Cin == Cin2, (x.shape, w.shape)
     Ho, Wo = _out_hw(H, W, R, S, stride, pad, dil)
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
-    nwg = (B * Ho * Wo + 127) // 128
+    ws, ws_bytes = _conv_workspace(x.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0)
+    nwg = hip.conv_stats_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes)
     slab = torch.empty(nwg * Cout * 2, device=x.device, dtype=torch.float32)
     _launch("conv_affine", 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd_stats", hip.ptr(x), hip.ptr(rsck(w)),
-            hip.ptr(bias), hip.ptr(y), hip.ptr(slab), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, float(drop_p), int(drop_key))
+            hip.ptr(bias), hip.ptr(y), hip.ptr(slab), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, float(drop_p), int(drop_key),
+            hip.ptr(ws), ws_bytes)
     return y, slab, nwg
 
 
@@ -132,8 +154,9 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1):
     _, Ho, Wo, _ = dy.shape
     dx = torch.empty(B, H, W, Cin, device=dy.device, dtype=torch.float32)
     kind = "conv_affine" if (Cin % 4 == 0 and Cout % 4 == 0) else "conv_generic"
+    ws, ws_bytes = _conv_workspace(dy.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 1)
     _launch(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx),
-            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)
+            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, hip.ptr(ws), ws_bytes)
     return dx
 
 

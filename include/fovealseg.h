@@ -66,19 +66,31 @@ int fs_inverse_index_maps(const float* grid, long long* u, long long* v, long n,
  * Default 1 (or FS_CONV_PRECISION=f32|bf16x3 in the environment).  Host-side switch, not a launch. */
 int fs_set_conv_precision(int mode);
 int fs_get_conv_precision(void);
+/* Scratch the forward (transposed=0) / bwd-data (transposed=1) entry points can use for this shape, in bytes
+ * (0 = none).  In split-precision mode 3x3 / stride 1 / pad 1 convolutions with >= 32 input channels run as a
+ * halo-tiled kernel that first packs the weights, already split into bf16 terms, into this scratch; without
+ * scratch (ws = NULL) they fall back to the kernel that splits weights in flight.  Host-side query, no launch. */
+long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                               int transposed);
+/* Number of [Cout][2] partial-sum slabs fs_conv2d_fwd_stats writes for this shape given ws_bytes of scratch. */
+int fs_conv2d_stats_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                          long ws_bytes);
 /* F.conv2d(x, w, bias, stride, pad, dilation=dil) [+ Dropout(drop_p) keyed by drop_key when drop_p > 0].
+ * ws / ws_bytes: caller-owned scratch (see fs_conv2d_workspace_bytes), may be NULL / 0.
  * models/hrnetv2_nodownsp.py:49-50,54-55 and every nn.Conv2d on the path. */
 int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Ho, int Wo,
-                  int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key, fs_stream_t stream);
+                  int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key, void* ws, long ws_bytes,
+                  fs_stream_t stream);
 /* Same forward conv, additionally writing per-workgroup BatchNorm partial sums of the stored output into
- * stats = [ceil(B*Ho*Wo/128)][Cout][2] floats (needs Cin%4==0 && Cout%4==0); finalise with fs_bn_finalize_slab.
- * Fuses the statistics pass of F.batch_norm(training=True) (lib/nn/modules/batchnorm.py:58-61) into the conv. */
+ * stats = [fs_conv2d_stats_slabs(...)][Cout][2] floats (needs Cin%4==0 && Cout%4==0); finalise with
+ * fs_bn_finalize_slab.  Fuses the statistics pass of F.batch_norm(training=True)
+ * (lib/nn/modules/batchnorm.py:58-61) into the conv. */
 int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* stats, int B, int H, int W, int Cin,
                         int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key,
-                        fs_stream_t stream);
+                        void* ws, long ws_bytes, fs_stream_t stream);
 /* convolution_backward: input gradient / weight gradient (dw overwritten). */
 int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R,
-                       int S, int stride, int pad, int dil, fs_stream_t stream);
+                       int S, int stride, int pad, int dil, void* ws, long ws_bytes, fs_stream_t stream);
 int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
                          int R, int S, int stride, int pad, int dil, fs_stream_t stream);
 
