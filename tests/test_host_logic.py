@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _header_symbols():
     src = open(os.path.join(ROOT, "include", "fovealseg.h")).read()
-    return sorted(set(re.findall(r"\bint\s+(fs_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|long)\s+(fs_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
