@@ -915,6 +915,38 @@ bool use_halo(const ConvArgs& c) {
          c.Hs == c.Hd && c.Ws == c.Wd && c.ws_bytes_ >= fs_halo_pack_bytes(c.Cs, c.Cd);
 }
 
+// Everything else that is channel-aligned, undilated and has scratch goes to the tap-class kernel (conv_tapset.hip).
+static const bool g_tapset_all = [] { const char* e = getenv("FS_TAPSET_ALL"); return e && e[0] == '1'; }();
+bool tapset_shape_ok(int Cs, int Cd, int R, int S, int stride, int dil) {
+  const int cr = stride < R ? stride : R, cs = stride < S ? stride : S;
+  // 1x1 filters have no tap reuse: measured slower than conv_igemm_x3_kernel (43 vs 55 TF on 64->256 @ 80x80), not routed here
+  return dil == 1 && R * S > 1 && Cs % 4 == 0 && Cd % 4 == 0 && Cs >= 16 && cr * cs <= 9 &&
+         ((R + stride - 1) / stride) * ((S + stride - 1) / stride) <= 64;
+}
+bool use_tapset(const ConvArgs& c) {
+  return g_conv_precision == 1 && c.ws_ != nullptr && tapset_shape_ok(c.Cs, c.Cd, c.R, c.S, c.stride, c.dil) &&
+         c.ws_bytes_ >= fs_tapset_pack_bytes(c.Cs, c.Cd, c.R * c.S);
+}
+FsTapsetProblem tapset_base(const ConvArgs& c) {
+  FsTapsetProblem p{};
+  p.src = c.src; p.w = c.w; p.bias = c.bias; p.dst = c.dst; p.stats = c.stats_; p.ws = c.ws_;
+  p.B = c.B; p.Hs = c.Hs; p.Ws = c.Ws; p.Cs = c.Cs; p.Hd = c.Hd; p.Wd = c.Wd; p.Cd = c.Cd;
+  p.Cin = c.transposed ? c.Cd : c.Cs; p.Cout = c.transposed ? c.Cs : c.Cd; p.S = c.S;
+  p.transposed = c.transposed;
+  p.drop_scale = c.drop_scale; p.drop_thresh = c.drop_thresh; p.drop_key = c.drop_key;
+  return p;
+}
+int launch_tapset_forward(const ConvArgs& c) {
+  FsTapsetProblem p = tapset_base(c);
+  p.Hq = c.Hd; p.Wq = c.Wd; p.os = 1; p.oy0 = 0; p.ox0 = 0; p.sm = c.stride;
+  const int st = c.stride;
+  p.ncls = 0;
+  for (int r0 = 0; r0 < st && r0 < c.R; ++r0)
+    for (int s0 = 0; s0 < st && s0 < c.S; ++s0)
+      p.cls[p.ncls++] = FsTapClass{r0 - c.pad, s0 - c.pad, (c.R - r0 + st - 1) / st, (c.S - s0 + st - 1) / st, r0, st, s0, st};
+  return fs_tapset_conv(p, c.stream_);
+}
+
 int launch_affine(const ConvArgs& c, long M) {
   AffArgs a{c.src, c.w, c.bias, c.dst, c.B, c.Hs, c.Ws, c.Cs, c.Hd, c.Wd, c.Cd, c.R, c.S, c.stride, c.pad, c.dil, c.transposed,
             c.drop_scale, c.drop_thresh, c.drop_key,
@@ -922,6 +954,14 @@ int launch_affine(const ConvArgs& c, long M) {
             c.Hd, c.Wd, 1, 0, 0, 0, 0, 1, c.R, c.S, c.pad, c.pad, 0, 0, c.stats_};
   a_stream = c.stream_;
   (void)M;
+  if (!c.transposed && use_tapset(c) && (g_tapset_all || !use_halo(c))) return launch_tapset_forward(c);
+  if (c.transposed && c.stride == 1 && use_tapset(c) && (g_tapset_all || !use_halo(c))) {
+    FsTapsetProblem p = tapset_base(c);
+    p.Hq = c.Hd; p.Wq = c.Wd; p.os = 1; p.oy0 = 0; p.ox0 = 0; p.sm = 1;
+    p.ncls = 1;
+    p.cls[0] = FsTapClass{c.pad - (c.R - 1), c.pad - (c.S - 1), c.R, c.S, c.R - 1, -1, c.S - 1, -1};
+    return fs_tapset_conv(p, c.stream_);
+  }
   if (use_halo(c))
     return fs_halo_conv3x3(c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.B, c.Hd, c.Wd, c.Cs, c.Cd, c.transposed ? c.Cd : c.Cs,
                            c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key, c.stream_);
@@ -941,6 +981,16 @@ int launch_affine(const ConvArgs& c, long M) {
       if (b.nR == 0 || b.nS == 0) { b.nR = 0; b.nS = 0; }       // no tap reaches this class: writes zeros
       b.cy = (oy0 + c.pad - b.r0) / st; b.cx = (ox0 + c.pad - b.s0) / st;
       if (b.Hq <= 0 || b.Wq <= 0) continue;
+      if (b.nR * b.nS > 1 && use_tapset(c)) {       // single-tap sub-problems: no reuse, the plain kernel is faster
+        // dY row of tap t is py + cy - t: in increasing source order tr = nR-1-t, filter row r0 + st*(nR-1-tr)
+        FsTapsetProblem p = tapset_base(c);
+        p.Hq = b.Hq; p.Wq = b.Wq; p.os = st; p.oy0 = oy0; p.ox0 = ox0; p.sm = 1;
+        p.ncls = 1;
+        p.cls[0] = FsTapClass{b.cy - (b.nR - 1), b.cx - (b.nS - 1), b.nR, b.nS, b.r0 + st * (b.nR - 1), -st, b.s0 + st * (b.nS - 1), -st};
+        int e2 = fs_tapset_conv(p, c.stream_);
+        if (e2 != FS_OK) return e2;
+        continue;
+      }
       int e = launch_affine_one(b);
       if (e != FS_OK) return e;
     }
@@ -962,10 +1012,15 @@ int fs_get_conv_precision(void) { return g_conv_precision; }
 // include/fovealseg.h: fs_conv2d_workspace_bytes -- scratch the conv entry points can use for this shape (0 = none).
 // transposed = 0 for fs_conv2d_fwd / fs_conv2d_fwd_stats, 1 for fs_conv2d_bwd_data.
 long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, int transposed) {
-  if (g_conv_precision != 1 || H != Ho || W != Wo) return 0;
+  if (g_conv_precision != 1) return 0;
   const int Cs = transposed ? Cout : Cin, Cd = transposed ? Cin : Cout;
-  if (!fs_halo_eligible(H, W, Cs, Cd, R, S, stride, pad, dil)) return 0;
-  return fs_halo_pack_bytes(Cs, Cd);
+  long need = 0;
+  if (H == Ho && W == Wo && fs_halo_eligible(H, W, Cs, Cd, R, S, stride, pad, dil)) need = fs_halo_pack_bytes(Cs, Cd);
+  if (tapset_shape_ok(Cs, Cd, R, S, stride, dil)) {
+    const long t = fs_tapset_pack_bytes(Cs, Cd, R * S);
+    if (t > need) need = t;
+  }
+  return need;
 }
 
 // include/fovealseg.h: fs_conv2d_stats_slabs -- number of [Cout][2] partial-sum slabs fs_conv2d_fwd_stats writes for
@@ -973,7 +1028,12 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
 int fs_conv2d_stats_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                           long ws_bytes) {
   const long need = fs_conv2d_workspace_bytes(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0);
-  if (need > 0 && ws_bytes >= need) return fs_halo_stats_slabs(B, Ho, Wo);
+  if (need > 0 && ws_bytes >= need) {
+    const bool halo = H == Ho && W == Wo && fs_halo_eligible(H, W, Cin, Cout, R, S, stride, pad, dil);
+    if (halo && !g_tapset_all) return fs_halo_stats_slabs(B, Ho, Wo);
+    if (tapset_shape_ok(Cin, Cout, R, S, stride, dil)) return fs_tapset_slabs(B, Ho, Wo, (R + stride - 1) / stride, (S + stride - 1) / stride);
+    if (halo) return fs_halo_stats_slabs(B, Ho, Wo);
+  }
   return cdiv((long)B * Ho * Wo, 128);
 }
 

@@ -19,3 +19,19 @@ int fs_halo_conv3x3(const float* src, const float* w, const float* bias, float* 
 // conv_wgrad_x3.hip: split-precision weight gradient of a 3x3 / stride-1 / pad-1 convolution (dw must be zeroed).
 bool fs_wgrad_x3_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil);
 int fs_wgrad_x3(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t stream);
+
+// conv_tapset.hip: general halo-tiled split-precision convolution over a list of tap classes.
+//   source row of (loop row oy, class tap tr) = sm*(oy + tr) + cy,  filter row r = rbase + rstep*tr  (columns alike)
+struct FsTapClass { int cy, cx, nR, nS, rbase, rstep, sbase, sstep; };
+struct FsTapsetProblem {
+  const float* src; const float* w; const float* bias; float* dst; float* stats; void* ws;
+  int B, Hs, Ws, Cs, Hd, Wd, Cd;     // source / destination tensors (NHWC)
+  int Cin, Cout, S;                  // logical weight shape [R][S][Cin][Cout]
+  int transposed;                    // 0: K = Cin, N = Cout;  1 (bwd-data): K = Cout, N = Cin
+  int Hq, Wq, os, oy0, ox0, sm;      // loop grid; destination pixel = (oy*os + oy0, ox*os + ox0)
+  int ncls; FsTapClass cls[9];
+  float drop_scale; uint32_t drop_thresh, drop_key;
+};
+long fs_tapset_pack_bytes(int Cs, int Cd, int total_taps);
+int fs_tapset_slabs(int B, int Hq, int Wq, int maxR, int maxS);
+int fs_tapset_conv(const FsTapsetProblem& p, hipStream_t stream);

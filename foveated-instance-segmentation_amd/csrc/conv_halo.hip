@@ -21,6 +21,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int XLD = 40;            // bf16 per LDS slot (80 bytes)
 constexpr int NSMAX = 224;         // halo slots per plane (7 x 32: every thread stores exactly NITEM quads)
@@ -37,6 +38,14 @@ __device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c)
   const float r = x - (float)a;
   b = (__bf16)r;
   c = (__bf16)(r - (float)b);
+}
+
+// ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (per 32-lane half).  Map the
+// 32 rows of an MFMA tile to patch pixels so that each group reads 16 CONSECUTIVE pixels (conflict-free 80-B rows).
+__device__ __forceinline__ int row_perm(int l) {
+  const bool g1 = (l >= 4 && l < 12) || (l >= 16 && l < 20) || l >= 28;
+  if (!g1) return l < 4 ? l : (l < 16 ? l - 8 : l - 12);
+  return 16 + (l < 12 ? l - 4 : (l < 20 ? l - 8 : l - 16));
 }
 
 struct HaloArgs {
@@ -83,6 +92,7 @@ __global__ __launch_bounds__(256) void conv_pack_x3_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(HaloArgs a) {
   __shared__ __attribute__((aligned(16))) __bf16 Ah[3 * PLANE];
+  __shared__ __attribute__((aligned(16))) int rowpix[128];      // output pixel of every tile row (MFMA row order), -1 = dead
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -101,17 +111,25 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(HaloArgs a) {
   const int y0 = ty * a.Ph, x0 = tx * a.Pw;
   const int Wh = a.Pw + 2, nslots = (a.Ph + 2) * Wh;
 
-  // ---- halo loader: item = tid + 256*i -> (slot = item>>3, channel quad q = item&7) ----
+  if (tid < 128) {
+    const int p = (tid & ~31) + row_perm(tid & 31);
+    const int py = p / a.Pw, px = p - py * a.Pw;
+    const bool live = p < a.Ph * a.Pw && y0 + py < a.H && x0 + px < a.W;
+    rowpix[tid] = live ? ((b * a.H + y0 + py) * a.W + x0 + px) : -1;
+  }
+  // ---- halo loader: item = tid + 256*i -> (slot = item>>3, channel quad q = item&7); slots advance by 32 per item ----
   const int q = tid & 7;
   int goff[NITEM];
+  {
+    const int q32 = 32 / Wh, r32 = 32 - q32 * Wh;
+    int hy = (tid >> 3) / Wh, hx = (tid >> 3) - hy * Wh;
 #pragma unroll
-  for (int i = 0; i < NITEM; ++i) {
-    const int slot = (tid >> 3) + 32 * i;
-    goff[i] = -1;
-    if (slot < nslots) {
-      const int hy = slot / Wh, hx = slot - hy * Wh;
+    for (int i = 0; i < NITEM; ++i) {
       const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) goff[i] = ((b * a.H + iy) * a.W + ix) * a.Cs + 4 * q;
+      const bool ok = (tid >> 3) + 32 * i < nslots && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      goff[i] = ok ? ((b * a.H + iy) * a.W + ix) * a.Cs + 4 * q : -1;
+      hx += r32; hy += q32;
+      if (hx >= Wh) { hx -= Wh; ++hy; }
     }
   }
   const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(a.src, a.src_bytes);
@@ -142,13 +160,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(HaloArgs a) {
     }
   };
 
-  // ---- A fragment rows: wave rows m = 64*wm + 32*mi + l31 -> patch pixel (py, px); top-left halo slot = (py, px) ----
+  // ---- A fragment rows: tile row 64*wm + 32*mi + l31 -> patch pixel p = 64*wm + 32*mi + row_perm(l31); top-left halo slot = (py, px) ----
   int rowbase[2][3];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
-    const int m = 64 * wm + 32 * mi + l31;
-    const bool live = m < a.Ph * a.Pw;
-    const int py = live ? m / a.Pw : 0, px = live ? m - py * a.Pw : 0;
+    const int p = 64 * wm + 32 * mi + row_perm(l31);
+    const bool live = p < a.Ph * a.Pw;
+    const int py = live ? p / a.Pw : 0, px = live ? p - py * a.Pw : 0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) rowbase[mi][r] = ((py + r) * Wh + px) * XLD + 8 * lh;
   }
@@ -175,10 +193,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(HaloArgs a) {
   load_halo(0);
   int g = 0;
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+#ifdef FS_EXP_NO_REFILL
+    if (chunk == 0) {
+#endif
     __syncthreads();
     store_halo();
     __syncthreads();
     if (chunk + 1 < a.nchunk) load_halo(chunk + 1);
+#ifdef FS_EXP_NO_REFILL
+    }
+#endif
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -193,7 +217,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(HaloArgs a) {
           for (int pl = 0; pl < 3; ++pl)
             fa[(step + 1) & 1][mi][pl] = *reinterpret_cast<const bf16x8*>(&Ah[pl * PLANE + rowbase[mi][r] + s * XLD + 16 * s2]);
       }
+#ifndef FS_EXP_NO_B
       load_b(g + 2, fb[(step + 2) % 3]);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8(&A)[2][3] = fa[step & 1];
       const bf16x8(&Bf)[3] = fb[step % 3];
@@ -216,6 +242,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(HaloArgs a) {
   }
 
   // ---- epilogue: bias, dropout, store, optional BatchNorm partial sums ----
+  __syncthreads();      // rowpix visible; every wave is done with the halo image
   const int n = n0 + 32 * wn + l31;
   float csum = 0.f, csq = 0.f;
   if (n < a.Cd) {
@@ -223,23 +250,23 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(HaloArgs a) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = 64 * wm + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= a.Ph * a.Pw) continue;
-        const int py = m / a.Pw, px = m - py * a.Pw;
-        const int y = y0 + py, x = x0 + px;
-        if (y >= a.H || x >= a.W) continue;
-        float v = (mi == 0 ? acc0[r] : acc1[r]) + bv;
-        const long e = (((long)b * a.H + y) * a.W + x) * a.Cd + n;
-        if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-        a.dst[e] = v;
-        csum += v; csq += v * v;
+      for (int rg = 0; rg < 4; ++rg) {
+        const i32x4 pix = *reinterpret_cast<const i32x4*>(&rowpix[64 * wm + 32 * mi + 8 * rg + 4 * lh]);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+          if (pix[ri] < 0) continue;
+          const int r = 4 * rg + ri;
+          float v = (mi == 0 ? acc0[r] : acc1[r]) + bv;
+          const long e = (long)pix[ri] * a.Cd + n;
+          if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+          a.dst[e] = v;
+          csum += v; csq += v * v;
+        }
       }
     }
   }
   if (a.stats != nullptr) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(&Ah[0]);     // [wm][64 cols][2]
+    float* red = reinterpret_cast<float*>(&Ah[0]);     // [wm][64 cols][2]; the halo image is dead since the barrier above
     const float s1 = csum + __shfl_xor(csum, 32, 64), s2 = csq + __shfl_xor(csq, 32, 64);
     if (lh == 0) { red[(wm * 64 + 32 * wn + l31) * 2] = s1; red[(wm * 64 + 32 * wn + l31) * 2 + 1] = s2; }
     __syncthreads();

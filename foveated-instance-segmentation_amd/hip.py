@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfovealseg_hip.so")
+LIB_PATH = os.environ.get("FS_HIP_LIB") or os.path.join(_HERE, "csrc", "libfovealseg_hip.so")   # FS_HIP_LIB: kernel experiments
 
 _P, _I, _L, _F, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint32
 
