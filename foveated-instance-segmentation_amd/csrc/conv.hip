@@ -245,7 +245,8 @@ static thread_local hipStream_t a_stream = nullptr;   // host: stream of the lau
 // Default from FS_CONV_PRECISION=f32|bf16x3 (bf16x3 when unset); fs_set_conv_precision() overrides.
 static int g_conv_precision = [] {
   const char* e = getenv("FS_CONV_PRECISION");
-  return (e && e[0] == 'f') ? 0 : 1;
+  if (e && e[0] == 'f' && e[1] == '1') return 2;      // f16x2
+  return (e && e[0] == 'f') ? 0 : 1;                   // f32 | bf16x3
 }();
 
 template <int MT>
@@ -900,7 +901,7 @@ int launch_affine_one(AffArgs& a) {
   a.nx = cdiv(M, 128);
   a.ny = cdiv(a.Cd, BN);
   // MT=2 (256-row tiles) needs 84 KB of LDS = one workgroup per CU and measured 20-25 % slower.
-  if (g_conv_precision == 1)
+  if (g_conv_precision >= 1)
     hipLaunchKernelGGL(conv_igemm_x3_kernel, dim3(a.nx * a.ny), dim3(256), 0, a_stream, a);
   else
     hipLaunchKernelGGL(conv_igemm_affine_kernel<1>, dim3(a.nx * a.ny), dim3(256), 0, a_stream, a);
@@ -910,9 +911,10 @@ int launch_affine_one(AffArgs& a) {
 
 // The halo-tiled 3x3 kernel (conv_halo.hip) runs when the split-precision mode is on, the shape qualifies and the
 // caller handed over enough scratch for the weight pack.
+long halo_pack_bytes(int Cs, int Cd) { return g_conv_precision == 2 ? fs_halo_f16_pack_bytes(Cs, Cd) : fs_halo_pack_bytes(Cs, Cd); }
 bool use_halo(const ConvArgs& c) {
-  return g_conv_precision == 1 && c.ws_ != nullptr && fs_halo_eligible(c.Hd, c.Wd, c.Cs, c.Cd, c.R, c.S, c.stride, c.pad, c.dil) &&
-         c.Hs == c.Hd && c.Ws == c.Wd && c.ws_bytes_ >= fs_halo_pack_bytes(c.Cs, c.Cd);
+  return g_conv_precision >= 1 && c.ws_ != nullptr && fs_halo_eligible(c.Hd, c.Wd, c.Cs, c.Cd, c.R, c.S, c.stride, c.pad, c.dil) &&
+         c.Hs == c.Hd && c.Ws == c.Wd && c.ws_bytes_ >= halo_pack_bytes(c.Cs, c.Cd);
 }
 
 // Everything else that is channel-aligned, undilated and has scratch goes to the tap-class kernel (conv_tapset.hip).
@@ -924,7 +926,7 @@ bool tapset_shape_ok(int Cs, int Cd, int R, int S, int stride, int dil) {
          ((R + stride - 1) / stride) * ((S + stride - 1) / stride) <= 64;
 }
 bool use_tapset(const ConvArgs& c) {
-  return g_conv_precision == 1 && c.ws_ != nullptr && tapset_shape_ok(c.Cs, c.Cd, c.R, c.S, c.stride, c.dil) &&
+  return g_conv_precision >= 1 && c.ws_ != nullptr && tapset_shape_ok(c.Cs, c.Cd, c.R, c.S, c.stride, c.dil) &&
          c.ws_bytes_ >= fs_tapset_pack_bytes(c.Cs, c.Cd, c.R * c.S);
 }
 FsTapsetProblem tapset_base(const ConvArgs& c) {
@@ -962,6 +964,9 @@ int launch_affine(const ConvArgs& c, long M) {
     p.cls[0] = FsTapClass{c.pad - (c.R - 1), c.pad - (c.S - 1), c.R, c.S, c.R - 1, -1, c.S - 1, -1};
     return fs_tapset_conv(p, c.stream_);
   }
+  if (use_halo(c) && g_conv_precision == 2)
+    return fs_halo_f16_conv3x3(c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.B, c.Hd, c.Wd, c.Cs, c.Cd, c.transposed ? c.Cd : c.Cs,
+                               c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key, c.stream_);
   if (use_halo(c))
     return fs_halo_conv3x3(c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.B, c.Hd, c.Wd, c.Cs, c.Cd, c.transposed ? c.Cd : c.Cs,
                            c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key, c.stream_);
@@ -1003,7 +1008,7 @@ extern "C" {
 
 // include/fovealseg.h: fs_set_conv_precision / fs_get_conv_precision (host-side switch, no launch)
 int fs_set_conv_precision(int mode) {
-  FS_REQUIRE(mode == 0 || mode == 1);
+  FS_REQUIRE(mode >= 0 && mode <= 2);
   g_conv_precision = mode;
   return FS_OK;
 }
@@ -1012,10 +1017,10 @@ int fs_get_conv_precision(void) { return g_conv_precision; }
 // include/fovealseg.h: fs_conv2d_workspace_bytes -- scratch the conv entry points can use for this shape (0 = none).
 // transposed = 0 for fs_conv2d_fwd / fs_conv2d_fwd_stats, 1 for fs_conv2d_bwd_data.
 long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, int transposed) {
-  if (g_conv_precision != 1) return 0;
+  if (g_conv_precision < 1) return 0;
   const int Cs = transposed ? Cout : Cin, Cd = transposed ? Cin : Cout;
   long need = 0;
-  if (H == Ho && W == Wo && fs_halo_eligible(H, W, Cs, Cd, R, S, stride, pad, dil)) need = fs_halo_pack_bytes(Cs, Cd);
+  if (H == Ho && W == Wo && fs_halo_eligible(H, W, Cs, Cd, R, S, stride, pad, dil)) need = halo_pack_bytes(Cs, Cd);
   if (tapset_shape_ok(Cs, Cd, R, S, stride, dil)) {
     const long t = fs_tapset_pack_bytes(Cs, Cd, R * S);
     if (t > need) need = t;
@@ -1115,7 +1120,7 @@ int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
   hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)R * S * Cin * Cout, stream);
   if (e != hipSuccess) return (int)e;
   const long P = (long)B * Ho * Wo;
-  if (g_conv_precision == 1 && H == Ho && W == Wo && fs_wgrad_x3_eligible(Cin, Cout, R, S, stride, pad, dil) &&
+  if (g_conv_precision >= 1 && H == Ho && W == Wo && fs_wgrad_x3_eligible(Cin, Cout, R, S, stride, pad, dil) &&
       (size_t)B * H * W * Cin * 4 < 4294967000UL && (size_t)P * Cout * 4 < 4294967000UL)
     return fs_wgrad_x3(x, dy, dw, B, H, W, Cin, Cout, stream);
   const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);

@@ -16,6 +16,14 @@ int fs_halo_conv3x3(const float* src, const float* w, const float* bias, float* 
                     int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,
                     hipStream_t stream);
 
+// patch (Ph x Pw output pixels per workgroup) the halo kernels use for an H x W image
+void fs_halo_patch(int H, int W, int* Ph, int* Pw);
+// conv_halo_f16.hip: the same convolution in f16x2 split precision (3 fp16 MFMAs per product, scaled operands)
+long fs_halo_f16_pack_bytes(int Cs, int Cd);
+int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, int B, int H, int W,
+                        int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,
+                        hipStream_t stream);
+
 // conv_wgrad_x3.hip: split-precision weight gradient of a 3x3 / stride-1 / pad-1 convolution (dw must be zeroed).
 bool fs_wgrad_x3_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil);
 int fs_wgrad_x3(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t stream);

@@ -193,16 +193,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(HaloArgs a) {
   load_halo(0);
   int g = 0;
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-#ifdef FS_EXP_NO_REFILL
-    if (chunk == 0) {
-#endif
     __syncthreads();
     store_halo();
     __syncthreads();
     if (chunk + 1 < a.nchunk) load_halo(chunk + 1);
-#ifdef FS_EXP_NO_REFILL
-    }
-#endif
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -217,9 +211,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(HaloArgs a) {
           for (int pl = 0; pl < 3; ++pl)
             fa[(step + 1) & 1][mi][pl] = *reinterpret_cast<const bf16x8*>(&Ah[pl * PLANE + rowbase[mi][r] + s * XLD + 16 * s2]);
       }
-#ifndef FS_EXP_NO_B
       load_b(g + 2, fb[(step + 2) % 3]);
-#endif
       __builtin_amdgcn_sched_barrier(0);
       const bf16x8(&A)[2][3] = fa[step & 1];
       const bf16x8(&Bf)[3] = fb[step % 3];
@@ -294,6 +286,8 @@ void choose_patch(int H, int W, int& Ph, int& Pw) {
 }
 
 }  // namespace
+
+void fs_halo_patch(int H, int W, int* Ph, int* Pw) { choose_patch(H, W, *Ph, *Pw); }
 
 bool fs_halo_eligible(int H, int W, int Cs, int Cd, int R, int S, int stride, int pad, int dil) {
   (void)H; (void)W;

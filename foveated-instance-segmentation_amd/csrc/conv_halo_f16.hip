@@ -1,0 +1,328 @@
+// 3x3 / stride-1 / pad-1 convolution (forward and bwd-data), halo-tiled like conv_halo.hip, in the "f16x2" split
+// precision: every fp32 operand is scaled by a power of two and split into two fp16 terms x*s = h1 + h2
+// (22 significant bits), and each product is THREE v_mfma_f32_32x32x16_f16 (h1 g2 + h2 g1 + h1 g1, fp32 accumulate;
+// the dropped h2 g2 is <= 2^-22 relative).  Half the MFMA work of bf16x3 at an error that stays below the rounding
+// error of an fp32 accumulation chain of the same length (tools/conv_accuracy.py; DESIGN.md "precision modes").
+//
+// Range: fp16 has 5 exponent bits, so the scale is chosen where the data is seen.
+//   * activations: per (workgroup, 32-channel chunk) -- the workgroup takes the max |x| of the halo tile it has
+//     just loaded (register max -> wave max -> LDS atomic max, read back behind the barrier that already separates
+//     the MFMA phase from the LDS refill) and keeps a running exponent E = max over chunks; operands are scaled by
+//     2^(14-E) (largest element in [2^14, 2^15), never overflows), and when a new chunk raises E the fp32
+//     accumulators are rescaled by the exact power of two.  A chunk much smaller than an earlier one is therefore
+//     resolved relative to the accumulated magnitude -- which is what an fp32 chain does as well.
+//   * weights: one exponent per weight tensor, from an atomic-max pre-pass (conv_f16_amax_kernel) stored in the
+//     pack header; the pack kernel writes both fp16 planes already scaled, in MFMA B-fragment order.
+// The final result is acc * 2^(E-14) * 2^(Ew-14), applied in the epilogue.
+#include "common.h"
+#include "conv_halo.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XLD = 40;            // fp16 per LDS slot (80 bytes)
+constexpr int NSMAX = 224;
+constexpr int NITEM = 7;
+constexpr int PLANE = NSMAX * XLD;
+constexpr unsigned OOB = 0xFFFFFFF0u;
+constexpr int HDR = 256;           // bytes of pack header (amax bits at offset 0)
+constexpr int EMIN = -100;         // exponent floor (all-zero tiles)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }   // -126 <= e <= 127
+__device__ __forceinline__ int exponent_of_bits(unsigned bits) {
+  const int e = (int)((bits >> 23) & 0xffu) - 127;
+  return e < EMIN ? EMIN : e;
+}
+__device__ __forceinline__ void split2(float xs, _Float16& a, _Float16& b) {
+  a = (_Float16)xs;
+  b = (_Float16)(xs - (float)a);
+}
+__device__ __forceinline__ int row_perm(int l) {       // see conv_halo.hip
+  const bool g1 = (l >= 4 && l < 12) || (l >= 16 && l < 20) || l >= 28;
+  if (!g1) return l < 4 ? l : (l < 16 ? l - 8 : l - 12);
+  return 16 + (l < 12 ? l - 4 : (l < 20 ? l - 8 : l - 16));
+}
+
+struct HaloF16Args {
+  const float* src; const unsigned char* ws; const float* bias; float* dst; float* stats;
+  int B, H, W, Cs, Cd, Npad, nchunk;
+  int Ph, Pw, tiles_y, tiles_x;
+  int nx, ny;
+  unsigned src_bytes, ws_bytes;
+  float drop_scale; uint32_t drop_thresh, drop_key;
+};
+
+// max |w| over the weight tensor as float bits (non-negative floats order like unsigned ints)
+__global__ __launch_bounds__(256) void conv_f16_amax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+
+// Wp[g = (chunk*9 + tap)*2 + s][plane][n][j] (fp16, scaled by 2^(14-Ew)); layout as conv_pack_x3_kernel with 2 planes.
+__global__ __launch_bounds__(256) void conv_pack_f16_kernel(const float* __restrict__ w, unsigned char* __restrict__ ws, int Cin, int Cout,
+                                                            int transposed, int Ks, int Ns, int Npad, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const float sc = pow2f(14 - exponent_of_bits(*reinterpret_cast<const unsigned*>(ws)));
+  _Float16* wp = reinterpret_cast<_Float16*>(ws + HDR);
+  const int n = (int)(idx % Npad);
+  const int g = (int)(idx / Npad);
+  const int s = g & 1, tap = (g >> 1) % 9, chunk = g / 18;
+  const int k0 = chunk * 32 + s * 16;
+  f16x8 p[2][2];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = k0 + j;
+    float v = 0.f;
+    if (n < Ns && k < Ks) v = transposed ? w[((long)(8 - tap) * Cin + n) * Cout + k] : w[((long)tap * Cin + k) * Cout + n];
+    _Float16 a, b;
+    split2(v * sc, a, b);
+    p[0][j >> 3][j & 7] = a; p[1][j >> 3][j & 7] = b;
+  }
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+    f16x8* o = reinterpret_cast<f16x8*>(wp + (((long)g * 2 + pl) * Npad + n) * 16);
+    o[0] = p[pl][0]; o[1] = p[pl][1];
+  }
+}
+
+__global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a) {
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[2 * PLANE];
+  __shared__ __attribute__((aligned(16))) int rowpix[128];
+  __shared__ unsigned amax_cell[2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nwg = a.nx * a.ny;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd = nwg >> 3, rm = nwg & 7;
+  const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+  const int mt = wg / a.ny;
+  const int n0 = (wg - mt * a.ny) * 64;
+  const int tpi = a.tiles_y * a.tiles_x;
+  const int b = mt / tpi;
+  const int trem = mt - b * tpi;
+  const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+  const int y0 = ty * a.Ph, x0 = tx * a.Pw;
+  const int Wh = a.Pw + 2, nslots = (a.Ph + 2) * Wh;
+
+  if (tid < 128) {
+    const int p = (tid & ~31) + row_perm(tid & 31);
+    const int py = p / a.Pw, px = p - py * a.Pw;
+    const bool live = p < a.Ph * a.Pw && y0 + py < a.H && x0 + px < a.W;
+    rowpix[tid] = live ? ((b * a.H + y0 + py) * a.W + x0 + px) : -1;
+  }
+  if (tid < 2) amax_cell[tid] = 0u;
+  const int q = tid & 7;
+  int goff[NITEM];
+  {
+    const int q32 = 32 / Wh, r32 = 32 - q32 * Wh;
+    int hy = (tid >> 3) / Wh, hx = (tid >> 3) - hy * Wh;
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      const bool ok = (tid >> 3) + 32 * i < nslots && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      goff[i] = ok ? ((b * a.H + iy) * a.W + ix) * a.Cs + 4 * q : -1;
+      hx += r32; hy += q32;
+      if (hx >= Wh) { hx -= Wh; ++hy; }
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(a.src, a.src_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.ws, a.ws_bytes);
+
+  f32x4 ra[NITEM];
+  auto load_halo = [&](int chunk) {
+    const int c0 = chunk * 32;
+    const bool cok = c0 + 4 * q < a.Cs;
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+      const bool ok = cok && goff[i] >= 0;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? (int)((unsigned)(goff[i] + c0) * 4u) : (int)OOB, 0, 0);
+      ra[i] = __builtin_bit_cast(f32x4, v);
+    }
+  };
+  auto tile_amax = [&](int cell) {       // max |x| of the loaded halo registers -> LDS cell
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(ra[i][e]));
+    m = wave_max(m);
+    if (lane == 0) atomicMax(&amax_cell[cell], __builtin_bit_cast(unsigned, m));
+  };
+  auto store_halo = [&](float sc) {
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+      const int slot = (tid >> 3) + 32 * i;
+      f16x4 p0, p1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { _Float16 x, y; split2(ra[i][e] * sc, x, y); p0[e] = x; p1[e] = y; }
+      const int o = slot * XLD + 4 * q;
+      *reinterpret_cast<f16x4*>(&Ah[o]) = p0;
+      *reinterpret_cast<f16x4*>(&Ah[PLANE + o]) = p1;
+    }
+  };
+
+  int rowbase[2][3];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int p = 64 * wm + 32 * mi + row_perm(l31);
+    const bool live = p < a.Ph * a.Pw;
+    const int py = live ? p / a.Pw : 0, px = live ? p - py * a.Pw : 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) rowbase[mi][r] = ((py + r) * Wh + px) * XLD + 8 * lh;
+  }
+  const int bvoff = HDR + ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2;
+  const int plane_bytes = a.Npad * 32;
+  const int step_bytes = 2 * plane_bytes;
+  const int G = a.nchunk * 18;
+
+  f16x8 fa[2][2][2];   // [buffer][mi][plane]
+  f16x8 fb[3][2];      // [ring slot][plane]: fragments run 2 steps ahead of the MFMAs
+  auto load_b = [&](int g, f16x8 (&dst)[2]) {
+    const int gg = g < G ? g : G - 1;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff + gg * step_bytes + pl * plane_bytes, 0, 0);
+      dst[pl] = __builtin_bit_cast(f16x8, v);
+    }
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  int E = EMIN;
+  load_b(0, fb[0]);
+  load_b(1, fb[1]);
+  load_halo(0);
+  __syncthreads();                        // amax cells zeroed before the first atomic
+  int g = 0;
+  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    tile_amax(chunk & 1);
+    __syncthreads();                      // amax complete; every wave has finished reading the previous image
+    const int ec = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[chunk & 1]));
+    if (ec > E) {
+      const int d = E - ec;               // accumulators move to the new unit 2^(ec-14)
+      const float f = d < -126 ? 0.f : pow2f(d);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] *= f; acc1[r] *= f; }
+      E = ec;
+    }
+    store_halo(pow2f(14 - E));
+    if (tid == 0) amax_cell[(chunk + 1) & 1] = 0u;
+    __syncthreads();
+    if (chunk + 1 < a.nchunk) load_halo(chunk + 1);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) fa[0][mi][pl] = *reinterpret_cast<const f16x8*>(&Ah[pl * PLANE + rowbase[mi][0]]);
+#pragma unroll
+    for (int step = 0; step < 18; ++step) {
+      if (step + 1 < 18) {
+        const int tap = (step + 1) >> 1, s2 = (step + 1) & 1, r = tap / 3, s = tap - 3 * r;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+            fa[(step + 1) & 1][mi][pl] = *reinterpret_cast<const f16x8*>(&Ah[pl * PLANE + rowbase[mi][r] + s * XLD + 16 * s2]);
+      }
+      load_b(g + 2, fb[(step + 2) % 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8(&A)[2][2] = fa[step & 1];
+      const f16x8(&Bf)[2] = fb[step % 3];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][0], Bf[1], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][0], Bf[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][1], Bf[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][1], Bf[0], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][0], Bf[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][0], Bf[0], acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ++g;
+    }
+  }
+
+  // ---- epilogue ----
+  __syncthreads();
+  const int n = n0 + 32 * wn + l31;
+  float csum = 0.f, csq = 0.f;
+  if (n < a.Cd) {
+    const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
+    const int Ew = exponent_of_bits(*reinterpret_cast<const unsigned*>(a.ws));
+    const float f1 = pow2f(E - 14), f2 = pow2f(Ew - 14);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const i32x4 pix = *reinterpret_cast<const i32x4*>(&rowpix[64 * wm + 32 * mi + 8 * rg + 4 * lh]);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+          if (pix[ri] < 0) continue;
+          const int r = 4 * rg + ri;
+          float v = (mi == 0 ? acc0[r] : acc1[r]) * f1 * f2 + bv;
+          const long e = (long)pix[ri] * a.Cd + n;
+          if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+          a.dst[e] = v;
+          csum += v; csq += v * v;
+        }
+      }
+    }
+  }
+  if (a.stats != nullptr) {
+    float* red = reinterpret_cast<float*>(&Ah[0]);     // the halo image is dead since the barrier above
+    const float s1 = csum + __shfl_xor(csum, 32, 64), s2 = csq + __shfl_xor(csq, 32, 64);
+    if (lh == 0) { red[(wm * 64 + 32 * wn + l31) * 2] = s1; red[(wm * 64 + 32 * wn + l31) * 2 + 1] = s2; }
+    __syncthreads();
+    if (tid < 128) {
+      const int col = tid >> 1, which = tid & 1;
+      const float v = red[col * 2 + which] + red[(64 + col) * 2 + which];
+      if (n0 + col < a.Cd) a.stats[((long)mt * a.Cd + n0 + col) * 2 + which] = v;
+    }
+  }
+}
+
+}  // namespace
+
+long fs_halo_f16_pack_bytes(int Cs, int Cd) {
+  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 63) / 64) * 64;
+  return HDR + nchunk * 18 * 2 * Npad * 16 * 2;
+}
+
+int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, int B, int H, int W,
+                        int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,
+                        hipStream_t stream) {
+  HaloF16Args a;
+  a.src = src; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = dst; a.stats = stats;
+  a.B = B; a.H = H; a.W = W; a.Cs = Cs; a.Cd = Cd;
+  a.Npad = ((Cd + 63) / 64) * 64;
+  a.nchunk = (Cs + 31) / 32;
+  fs_halo_patch(H, W, &a.Ph, &a.Pw);
+  a.tiles_y = cdiv(H, a.Ph); a.tiles_x = cdiv(W, a.Pw);
+  a.nx = B * a.tiles_y * a.tiles_x;
+  a.ny = a.Npad / 64;
+  a.src_bytes = (unsigned)((size_t)B * H * W * Cs * 4);
+  const long pack_bytes = fs_halo_f16_pack_bytes(Cs, Cd);
+  if (pack_bytes >= 2147483647L || (size_t)B * H * W * Cs * 4 >= 4294967000UL) return FS_ERR_ARG;
+  a.ws_bytes = (unsigned)pack_bytes;
+  a.drop_scale = drop_scale; a.drop_thresh = drop_thresh; a.drop_key = drop_key;
+  hipError_t e = hipMemsetAsync(ws, 0, 4, stream);
+  if (e != hipSuccess) return (int)e;
+  const long nw = (long)9 * Cin * Cout;
+  int ab = cdiv(nw, 256 * 8); if (ab > 256) ab = 256;
+  hipLaunchKernelGGL(conv_f16_amax_kernel, dim3(ab), dim3(256), 0, stream, w, nw, reinterpret_cast<unsigned*>(ws));
+  FS_LAUNCH_CHECK();
+  const long total = (long)a.nchunk * 18 * a.Npad;
+  hipLaunchKernelGGL(conv_pack_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws),
+                     Cin, Cout, transposed, Cs, Cd, a.Npad, total);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(conv3x3_halo_f16_kernel, dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}

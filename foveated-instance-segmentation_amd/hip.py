@@ -103,8 +103,10 @@ def load():
 
 
 def set_conv_precision(mode: str) -> None:
-    """'f32' (fp32 MFMA) or 'bf16x3' (split-precision bf16 MFMA, fp32-level accuracy; the default)."""
-    code = {"f32": 0, "bf16x3": 1}[mode]
+    """'f32' (fp32 MFMA), 'bf16x3' (three bf16 terms per operand, six bf16 MFMAs per product) or 'f16x2' (two scaled
+    fp16 terms, three fp16 MFMAs per product, used by the 3x3 stride-1 kernels; other shapes run bf16x3).  All three
+    accumulate in fp32 and stay within the rounding error of an fp32 accumulation chain."""
+    code = {"f32": 0, "bf16x3": 1, "f16x2": 2}[mode]
     if load().fs_set_conv_precision(code) != 0:
         raise HipLibraryError("fs_set_conv_precision rejected the mode")
     _ws_cache.clear()
@@ -131,7 +133,7 @@ def conv_stats_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_byte
 
 
 def get_conv_precision() -> str:
-    return ("f32", "bf16x3")[load().fs_get_conv_precision()]
+    return ("f32", "bf16x3", "f16x2")[load().fs_get_conv_precision()]
 
 
 def _stream():
