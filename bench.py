@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--serial-streams", action="store_true", help="run the HRNet branches on one stream (profiling)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
-    ap.add_argument("--conv-precision", default="bf16x3", choices=["bf16x3", "f32"],
+    ap.add_argument("--conv-precision", default="bf16x3", choices=["f16x2", "bf16x3", "f32"],
                     help="arithmetic of the aligned conv kernel: bf16x3 = fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs "
                          "per product, fp32 accumulation (fp32-level accuracy); f32 = fp32 MFMA")
     args = ap.parse_args()

@@ -1122,7 +1122,7 @@ int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
   const long P = (long)B * Ho * Wo;
   if (g_conv_precision >= 1 && H == Ho && W == Wo && fs_wgrad_x3_eligible(Cin, Cout, R, S, stride, pad, dil) &&
       (size_t)B * H * W * Cin * 4 < 4294967000UL && (size_t)P * Cout * 4 < 4294967000UL)
-    return fs_wgrad_x3(x, dy, dw, B, H, W, Cin, Cout, stream);
+    return g_conv_precision == 2 ? fs_wgrad_f16(x, dy, dw, B, H, W, Cin, Cout, stream) : fs_wgrad_x3(x, dy, dw, B, H, W, Cin, Cout, stream);
   const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);
   // one filter row per workgroup for narrow layers (more workgroups, fewer atomics each), the whole 3x3
   // filter per workgroup once there are >= 9 channel tiles (measured: 64^2/128^2 87-90 TF with 3,

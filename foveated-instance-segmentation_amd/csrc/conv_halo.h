@@ -27,6 +27,8 @@ int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, flo
 // conv_wgrad_x3.hip: split-precision weight gradient of a 3x3 / stride-1 / pad-1 convolution (dw must be zeroed).
 bool fs_wgrad_x3_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil);
 int fs_wgrad_x3(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t stream);
+// conv_wgrad_f16.hip: the same in f16x2 split precision
+int fs_wgrad_f16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t stream);
 
 // conv_tapset.hip: general halo-tiled split-precision convolution over a list of tap classes.
 //   source row of (loop row oy, class tap tr) = sm*(oy + tr) + cy,  filter row r = rbase + rstep*tr  (columns alike)

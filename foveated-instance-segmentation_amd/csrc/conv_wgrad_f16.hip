@@ -1,0 +1,278 @@
+// Weight gradient of a 3x3 / stride-1 / pad-1 convolution in the f16x2 split precision (see conv_halo_f16.hip for the
+// arithmetic; conv_wgrad_x3.hip for the tiling, which is identical: 64(ci) x 64(co) tile of all 9 taps per workgroup,
+// split-K over pixel patches, X halo and dY patch kept in LDS in [pixel][channel] order and read transposed with
+// ds_read_b64_tr_b16).  Two fp16 planes per operand, three MFMAs per product.
+//
+// Scaling: per patch the workgroup takes max|X| over the halo tile and max|dY| over the patch (exponents ex, ey) and
+// keeps a running exponent E of the accumulators' unit (products are accumulated in units of 2^(E-28)).  If
+// ex + ey > E the nine accumulators are rescaled by the exact power of two and E = ex + ey; dY is scaled by 2^(14-ey)
+// and X by 2^(14-(E-ey)) (<= 2^(14-ex): never overflows; a patch far below the running magnitude loses low-order bits
+// only relative to what is already accumulated).  The atomics at the end add acc * 2^(E-28).
+#include "common.h"
+#include "conv_halo.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16v4 __attribute__((vector_size(8)));
+typedef __attribute__((address_space(3))) fp16v4* lds_f16x4_ptr;
+constexpr int EMIN = -100;
+
+constexpr int XS = 112;               // halo slots per patch (max)
+constexpr int YP = 64;                // pixels per patch (max)
+constexpr int X_HALF = XS * 64;       // bytes of one 32-channel half image
+constexpr int X_PLANE = 2 * X_HALF;
+constexpr int Y_HALF = YP * 64;
+constexpr int Y_PLANE = 2 * Y_HALF;
+constexpr int NXI = XS * 16 / 256;    // 7 float4 loads per thread for the X halo
+constexpr int NYI = YP * 16 / 256;    // 4 for the dY patch
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void split2(float xs, _Float16& a, _Float16& b) {
+  a = (_Float16)xs;
+  b = (_Float16)(xs - (float)a);
+}
+__device__ __forceinline__ float pow2f(int e) {          // 2^e, 0 below the normal range
+  return e < -126 ? 0.f : __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
+__device__ __forceinline__ int exponent_of_bits(unsigned bits) {
+  const int e = (int)((bits >> 23) & 0xffu) - 127;
+  return e < EMIN ? EMIN : e;
+}
+
+struct WgF16Args {
+  const float* x;    // (B,H,W,Cin)
+  const float* dy;   // (B,H,W,Cout)
+  float* dw;         // [3][3][Cin][Cout], zero-initialised
+  int B, H, W, Cin, Cout;
+  int Ph, Pw, tiles_y, tiles_x, npatch, patches_per_split;
+  int tiles_ci, tiles_co;
+  unsigned x_bytes, dy_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_f16_kernel(WgF16Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char Xl[2 * X_PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char Yl[2 * Y_PLANE];
+  __shared__ unsigned amax_cell[2][2];      // [patch parity][X, dY]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntile = a.tiles_ci * a.tiles_co;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous range so the
+  // ntile workgroups of one split (same pixels, different channel tiles) share one L2.
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd = nwg >> 3, rmd = nwg & 7;
+  const int wg = (xcd < rmd ? xcd * (qd + 1) : rmd * (qd + 1) + (xcd - rmd) * qd) + loc;
+  const int split = wg / ntile, tile = wg - split * ntile;
+  const int tci = tile / a.tiles_co, tco = tile - tci * a.tiles_co;
+  const int ci0 = tci * 64, co0 = tco * 64;
+  const int p_begin = split * a.patches_per_split;
+  const int p_end = (p_begin + a.patches_per_split < a.npatch) ? p_begin + a.patches_per_split : a.npatch;
+  const int Wh = a.Pw + 2, nslots = (a.Ph + 2) * Wh, npix = a.Ph * a.Pw, nk = (npix + 15) >> 4;
+  const int tpi = a.tiles_y * a.tiles_x;
+
+  // ---- loader constants: item i of a thread = (row (tid>>4) + 16 i, channel quad cq) ----
+  const int cq = tid & 15;
+  int xcode[NXI], ycode[NYI];     // (hy << 16 | hx) of the halo slot / (py << 16 | px) of the patch pixel, -1 = unused
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) {
+    const int slot = (tid >> 4) + 16 * i;
+    const int hy = slot / Wh, hx = slot - hy * Wh;
+    xcode[i] = (slot < nslots && ci0 + 4 * cq < a.Cin) ? ((hy << 16) | hx) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NYI; ++i) {
+    const int p = (tid >> 4) + 16 * i;
+    const int py = p / a.Pw, px = p - py * a.Pw;
+    ycode[i] = (p < npix && co0 + 4 * cq < a.Cout) ? ((py << 16) | px) : -1;
+  }
+  const int xw = (cq >> 3) * X_HALF + (tid >> 4) * 64 + (cq & 7) * 8;     // + i*1024 + plane*X_PLANE
+  const int yw = (cq >> 3) * Y_HALF + (tid >> 4) * 64 + (cq & 7) * 8;     // + i*1024 + plane*Y_PLANE
+  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.x, a.x_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(a.dy, a.dy_bytes);
+
+  // ---- transposed-read lane constants: 16-lane group g reads rows (pixels) q = 0..3, columns cb + 4pp .. +3 ----
+  const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, g = lane >> 4, lh = g >> 1, cb = 16 * (g & 1);
+  int xb[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      int pidx = 16 * ks + 8 * lh + 4 * t + q;
+      if (pidx >= npix) pidx = 0;             // padded k: dY is zero there, any valid X address will do
+      const int py = pidx / a.Pw, px = pidx - py * a.Pw;
+      xb[ks][t] = wm * X_HALF + (py * Wh + px) * 64 + (cb + 4 * pp) * 2;
+    }
+  const int yb = wn * Y_HALF + (8 * lh + q) * 64 + (cb + 4 * pp) * 2;      // + ks*1024 + t*256 + plane*Y_PLANE
+  const int rowoff1 = Wh * 64, rowoff2 = 2 * Wh * 64;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  auto tr = [&](const unsigned char* base, int off) -> f16x4 {
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4_ptr)(base + off)));
+  };
+  auto cat = [](f16x4 lo, f16x4 hi) -> f16x8 { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); };
+  if (tid < 4) amax_cell[tid >> 1][tid & 1] = 0u;
+  __syncthreads();
+  int E = 2 * EMIN - 1, par = 0;
+
+  for (int patch = p_begin; patch < p_end; ++patch) {
+    const int b = patch / tpi;
+    const int trem = patch - b * tpi;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int y0 = ty * a.Ph, x0 = tx * a.Pw;
+
+    f32x4 rx[NXI], ry[NYI];
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const int hy = xcode[i] >> 16, hx = xcode[i] & 0xffff;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      const bool ok = xcode[i] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const unsigned off = (unsigned)(((b * a.H + iy) * a.W + ix) * a.Cin + ci0 + 4 * cq) * 4u;
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? (int)off : (int)OOB, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < NYI; ++i) {
+      const int py = ycode[i] >> 16, px = ycode[i] & 0xffff;
+      const int y = y0 + py, x = x0 + px;
+      const bool ok = ycode[i] >= 0 && y < a.H && x < a.W;
+      const unsigned off = (unsigned)(((b * a.H + y) * a.W + x) * a.Cout + co0 + 4 * cq) * 4u;
+      ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, ok ? (int)off : (int)OOB, 0, 0));
+    }
+    {   // tile maxima -> LDS cells of this patch's parity
+      float mx = 0.f, my = 0.f;
+#pragma unroll
+      for (int i = 0; i < NXI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(rx[i][e]));
+#pragma unroll
+      for (int i = 0; i < NYI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) my = fmaxf(my, fabsf(ry[i][e]));
+      mx = wave_max(mx); my = wave_max(my);
+      if (lane == 0) { atomicMax(&amax_cell[par][0], __builtin_bit_cast(unsigned, mx)); atomicMax(&amax_cell[par][1], __builtin_bit_cast(unsigned, my)); }
+    }
+    __syncthreads();     // maxima complete; every wave has finished reading the previous patch
+    const int ex = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[par][0]));
+    const int ey = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[par][1]));
+    if (ex + ey > E) {
+      const float f = pow2f(E - ex - ey);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] *= f;
+      E = ex + ey;
+    }
+    const float sx = pow2f(14 - (E - ey)), sy = pow2f(14 - ey);
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      f16x4 p0, p1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { _Float16 u, v; split2(rx[i][e] * sx, u, v); p0[e] = u; p1[e] = v; }
+      *reinterpret_cast<f16x4*>(&Xl[xw + i * 1024]) = p0;
+      *reinterpret_cast<f16x4*>(&Xl[xw + i * 1024 + X_PLANE]) = p1;
+    }
+#pragma unroll
+    for (int i = 0; i < NYI; ++i) {
+      f16x4 p0, p1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { _Float16 u, v; split2(ry[i][e] * sy, u, v); p0[e] = u; p1[e] = v; }
+      *reinterpret_cast<f16x4*>(&Yl[yw + i * 1024]) = p0;
+      *reinterpret_cast<f16x4*>(&Yl[yw + i * 1024 + Y_PLANE]) = p1;
+    }
+    par ^= 1;
+    if (tid < 2) amax_cell[par][tid] = 0u;
+    __syncthreads();
+
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < nk) {
+        f16x8 fb[2], fa[2][2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) fb[pl] = cat(tr(Yl, yb + ks * 1024 + pl * Y_PLANE), tr(Yl, yb + ks * 1024 + 256 + pl * Y_PLANE));
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) fa[0][pl] = cat(tr(Xl, xb[ks][0] + pl * X_PLANE), tr(Xl, xb[ks][1] + pl * X_PLANE));
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          if (tap + 1 < 9) {
+            const int r = (tap + 1) / 3, s = (tap + 1) - 3 * r;
+            const int ro = r == 0 ? 0 : (r == 1 ? rowoff1 : rowoff2);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+              fa[(tap + 1) & 1][pl] = cat(tr(Xl, xb[ks][0] + ro + s * 64 + pl * X_PLANE), tr(Xl, xb[ks][1] + ro + s * 64 + pl * X_PLANE));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const f16x8(&A)[2] = fa[tap & 1];
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], fb[1], acc[tap], 0, 0, 0);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], fb[0], acc[tap], 0, 0, 0);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], fb[0], acc[tap], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+
+  const int co = co0 + 32 * wn + (lane & 31);
+  const int Eo = E - 28;                                   // two factors: the combined exponent can leave the float range
+  const float fo1 = pow2f(Eo / 2), fo2 = pow2f(Eo - Eo / 2);
+  if (co < a.Cout && p_begin < p_end) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (ci < a.Cin) atomicAdd(&a.dw[((long)tap * a.Cin + ci) * a.Cout + co], acc[tap][r] * fo1 * fo2);
+      }
+    }
+  }
+}
+
+// Patch choice: Ph*Pw <= 64 pixels (padded to a multiple of 16 for the k-steps), halo (Ph+2)(Pw+2) <= 112 slots;
+// minimise total k-steps, then the number of patches.
+void choose_wgrad_patch(int H, int W, int& Ph, int& Pw) {
+  long best = -1;
+  Ph = 8; Pw = 8;
+  for (int pw = 2; pw <= 64 && pw <= W + 1; ++pw)
+    for (int ph = 1; ph <= 64 && ph <= H + 1; ++ph) {
+      if (ph * pw > YP || (ph + 2) * (pw + 2) > XS) continue;
+      const long patches = (long)cdiv(H, ph) * cdiv(W, pw);
+      const long ksteps = patches * cdiv(ph * pw, 16);
+      const long cost = ksteps * 1000000 + patches * 100 + ((pw & 3) ? 50 : 0) + (ph + 2) * (pw + 2) / 4;
+      if (best < 0 || cost < best) { best = cost; Ph = ph; Pw = pw; }
+    }
+}
+
+}  // namespace
+
+int fs_wgrad_f16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t stream) {
+  if ((size_t)B * H * W * Cin * 4 >= 4294967000UL || (size_t)B * H * W * Cout * 4 >= 4294967000UL) return FS_ERR_ARG;
+  WgF16Args a;
+  a.x = x; a.dy = dy; a.dw = dw;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  choose_wgrad_patch(H, W, a.Ph, a.Pw);
+  a.tiles_y = cdiv(H, a.Ph); a.tiles_x = cdiv(W, a.Pw);
+  a.npatch = B * a.tiles_y * a.tiles_x;
+  a.tiles_ci = cdiv(Cin, 64); a.tiles_co = cdiv(Cout, 64);
+  const int ntile = a.tiles_ci * a.tiles_co;
+  // two workgroups fit per CU (LDS, registers): one full round of 512 workgroups, never a short second round
+  int nsplit = 512 / ntile;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > a.npatch) nsplit = a.npatch;
+  a.patches_per_split = cdiv(a.npatch, nsplit);
+  nsplit = cdiv(a.npatch, a.patches_per_split);
+  a.x_bytes = (unsigned)((size_t)B * H * W * Cin * 4);
+  a.dy_bytes = (unsigned)((size_t)B * H * W * Cout * 4);
+  hipLaunchKernelGGL(conv_wgrad3x3_f16_kernel, dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
