@@ -22,6 +22,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, dense bf16 MFMA; the bf16x3 conv issues 6 bf16 MFMAs per fp32 product
+PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16 MFMA (same rate as bf16); the f16x2 conv issues 3 fp16 MFMAs per fp32 product
 PEAK_HBM_GBS = 8000.0
 
 
@@ -79,9 +80,11 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--serial-streams", action="store_true", help="run the HRNet branches on one stream (profiling)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
-    ap.add_argument("--conv-precision", default="bf16x3", choices=["f16x2", "bf16x3", "f32"],
-                    help="arithmetic of the aligned conv kernel: bf16x3 = fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs "
-                         "per product, fp32 accumulation (fp32-level accuracy); f32 = fp32 MFMA")
+    ap.add_argument("--conv-precision", default="f16x2", choices=["f16x2", "bf16x3", "f32"],
+                    help="arithmetic of the conv kernels (fp32 tensors and fp32 accumulation in every mode): f16x2 = operands "
+                         "scaled and split into 2 fp16 terms, 3 fp16 MFMAs per product (3x3 stride-1 kernels; the rest bf16x3); "
+                         "bf16x3 = 3 bf16 terms, 6 bf16 MFMAs per product; f32 = fp32 MFMA.  All three are at the fp32 error level "
+                         "(tools/conv_accuracy.py)")
     args = ap.parse_args()
 
     import fovealseg
@@ -161,35 +164,40 @@ def main():
     if rank == 0:
         if timer is not None:
             summ = timer.summary()
-            k = summ.get("conv_affine")
-            if k:
-                achieved = k["flops"] / (k["total_ms"] * 1e-3) / 1e12
-                if args.conv_precision == "bf16x3":
-                    kname, peak = "conv_igemm_x3_kernel", PEAK_BF16_MFMA_TFLOPS / 6.0
-                    kdesc = ("conv_igemm_x3_kernel (fwd + bwd-data implicit GEMM; fp32 operands split into 3 bf16 terms, 6 x "
-                             "v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; achieved = algorithmic fp32 FLOP/s, "
-                             "peak = dense bf16 MFMA peak / 6)")
-                else:
-                    kname, peak = "conv_igemm_affine_kernel<1>", PEAK_F32_MFMA_TFLOPS
-                    kdesc = "conv_igemm_affine_kernel<1> (fwd + bwd-data implicit GEMM, fp32 MFMA 32x32x2)"
-                line["roofline"] = {
-                    "kernel": kdesc,
-                    "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": _profiled_traffic(kname),
-                    "launches_per_step": k["launches"] // args.steps,
-                    "avg_launch_us": round(1000.0 * k["total_ms"] / k["launches"], 2),
-                    "gflop_per_launch": round(k["flops"] / k["launches"] / 1e9, 3),
-                    "share_of_serial_step": round(k["total_ms"] / (1000.0 * serial_elapsed), 3),
-                    "serial_ms_per_step": round(1000.0 * serial_elapsed / args.steps, 2),
-                    "measured": "second pass of the same K steps with branch streams serialised, HIP events per launch"}
-            w = summ.get("conv_wgrad")
-            if w:
-                line["roofline_wgrad"] = {
-                    "kernel": "conv_wgrad_taps_kernel<3|9> + conv_wgrad_kernel (bwd-weight, fp32 MFMA)", "bound": "mfma",
-                    "achieved": round(w["flops"] / (w["total_ms"] * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(w["flops"] / (w["total_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                    "avg_launch_us": round(1000.0 * w["total_ms"] / w["launches"], 2),
-                    "share_of_serial_step": round(w["total_ms"] / (1000.0 * serial_elapsed), 3)}
+            def entry(kk, desc, peak, kname):
+                ach = kk["flops"] / (kk["total_ms"] * 1e-3) / 1e12
+                return {"kernel": desc, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": _profiled_traffic(kname),
+                        "launches_per_step": kk["launches"] // args.steps,
+                        "avg_launch_us": round(1000.0 * kk["total_ms"] / kk["launches"], 2),
+                        "gflop_per_launch": round(kk["flops"] / kk["launches"] / 1e9, 3),
+                        "share_of_serial_step": round(kk["total_ms"] / (1000.0 * serial_elapsed), 3)}
+            split = {"f16x2": ("f16", PEAK_F16_MFMA_TFLOPS / 3.0, "two scaled fp16 terms per operand, 3 x v_mfma_f32_32x32x16_f16 per product"),
+                     "bf16x3": ("x3", PEAK_BF16_MFMA_TFLOPS / 6.0, "three bf16 terms per operand, 6 x v_mfma_f32_32x32x16_bf16 per product")}
+            if args.conv_precision in split and "conv3x3" in summ:
+                tag, peak, how = split[args.conv_precision]
+                line["roofline"] = entry(
+                    summ["conv3x3"],
+                    f"conv3x3_halo_{tag}_kernel (3x3 stride-1 forward + bwd-data, halo-tiled implicit GEMM; {how}, fp32 accumulate; "
+                    "achieved = algorithmic fp32 FLOP/s over the C-ABI call incl. its weight pack pre-kernels, peak = dense MFMA peak / "
+                    "MFMAs per product)", peak, f"conv3x3_halo_{tag}_kernel")
+                line["roofline"]["serial_ms_per_step"] = round(1000.0 * serial_elapsed / args.steps, 2)
+                line["roofline"]["measured"] = "second pass of the same K steps with branch streams serialised, HIP events per launch"
+                if "wgrad3x3" in summ:
+                    line["roofline_wgrad"] = entry(
+                        summ["wgrad3x3"], f"conv_wgrad3x3_{tag}_kernel (3x3 stride-1 bwd-weight, 9 taps per workgroup, split-K atomics; {how})",
+                        peak, f"conv_wgrad3x3_{tag}_kernel")
+                if "conv_affine" in summ:
+                    line["roofline_other_convs"] = entry(
+                        summ["conv_affine"], "conv_tapset_x3_kernel / conv_igemm_x3_kernel (strided 3x3 and 1x1 forward + bwd-data, bf16x3)",
+                        PEAK_BF16_MFMA_TFLOPS / 6.0, "conv_igemm_x3_kernel")
+            elif "conv_affine" in summ:
+                line["roofline"] = entry(summ["conv_affine"], "conv_igemm_affine_kernel<1> (fwd + bwd-data implicit GEMM, fp32 MFMA 32x32x2)",
+                                         PEAK_F32_MFMA_TFLOPS, "conv_igemm_affine_kernel<1>")
+                line["roofline"]["serial_ms_per_step"] = round(1000.0 * serial_elapsed / args.steps, 2)
+                if "conv_wgrad" in summ:
+                    line["roofline_wgrad"] = entry(summ["conv_wgrad"], "conv_wgrad_taps_kernel<3|9> + conv_wgrad_kernel (bwd-weight, fp32 MFMA)",
+                                                   PEAK_F32_MFMA_TFLOPS, "conv_wgrad_taps_kernel")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "conv_halo.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -241,12 +242,14 @@ struct AffArgs {
 };
 
 static thread_local hipStream_t a_stream = nullptr;   // host: stream of the launch being issued
-// 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-precision bf16x3 (six v_mfma_f32_32x32x16_bf16 per product).
-// Default from FS_CONV_PRECISION=f32|bf16x3 (bf16x3 when unset); fs_set_conv_precision() overrides.
+// 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-precision bf16x3 (six v_mfma_f32_32x32x16_bf16 per product),
+// 2 = f16x2 (three v_mfma_f32_32x32x16_f16 per product on scaled operands) in the 3x3 stride-1 kernels, bf16x3 elsewhere.
+// Default from FS_CONV_PRECISION=f32|bf16x3|f16x2 (f16x2 when unset); fs_set_conv_precision() overrides.
 static int g_conv_precision = [] {
   const char* e = getenv("FS_CONV_PRECISION");
-  if (e && e[0] == 'f' && e[1] == '1') return 2;      // f16x2
-  return (e && e[0] == 'f') ? 0 : 1;                   // f32 | bf16x3
+  if (e && strcmp(e, "f32") == 0) return 0;
+  if (e && strcmp(e, "bf16x3") == 0) return 1;
+  return 2;                                            // f16x2
 }();
 
 template <int MT>

@@ -10,6 +10,8 @@
 // only relative to what is already accumulated).  The atomics at the end add acc * 2^(E-28).
 #include "common.h"
 #include "conv_halo.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -238,16 +240,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_f16_kernel(WgF16Args a) 
 }
 
 // Patch choice: Ph*Pw <= 64 pixels (padded to a multiple of 16 for the k-steps), halo (Ph+2)(Pw+2) <= 112 slots;
-// minimise total k-steps, then the number of patches.
+// minimise patches * (k-steps per patch + 1.5).
 void choose_wgrad_patch(int H, int W, int& Ph, int& Pw) {
+  if (const char* e = getenv("FS_WGRAD_PATCH")) {       // kernel experiments: "PhxPw"
+    int ph = 0, pw = 0;
+    if (sscanf(e, "%dx%d", &ph, &pw) == 2 && ph >= 1 && pw >= 1 && ph * pw <= YP && (ph + 2) * (pw + 2) <= XS) { Ph = ph; Pw = pw; return; }
+  }
   long best = -1;
   Ph = 8; Pw = 8;
   for (int pw = 2; pw <= 64 && pw <= W + 1; ++pw)
     for (int ph = 1; ph <= 64 && ph <= H + 1; ++ph) {
       if (ph * pw > YP || (ph + 2) * (pw + 2) > XS) continue;
       const long patches = (long)cdiv(H, ph) * cdiv(W, pw);
-      const long ksteps = patches * cdiv(ph * pw, 16);
-      const long cost = ksteps * 1000000 + patches * 100 + ((pw & 3) ? 50 : 0) + (ph + 2) * (pw + 2) / 4;
+      // measured on 20x20 x 256 ch: time ~ patches * (k-steps per patch + 1.5) -- every patch pays a load/split/barrier round
+      const long cost = patches * (2 * cdiv(ph * pw, 16) + 3) * 10000 + ((pw & 3) ? 5000 : 0) + (ph + 2) * (pw + 2);
       if (best < 0 || cost < best) { best = cost; Ph = ph; Pw = pw; }
     }
 }

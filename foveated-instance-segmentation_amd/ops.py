@@ -108,13 +108,22 @@ def _launch(kind, flops, name, *args):
         TIMER.launch(kind, flops, lambda: hip.call(name, *args), tag=(name,) + tuple(a for a in args if type(a) is int and a < (1 << 20)))
 
 
+def _conv_kind(Cs, Cd, R, S, stride, pad, dil):
+    """Timer bucket = the kernel csrc/conv.hip selects: the halo-tiled 3x3 stride-1 kernel, the other aligned kernels, or the generic one."""
+    if Cs % 4 or Cd % 4:
+        return "conv_generic"
+    if R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and Cs >= 32 and hip.get_conv_precision() != "f32":
+        return "conv3x3"
+    return "conv_affine"
+
+
 def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1):
     B, H, W, Cin = x.shape
     Cout, Cin2, R, S = w.shape
     assert Cin == Cin2, (x.shape, w.shape)
     Ho, Wo = _out_hw(H, W, R, S, stride, pad, dil)
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
-    kind = "conv_affine" if (Cin % 4 == 0 and Cout % 4 == 0) else "conv_generic"      # mirrors csrc/conv.hip dispatch
+    kind = _conv_kind(Cin, Cout, R, S, stride, pad, dil)
     ws, ws_bytes = _conv_workspace(x.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0)
     _launch(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd", hip.ptr(x), hip.ptr(rsck(w)), hip.ptr(bias),
             hip.ptr(y), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, float(drop_p), int(drop_key), hip.ptr(ws), ws_bytes)
@@ -142,7 +151,7 @@ def conv2d_fwd_stats(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1):
     ws, ws_bytes = _conv_workspace(x.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0)
     nwg = hip.conv_stats_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes)
     slab = torch.empty(nwg * Cout * 2, device=x.device, dtype=torch.float32)
-    _launch("conv_affine", 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd_stats", hip.ptr(x), hip.ptr(rsck(w)),
+    _launch(_conv_kind(Cin, Cout, R, S, stride, pad, dil), 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd_stats", hip.ptr(x), hip.ptr(rsck(w)),
             hip.ptr(bias), hip.ptr(y), hip.ptr(slab), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, float(drop_p), int(drop_key),
             hip.ptr(ws), ws_bytes)
     return y, slab, nwg
@@ -153,7 +162,7 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1):
     Cout, _, R, S = w.shape
     _, Ho, Wo, _ = dy.shape
     dx = torch.empty(B, H, W, Cin, device=dy.device, dtype=torch.float32)
-    kind = "conv_affine" if (Cin % 4 == 0 and Cout % 4 == 0) else "conv_generic"
+    kind = _conv_kind(Cout, Cin, R, S, stride, pad, dil)
     ws, ws_bytes = _conv_workspace(dy.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 1)
     _launch(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx),
             B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, hip.ptr(ws), ws_bytes)
@@ -181,7 +190,9 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None, dil=1):
     Cout, _, R, S = w_shape
     _, Ho, Wo, _ = dy.shape
     dw = rsck(out) if out is not None else torch.empty(R, S, Cin, Cout, device=x.device, dtype=torch.float32)
-    _launch("conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_bwd_weight", hip.ptr(x), hip.ptr(dy), hip.ptr(dw),
+    k3 = R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 16 and Cout >= 16
+    _launch("wgrad3x3" if (k3 and hip.get_conv_precision() != "f32") else "conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin,
+            "fs_conv2d_bwd_weight", hip.ptr(x), hip.ptr(dy), hip.ptr(dw),
             B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)
     return out if out is not None else dw.permute(3, 2, 0, 1)
 
