@@ -107,8 +107,8 @@ __global__ void bn_eval_prepare_kernel(const float* __restrict__ running_mean, c
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ res,
-                                                         float* __restrict__ out, long M, int C, int ld, int rows_per_block,
-                                                         int act) {
+                                                         float* __restrict__ out, unsigned char* __restrict__ mask, long M, int C,
+                                                         int ld, int rows_per_block, int act) {
   RowWalk w(C);
   if (!w.active()) return;
   const int c = 4 * w.col;
@@ -127,11 +127,18 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = fs_act(v[j], act);
     *reinterpret_cast<f32x4*>(out + r * ld + c) = v;
+    if (mask != nullptr) {      // activation-derivative bits of the 4 channels, one byte per float4 (read back by the backward passes)
+      unsigned m = 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m |= (fs_act_mask(v[j], act) != 0.f ? 1u : 0u) << j;
+      mask[(r * ld + c) >> 2] = (unsigned char)m;
+    }
   }
 }
 
 // ---- BN backward pass 1: sum(g), sum(g*xhat), g = dz * act'(z) --------------------------------
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                            const unsigned char* __restrict__ mask,
                                                             const float* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, long M, int C, int ld,
                                                             int Ctot, int rows_per_block, int act,
@@ -149,9 +156,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     for (long r = rb + w.r0; r < re; r += w.rpi) {
       f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * ld + c);
       if (act != FS_ACT_NONE) {
-        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * ld + c);
+        if (mask != nullptr) {
+          const unsigned m = mask[(r * ld + c) >> 2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] *= fs_act_mask(zz[j], act);
+          for (int j = 0; j < 4; ++j) g[j] = ((m >> j) & 1u) ? g[j] : 0.f;
+        } else {
+          const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * ld + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[j] *= fs_act_mask(zz[j], act);
+        }
       }
       const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + r * ld + c) - mu) * is;
       s += g; sx += g * xh;
@@ -170,6 +183,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 // ---- BN backward pass 2: dy (conv-output gradient, dropout applied), dres, dgamma/dbeta -------
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                           const unsigned char* __restrict__ mask,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const double* __restrict__ sums, long M, int C, int ld, int Ctot,
@@ -197,9 +211,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   for (long r = rb + w.r0; r < re; r += w.rpi) {
     f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * ld + c);
     if (act != FS_ACT_NONE) {
-      const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * ld + c);
+      if (mask != nullptr) {
+        const unsigned m = mask[(r * ld + c) >> 2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] *= fs_act_mask(zz[j], act);
+        for (int j = 0; j < 4; ++j) g[j] = ((m >> j) & 1u) ? g[j] : 0.f;
+      } else {
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * ld + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] *= fs_act_mask(zz[j], act);
+      }
     }
     if (dres != nullptr) *reinterpret_cast<f32x4*>(dres + r * ld + c) = g;
     const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + r * ld + c) - mu) * is;
@@ -481,13 +501,13 @@ int fs_bn_eval_prepare(const float* running_mean, const float* running_var, int 
 }
 
 int fs_bn_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                  const float* res, float* out, long M, int C, int act, hipStream_t stream) {
+                  const float* res, float* out, unsigned char* mask, long M, int C, int act, hipStream_t stream) {
   FS_REQUIRE(y && mean && invstd && gamma && beta && out && M > 0 && C > 0 && C % 4 == 0);
   for (int c0 = 0; c0 < C; c0 += 1024) {
     const int Cc = C - c0 < 1024 ? C - c0 : 1024;
     const int rpb = rows_per_block_for(M, Cc);
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, stream, y + c0, mean + c0, invstd + c0, gamma + c0,
-                       beta + c0, res ? res + c0 : nullptr, out + c0, M, Cc, C, rpb, act);
+                       beta + c0, res ? res + c0 : nullptr, out + c0, mask ? mask + c0 / 4 : nullptr, M, Cc, C, rpb, act);
     FS_LAUNCH_CHECK();
   }
   return FS_OK;
@@ -496,11 +516,11 @@ int fs_bn_act_fwd(const float* y, const float* mean, const float* invstd, const 
 // Backward of out = act(bn(y) + res).  training=1: batch statistics (sum terms); 0: running stats.
 // dy = gradient w.r.t. the (dropped-out) conv output, multiplied by the dropout mask when
 // drop_p > 0; dres (nullable) = gradient w.r.t. res; dgamma/dbeta overwritten.
-int fs_bn_act_bwd(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+int fs_bn_act_bwd(const float* dz, const float* z, const unsigned char* mask, const float* y, const float* mean, const float* invstd,
                   const float* gamma, long M, int C, int act, int training, float drop_p, uint32_t drop_key, float* dy,
                   float* dres, float* dgamma, float* dbeta, double* sums, hipStream_t stream) {
   FS_REQUIRE(dz && y && mean && invstd && gamma && dy && dgamma && dbeta && sums && M > 0 && C % 4 == 0);
-  FS_REQUIRE(act == FS_ACT_NONE || z != nullptr);
+  FS_REQUIRE(act == FS_ACT_NONE || z != nullptr || mask != nullptr);
   hipError_t e = hipMemsetAsync(sums, 0, 2 * C * sizeof(double), stream);
   if (e != hipSuccess) return (int)e;
   float scale = 1.f; uint32_t thresh = 0u;
@@ -509,10 +529,10 @@ int fs_bn_act_bwd(const float* dz, const float* z, const float* y, const float* 
     const int Cc = C - c0 < 1024 ? C - c0 : 1024;
     const int rpb = rows_per_block_for(M, Cc);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(M, rpb)), dim3(256), stats_smem(Cc), stream, dz + c0, z ? z + c0 : nullptr,
-                       y + c0, mean + c0, invstd + c0, M, Cc, C, C, rpb, act, sums + c0);
+                       mask ? mask + c0 / 4 : nullptr, y + c0, mean + c0, invstd + c0, M, Cc, C, C, rpb, act, sums + c0);
     FS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, stream, dz + c0, z ? z + c0 : nullptr, y + c0,
-                       mean + c0, invstd + c0, gamma + c0, sums + c0, M, Cc, C, C, c0, rpb, act, training, scale, thresh, drop_key,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, stream, dz + c0, z ? z + c0 : nullptr,
+                       mask ? mask + c0 / 4 : nullptr, y + c0, mean + c0, invstd + c0, gamma + c0, sums + c0, M, Cc, C, C, c0, rpb, act, training, scale, thresh, drop_key,
                        dy + c0, dres ? dres + c0 : nullptr, dgamma + c0, dbeta + c0);
     FS_LAUNCH_CHECK();
   }

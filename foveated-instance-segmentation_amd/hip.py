@@ -36,8 +36,8 @@ SIGNATURES = {
     "fs_bn_stats": "pliffppppp",
     "fs_bn_finalize_slab": "piliffpppp",
     "fs_bn_eval_prepare": "ppifpp",
-    "fs_bn_act_fwd": "ppppppplii",
-    "fs_bn_act_bwd": "ppppppliiifuppppp",
+    "fs_bn_act_fwd": "pppppppplii",
+    "fs_bn_act_bwd": "pppppppliiifuppppp",
     "fs_hr_fuse_fwd": "pppipiiiii",
     "fs_relu_bwd": "pppl",
     "fs_upsample_slice_fwd": "piiiipiiii",

@@ -239,17 +239,19 @@ class ConvBnAct(Function):
             hip.call("fs_bn_eval_prepare", hip.ptr(meta["running_mean"]), hip.ptr(meta["running_var"]), C, BN_EPS,
                      hip.ptr(mean), hip.ptr(invstd))
         z = torch.empty_like(y)
+        # activation-derivative bits for the backward passes (1 byte per 4 channels instead of re-reading z)
+        amask = torch.empty(M * C // 4, device=y.device, dtype=torch.uint8) if (meta["act"] != 0 and any(ctx.needs_input_grad)) else None
         hip.call("fs_bn_act_fwd", hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(beta), hip.ptr(res),
-                 hip.ptr(z), M, C, meta["act"])
+                 hip.ptr(z), hip.ptr(amask), M, C, meta["act"])
         ctx.meta = dict(stride=meta["stride"], pad=meta["pad"], dil=dil, act=meta["act"], training=training, drop_p=drop_p,
                         drop_key=meta["drop_key"], has_bias=bias is not None, has_res=res is not None)
-        ctx.save_for_backward(x, w, gamma, y, z, mean, invstd)
+        ctx.save_for_backward(x, w, gamma, y, z if amask is None else None, mean, invstd, amask)
         ctx.beta_ref = beta
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, w, gamma, y, z, mean, invstd = ctx.saved_tensors
+        x, w, gamma, y, z, mean, invstd, amask = ctx.saved_tensors
         m = ctx.meta
         dz = dz.contiguous()
         B, Ho, Wo, C = y.shape
@@ -261,7 +263,7 @@ class ConvBnAct(Function):
         dgamma = tg if direct_affine else torch.empty(C, device=y.device, dtype=torch.float32)
         dbeta = tb if direct_affine else torch.empty(C, device=y.device, dtype=torch.float32)
         sums = torch.empty(2 * C, device=y.device, dtype=torch.float64)
-        hip.call("fs_bn_act_bwd", hip.ptr(dz), hip.ptr(z), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), M, C,
+        hip.call("fs_bn_act_bwd", hip.ptr(dz), hip.ptr(z), hip.ptr(amask), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), M, C,
                  m["act"], 1 if m["training"] else 0, float(m["drop_p"]), int(m["drop_key"]), hip.ptr(dy), hip.ptr(dres),
                  hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums))
         dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"]) if ctx.needs_input_grad[0] else None

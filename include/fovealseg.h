@@ -103,10 +103,12 @@ int fs_bn_finalize_slab(const float* slab, int nwg, long M, int C, float momentu
                         float* running_var, float* mean, float* invstd, fs_stream_t stream);
 int fs_bn_eval_prepare(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* invstd,
                        fs_stream_t stream);
-/* out = act((y-mean)*invstd*gamma + beta [+ res]).  models/hrnetv2_nodownsp.py:51-52,56-62. */
+/* out = act((y-mean)*invstd*gamma + beta [+ res]).  mask (nullable, M*C/4 bytes): bit j of byte e/4 = act'(out[e+j]) != 0, so the
+ * backward passes read one byte instead of four floats of `out`.  models/hrnetv2_nodownsp.py:51-52,56-62. */
 int fs_bn_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* res,
-                  float* out, long M, int C, int act, fs_stream_t stream);
-int fs_bn_act_bwd(const float* dz, const float* z, const float* y, const float* mean, const float* invstd, const float* gamma,
+                  float* out, unsigned char* mask, long M, int C, int act, fs_stream_t stream);
+/* Backward of the above; the activation derivative comes from `mask` when given, else from z (= out). */
+int fs_bn_act_bwd(const float* dz, const float* z, const unsigned char* mask, const float* y, const float* mean, const float* invstd, const float* gamma,
                   long M, int C, int act, int training, float drop_p, uint32_t drop_key, float* dy, float* dres, float* dgamma,
                   float* dbeta, double* sums, fs_stream_t stream);
 
