@@ -921,22 +921,27 @@ bool use_halo(const ConvArgs& c) {
 }
 
 // Everything else that is channel-aligned, undilated and has scratch goes to the tap-class kernel (conv_tapset.hip).
+static const bool g_tapset_1x1 = [] { const char* e = getenv("FS_TAPSET_1X1"); return e && e[0] == '1'; }();
 static const bool g_tapset_all = [] { const char* e = getenv("FS_TAPSET_ALL"); return e && e[0] == '1'; }();
 bool tapset_shape_ok(int Cs, int Cd, int R, int S, int stride, int dil) {
   const int cr = stride < R ? stride : R, cs = stride < S ? stride : S;
   // 1x1 filters have no tap reuse: measured slower than conv_igemm_x3_kernel (43 vs 55 TF on 64->256 @ 80x80), not routed here
-  return dil == 1 && R * S > 1 && Cs % 4 == 0 && Cd % 4 == 0 && Cs >= 16 && cr * cs <= 9 &&
+  return dil == 1 && (R * S > 1 || g_tapset_1x1) && Cs % 4 == 0 && Cd % 4 == 0 && Cs >= 16 && cr * cs <= 9 &&
          ((R + stride - 1) / stride) * ((S + stride - 1) / stride) <= 64;
+}
+long tapset_pack_bytes(int Cs, int Cd, int taps) {
+  return g_conv_precision == 2 ? fs_tapset_f16_pack_bytes(Cs, Cd, taps) : fs_tapset_pack_bytes(Cs, Cd, taps);
 }
 bool use_tapset(const ConvArgs& c) {
   return g_conv_precision >= 1 && c.ws_ != nullptr && tapset_shape_ok(c.Cs, c.Cd, c.R, c.S, c.stride, c.dil) &&
-         c.ws_bytes_ >= fs_tapset_pack_bytes(c.Cs, c.Cd, c.R * c.S);
+         c.ws_bytes_ >= tapset_pack_bytes(c.Cs, c.Cd, c.R * c.S);
 }
+int run_tapset(const FsTapsetProblem& p, hipStream_t stream) { return g_conv_precision == 2 ? fs_tapset_f16_conv(p, stream) : fs_tapset_conv(p, stream); }
 FsTapsetProblem tapset_base(const ConvArgs& c) {
   FsTapsetProblem p{};
   p.src = c.src; p.w = c.w; p.bias = c.bias; p.dst = c.dst; p.stats = c.stats_; p.ws = c.ws_;
   p.B = c.B; p.Hs = c.Hs; p.Ws = c.Ws; p.Cs = c.Cs; p.Hd = c.Hd; p.Wd = c.Wd; p.Cd = c.Cd;
-  p.Cin = c.transposed ? c.Cd : c.Cs; p.Cout = c.transposed ? c.Cs : c.Cd; p.S = c.S;
+  p.Cin = c.transposed ? c.Cd : c.Cs; p.Cout = c.transposed ? c.Cs : c.Cd; p.R = c.R; p.S = c.S;
   p.transposed = c.transposed;
   p.drop_scale = c.drop_scale; p.drop_thresh = c.drop_thresh; p.drop_key = c.drop_key;
   return p;
@@ -949,7 +954,7 @@ int launch_tapset_forward(const ConvArgs& c) {
   for (int r0 = 0; r0 < st && r0 < c.R; ++r0)
     for (int s0 = 0; s0 < st && s0 < c.S; ++s0)
       p.cls[p.ncls++] = FsTapClass{r0 - c.pad, s0 - c.pad, (c.R - r0 + st - 1) / st, (c.S - s0 + st - 1) / st, r0, st, s0, st};
-  return fs_tapset_conv(p, c.stream_);
+  return run_tapset(p, c.stream_);
 }
 
 int launch_affine(const ConvArgs& c, long M) {
@@ -965,7 +970,7 @@ int launch_affine(const ConvArgs& c, long M) {
     p.Hq = c.Hd; p.Wq = c.Wd; p.os = 1; p.oy0 = 0; p.ox0 = 0; p.sm = 1;
     p.ncls = 1;
     p.cls[0] = FsTapClass{c.pad - (c.R - 1), c.pad - (c.S - 1), c.R, c.S, c.R - 1, -1, c.S - 1, -1};
-    return fs_tapset_conv(p, c.stream_);
+    return run_tapset(p, c.stream_);
   }
   if (use_halo(c) && g_conv_precision == 2)
     return fs_halo_f16_conv3x3(c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.B, c.Hd, c.Wd, c.Cs, c.Cd, c.transposed ? c.Cd : c.Cs,
@@ -989,13 +994,13 @@ int launch_affine(const ConvArgs& c, long M) {
       if (b.nR == 0 || b.nS == 0) { b.nR = 0; b.nS = 0; }       // no tap reaches this class: writes zeros
       b.cy = (oy0 + c.pad - b.r0) / st; b.cx = (ox0 + c.pad - b.s0) / st;
       if (b.Hq <= 0 || b.Wq <= 0) continue;
-      if (b.nR * b.nS > 1 && use_tapset(c)) {       // single-tap sub-problems: no reuse, the plain kernel is faster
+      if ((b.nR * b.nS > 1 || (g_tapset_1x1 && b.nR * b.nS == 1)) && use_tapset(c)) {       // single-tap sub-problems: no reuse, the plain kernel is faster
         // dY row of tap t is py + cy - t: in increasing source order tr = nR-1-t, filter row r0 + st*(nR-1-tr)
         FsTapsetProblem p = tapset_base(c);
         p.Hq = b.Hq; p.Wq = b.Wq; p.os = st; p.oy0 = oy0; p.ox0 = ox0; p.sm = 1;
         p.ncls = 1;
         p.cls[0] = FsTapClass{b.cy - (b.nR - 1), b.cx - (b.nS - 1), b.nR, b.nS, b.r0 + st * (b.nR - 1), -st, b.s0 + st * (b.nS - 1), -st};
-        int e2 = fs_tapset_conv(p, c.stream_);
+        int e2 = run_tapset(p, c.stream_);
         if (e2 != FS_OK) return e2;
         continue;
       }
@@ -1025,7 +1030,7 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
   long need = 0;
   if (H == Ho && W == Wo && fs_halo_eligible(H, W, Cs, Cd, R, S, stride, pad, dil)) need = halo_pack_bytes(Cs, Cd);
   if (tapset_shape_ok(Cs, Cd, R, S, stride, dil)) {
-    const long t = fs_tapset_pack_bytes(Cs, Cd, R * S);
+    const long t = tapset_pack_bytes(Cs, Cd, R * S);
     if (t > need) need = t;
   }
   return need;

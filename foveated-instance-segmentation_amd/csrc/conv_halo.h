@@ -36,7 +36,7 @@ struct FsTapClass { int cy, cx, nR, nS, rbase, rstep, sbase, sstep; };
 struct FsTapsetProblem {
   const float* src; const float* w; const float* bias; float* dst; float* stats; void* ws;
   int B, Hs, Ws, Cs, Hd, Wd, Cd;     // source / destination tensors (NHWC)
-  int Cin, Cout, S;                  // logical weight shape [R][S][Cin][Cout]
+  int Cin, Cout, R, S;               // logical weight shape [R][S][Cin][Cout]
   int transposed;                    // 0: K = Cin, N = Cout;  1 (bwd-data): K = Cout, N = Cin
   int Hq, Wq, os, oy0, ox0, sm;      // loop grid; destination pixel = (oy*os + oy0, ox*os + ox0)
   int ncls; FsTapClass cls[9];
@@ -45,3 +45,9 @@ struct FsTapsetProblem {
 long fs_tapset_pack_bytes(int Cs, int Cd, int total_taps);
 int fs_tapset_slabs(int B, int Hq, int Wq, int maxR, int maxS);
 int fs_tapset_conv(const FsTapsetProblem& p, hipStream_t stream);
+void fs_tapset_patch(int Hq, int Wq, int maxR, int maxS, int* Ph, int* Pw);
+// conv_tapset_f16.hip: the same in f16x2 split precision
+long fs_tapset_f16_pack_bytes(int Cs, int Cd, int total_taps);
+int fs_tapset_f16_conv(const FsTapsetProblem& p, hipStream_t stream);
+// conv_halo_f16.hip: max |w| of a weight tensor as float bits into the first word of ws (memset + atomic-max kernel)
+int fs_f16_weight_amax(const float* w, long n, void* ws, hipStream_t stream);

@@ -290,6 +290,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
 
 }  // namespace
 
+int fs_f16_weight_amax(const float* w, long n, void* ws, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(ws, 0, 4, stream);
+  if (e != hipSuccess) return (int)e;
+  int ab = cdiv(n, 256 * 8); if (ab > 256) ab = 256;
+  hipLaunchKernelGGL(conv_f16_amax_kernel, dim3(ab), dim3(256), 0, stream, w, n, reinterpret_cast<unsigned*>(ws));
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
 long fs_halo_f16_pack_bytes(int Cs, int Cd) {
   const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 63) / 64) * 64;
   return HDR + nchunk * 18 * 2 * Npad * 16 * 2;
@@ -312,12 +321,8 @@ int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, flo
   if (pack_bytes >= 2147483647L || (size_t)B * H * W * Cs * 4 >= 4294967000UL) return FS_ERR_ARG;
   a.ws_bytes = (unsigned)pack_bytes;
   a.drop_scale = drop_scale; a.drop_thresh = drop_thresh; a.drop_key = drop_key;
-  hipError_t e = hipMemsetAsync(ws, 0, 4, stream);
-  if (e != hipSuccess) return (int)e;
-  const long nw = (long)9 * Cin * Cout;
-  int ab = cdiv(nw, 256 * 8); if (ab > 256) ab = 256;
-  hipLaunchKernelGGL(conv_f16_amax_kernel, dim3(ab), dim3(256), 0, stream, w, nw, reinterpret_cast<unsigned*>(ws));
-  FS_LAUNCH_CHECK();
+  int e = fs_f16_weight_amax(w, (long)9 * Cin * Cout, ws, stream);
+  if (e != FS_OK) return e;
   const long total = (long)a.nchunk * 18 * a.Npad;
   hipLaunchKernelGGL(conv_pack_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws),
                      Cin, Cout, transposed, Cs, Cd, a.Npad, total);

@@ -1,0 +1,377 @@
+// General halo-tiled convolution over tap classes (see conv_tapset.hip for the decomposition and tiling) in the f16x2
+// split precision (see conv_halo_f16.hip for the arithmetic and the scaling scheme): two fp16 planes per operand, three
+// v_mfma_f32_32x32x16_f16 per product, one running exponent per workgroup updated at every LDS refill, one exponent per
+// weight tensor from the amax pre-pass.
+#include "common.h"
+#include "conv_halo.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XLD = 40;            // bf16 per LDS slot (80 bytes)
+constexpr int NSMAX = 224;         // halo slots per plane
+constexpr int NITEM = 7;           // NSMAX * 8 quads / 256 threads
+constexpr int PLANE = NSMAX * XLD;
+constexpr unsigned OOB = 0xFFFFFFF0u;
+constexpr int HDR = 256;           // bytes of pack header (weight amax bits at offset 0)
+constexpr int EMIN = -100;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void split2(float xs, _Float16& a, _Float16& b) {
+  a = (_Float16)xs;
+  b = (_Float16)(xs - (float)a);
+}
+__device__ __forceinline__ float pow2f(int e) { return e < -126 ? 0.f : __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+__device__ __forceinline__ int exponent_of_bits(unsigned bits) {
+  const int e = (int)((bits >> 23) & 0xffu) - 127;
+  return e < EMIN ? EMIN : e;
+}
+// ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (per 32-lane half).  Map the
+// 32 rows of an MFMA tile to patch pixels so that each group reads 16 CONSECUTIVE pixels (conflict-free 80-B rows).
+__device__ __forceinline__ int row_perm(int l) {
+  const bool g1 = (l >= 4 && l < 12) || (l >= 16 && l < 20) || l >= 28;
+  if (!g1) return l < 4 ? l : (l < 16 ? l - 8 : l - 12);
+  return 16 + (l < 12 ? l - 4 : (l < 20 ? l - 8 : l - 16));
+}
+
+struct TsF16Args {
+  const float* src; const unsigned char* ws; const float* bias; float* dst; float* stats;
+  int B, Hs, Ws, Cs, Hd, Wd, Cd;
+  int Hq, Wq, os, oy0, ox0, sm;
+  int ncls;
+  FsTapClass cls[9];
+  int Npad, nchunk, ttot;
+  int Ph, Pw, tiles_y, tiles_x, nx, ny;
+  unsigned src_bytes, wp_bytes;
+  float drop_scale; uint32_t drop_thresh, drop_key;
+};
+
+// Wp[g = 2*T + s2][plane][n][j]: T enumerates (class, chunk, tap) in consumption order; k = 32*chunk + 16*s2 + j.
+//   forward : value = W[r][s][k][n]      bwd-data: value = W[r][s][n][k]      (w is [R][S][Cin][Cout])
+__global__ __launch_bounds__(256) void conv_tapset_pack_f16_kernel(const float* __restrict__ w, unsigned char* __restrict__ ws, int Cin, int Cout, int S,
+                                                               int transposed, int Ks, int Ns, int Npad, int nchunk, int ncls,
+                                                               FsTapClass c0, FsTapClass c1, FsTapClass c2, FsTapClass c3, FsTapClass c4,
+                                                               FsTapClass c5, FsTapClass c6, FsTapClass c7, FsTapClass c8, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const FsTapClass cls[9] = {c0, c1, c2, c3, c4, c5, c6, c7, c8};
+  const float sc = pow2f(14 - exponent_of_bits(*reinterpret_cast<const unsigned*>(ws)));
+  _Float16* wp = reinterpret_cast<_Float16*>(ws + HDR);
+  const int n = (int)(idx % Npad);
+  const int g = (int)(idx / Npad);
+  const int s2 = g & 1;
+  int T = g >> 1, r = 0, s = 0, chunk = 0;
+  for (int c = 0; c < ncls; ++c) {
+    const int nt = cls[c].nR * cls[c].nS;
+    if (T < nt * nchunk) {
+      chunk = T / nt;
+      const int tap = T - chunk * nt;
+      const int tr = tap / cls[c].nS, ts = tap - tr * cls[c].nS;
+      r = cls[c].rbase + cls[c].rstep * tr;
+      s = cls[c].sbase + cls[c].sstep * ts;
+      break;
+    }
+    T -= nt * nchunk;
+  }
+  const int k0 = chunk * 32 + s2 * 16;
+  f16x8 p[2][2];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = k0 + j;
+    float v = 0.f;
+    if (n < Ns && k < Ks) v = transposed ? w[((long)(r * S + s) * Cin + n) * Cout + k] : w[((long)(r * S + s) * Cin + k) * Cout + n];
+    _Float16 x, y;
+    split2(v * sc, x, y);
+    p[0][j >> 3][j & 7] = x; p[1][j >> 3][j & 7] = y;
+  }
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+    f16x8* o = reinterpret_cast<f16x8*>(wp + (((long)g * 2 + pl) * Npad + n) * 16);
+    o[0] = p[pl][0]; o[1] = p[pl][1];
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_tapset_f16_kernel(TsF16Args a) {
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[2 * PLANE];
+  __shared__ __attribute__((aligned(16))) int rowpix[128];
+  __shared__ unsigned amax_cell[2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nwg = a.nx * a.ny;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd = nwg >> 3, rm = nwg & 7;
+  const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+  const int mt = wg / a.ny;
+  const int n0 = (wg - mt * a.ny) * 64;
+  const int tpi = a.tiles_y * a.tiles_x;
+  const int b = mt / tpi;
+  const int trem = mt - b * tpi;
+  const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+  const int y0 = ty * a.Ph, x0 = tx * a.Pw;
+  const int npix = a.Ph * a.Pw;
+
+  // output pixel of every tile row (MFMA row order), -1 = dead row
+  if (tid < 128) {
+    const int p = (tid & ~31) + row_perm(tid & 31);
+    const int py = p / a.Pw, px = p - py * a.Pw;
+    const bool live = p < npix && y0 + py < a.Hq && x0 + px < a.Wq;
+    rowpix[tid] = live ? ((b * a.Hd + (y0 + py) * a.os + a.oy0) * a.Wd + (x0 + px) * a.os + a.ox0) : -1;
+  }
+  // A fragment rows of this lane -> patch pixel
+  int fpy[2], fpx[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int p = 64 * wm + 32 * mi + row_perm(l31);
+    const bool live = p < npix;
+    fpy[mi] = live ? p / a.Pw : 0;
+    fpx[mi] = live ? p - fpy[mi] * a.Pw : 0;
+  }
+
+  const int q = tid & 7;
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(a.src, a.src_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.ws, a.wp_bytes);
+  if (tid < 2) amax_cell[tid] = 0u;
+
+  // ---- halo loader state (runs one (class, chunk) ahead of the MFMA loop) ----
+  int goff[NITEM];
+  f32x4 ra[NITEM];
+  int pc = 0, pchunk = 0;        // (class, chunk) the registers ra hold / will hold
+  auto class_offsets = [&](int c) {
+    const int Wh = a.Pw + a.cls[c].nS - 1, nslots = (a.Ph + a.cls[c].nR - 1) * Wh;
+    const int cy = a.cls[c].cy, cx = a.cls[c].cx;
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+      const int slot = (tid >> 3) + 32 * i;
+      goff[i] = -1;
+      if (slot < nslots) {
+        const int hy = slot / Wh, hx = slot - hy * Wh;
+        const int sy = a.sm * (y0 + hy) + cy, sx = a.sm * (x0 + hx) + cx;
+        if (sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws) goff[i] = ((b * a.Hs + sy) * a.Ws + sx) * a.Cs + 4 * q;
+      }
+    }
+  };
+  auto load_halo = [&](int chunk) {
+    const int c0 = chunk * 32;
+    const bool cok = c0 + 4 * q < a.Cs;
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+      const bool ok = cok && goff[i] >= 0;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? (int)((unsigned)(goff[i] + c0) * 4u) : (int)OOB, 0, 0);
+      ra[i] = __builtin_bit_cast(f32x4, v);
+    }
+  };
+  auto tile_amax = [&](int cell) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(ra[i][e]));
+    m = wave_max(m);
+    if (lane == 0) atomicMax(&amax_cell[cell], __builtin_bit_cast(unsigned, m));
+  };
+  auto store_halo = [&](float sc) {
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+      const int slot = (tid >> 3) + 32 * i;
+      f16x4 p0, p1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { _Float16 x, y; split2(ra[i][e] * sc, x, y); p0[e] = x; p1[e] = y; }
+      const int o = slot * XLD + 4 * q;
+      *reinterpret_cast<f16x4*>(&Ah[o]) = p0;
+      *reinterpret_cast<f16x4*>(&Ah[PLANE + o]) = p1;
+    }
+  };
+
+  // ---- B fragments ----
+  const int bvoff = HDR + ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2;
+  const int plane_bytes = a.Npad * 32;
+  const int step_bytes = 2 * plane_bytes;
+  const int G = 2 * a.ttot;
+  auto load_b = [&](int g, f16x8 (&dst)[2]) {
+    const int gg = g < G ? g : G - 1;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff + gg * step_bytes + pl * plane_bytes, 0, 0);
+      dst[pl] = __builtin_bit_cast(f16x8, v);
+    }
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  f16x8 fa[2][2][2];         // [k16 step][mi][plane]
+  f16x8 fbA[2][2], fbB[2][2];
+  int E = EMIN, par = 0;
+  // MFMA-loop state
+  int c = 0, chunk = 0, tap = 0, tr = 0, ts = 0;
+  int ntaps = a.cls[0].nR * a.cls[0].nS, nS = a.cls[0].nS, Wh = a.Pw + a.cls[0].nS - 1;
+  int rowbase[2];
+  int T = 0;
+
+  auto read_a = [&](int toff, int s2, f16x8 (&dst)[2][2]) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) dst[mi][pl] = *reinterpret_cast<const f16x8*>(&Ah[pl * PLANE + rowbase[mi] + toff + 16 * s2]);
+  };
+  auto mfma6 = [&](const f16x8 (&A)[2][2], const f16x8 (&Bf)[2]) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][0], Bf[1], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][0], Bf[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][1], Bf[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][1], Bf[0], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][0], Bf[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][0], Bf[0], acc1, 0, 0, 0);
+  };
+  // one filter tap = two k16 steps; `cur` holds this tap's B fragments, `nxt` receives the next tap's
+  auto tap_body = [&](f16x8 (&cur)[2][2], f16x8 (&nxt)[2][2]) {
+    if (tap == 0) {                      // first tap of a (class, chunk): refill LDS
+      if (chunk == 0) {
+        ntaps = a.cls[c].nR * a.cls[c].nS; nS = a.cls[c].nS; Wh = a.Pw + nS - 1;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) rowbase[mi] = (fpy[mi] * Wh + fpx[mi]) * XLD + 8 * lh;
+      }
+      tile_amax(par);
+      __syncthreads();                      // amax complete; every wave has finished reading the previous image
+      const int ec = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[par]));
+      if (ec > E) {
+        const float f = pow2f(E - ec);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] *= f; acc1[r] *= f; }
+        E = ec;
+      }
+      store_halo(pow2f(14 - E));
+      par ^= 1;
+      if (tid == 0) amax_cell[par] = 0u;
+      __syncthreads();
+      if (++pchunk == a.nchunk) { pchunk = 0; ++pc; if (pc < a.ncls) class_offsets(pc); }
+      if (pc < a.ncls) load_halo(pchunk);
+      tr = 0; ts = 0;
+      read_a(0, 0, fa[0]);
+    }
+    const int toff = (tr * Wh + ts) * XLD;
+    // step 0
+    read_a(toff, 1, fa[1]);
+    load_b(2 * T + 2, nxt[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(fa[0], cur[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    // step 1
+    int ntr = tr, nts = ts + 1;
+    if (nts == nS) { nts = 0; ++ntr; }
+    if (tap + 1 < ntaps) read_a((ntr * Wh + nts) * XLD, 0, fa[0]);
+    load_b(2 * T + 3, nxt[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(fa[1], cur[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    tr = ntr; ts = nts;
+    ++T;
+    if (++tap == ntaps) { tap = 0; if (++chunk == a.nchunk) { chunk = 0; ++c; } }
+  };
+
+  if (a.ttot > 0) {
+    load_b(0, fbA[0]);
+    load_b(1, fbA[1]);
+    class_offsets(0);
+    load_halo(0);
+    __syncthreads();                        // amax cells zeroed before the first atomic
+    while (T < a.ttot) {
+      tap_body(fbA, fbB);
+      if (T < a.ttot) tap_body(fbB, fbA);
+    }
+  }
+  __syncthreads();     // rowpix visible (and all LDS reads done before the stats scratch reuse)
+
+  // ---- epilogue ----
+  const int n = n0 + 32 * wn + l31;
+  float csum = 0.f, csq = 0.f;
+  if (n < a.Cd) {
+    const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
+    const int Ew = exponent_of_bits(*reinterpret_cast<const unsigned*>(a.ws));
+    const float f1 = pow2f(E - 14), f2 = pow2f(Ew - 14);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const i32x4 pix = *reinterpret_cast<const i32x4*>(&rowpix[64 * wm + 32 * mi + 8 * rg + 4 * lh]);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+          if (pix[ri] < 0) continue;
+          const int r = 4 * rg + ri;
+          float v = (mi == 0 ? acc0[r] : acc1[r]) * f1 * f2 + bv;
+          const long e = (long)pix[ri] * a.Cd + n;
+          if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+          a.dst[e] = v;
+          csum += v; csq += v * v;
+        }
+      }
+    }
+  }
+  if (a.stats != nullptr) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&Ah[0]);     // [wm][64 cols][2]
+    const float s1 = csum + __shfl_xor(csum, 32, 64), s2 = csq + __shfl_xor(csq, 32, 64);
+    if (lh == 0) { red[(wm * 64 + 32 * wn + l31) * 2] = s1; red[(wm * 64 + 32 * wn + l31) * 2 + 1] = s2; }
+    __syncthreads();
+    if (tid < 128) {
+      const int col = tid >> 1, which = tid & 1;
+      const float v = red[col * 2 + which] + red[(64 + col) * 2 + which];
+      if (n0 + col < a.Cd) a.stats[((long)mt * a.Cd + n0 + col) * 2 + which] = v;
+    }
+  }
+}
+
+}  // namespace
+
+long fs_tapset_f16_pack_bytes(int Cs, int Cd, int total_taps) {
+  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 63) / 64) * 64;
+  return HDR + nchunk * total_taps * 2 * 2 * Npad * 16 * 2;
+}
+
+int fs_tapset_f16_conv(const FsTapsetProblem& p, hipStream_t stream) {
+  TsF16Args a;
+  a.src = p.src; a.ws = reinterpret_cast<const unsigned char*>(p.ws); a.bias = p.bias; a.dst = p.dst; a.stats = p.stats;
+  a.B = p.B; a.Hs = p.Hs; a.Ws = p.Ws; a.Cs = p.Cs; a.Hd = p.Hd; a.Wd = p.Wd; a.Cd = p.Cd;
+  a.Hq = p.Hq; a.Wq = p.Wq; a.os = p.os; a.oy0 = p.oy0; a.ox0 = p.ox0; a.sm = p.sm;
+  a.ncls = p.ncls;
+  int maxR = 1, maxS = 1, total_taps = 0;
+  for (int c = 0; c < 9; ++c) {
+    a.cls[c] = c < p.ncls ? p.cls[c] : FsTapClass{0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < p.ncls) {
+      if (p.cls[c].nR < 1 || p.cls[c].nS < 1) return FS_ERR_ARG;
+      if (p.cls[c].nR > maxR) maxR = p.cls[c].nR;
+      if (p.cls[c].nS > maxS) maxS = p.cls[c].nS;
+      total_taps += p.cls[c].nR * p.cls[c].nS;
+    }
+  }
+  if (p.ncls < 1 || p.ncls > 9 || total_taps < 1) return FS_ERR_ARG;
+  a.Npad = ((p.Cd + 63) / 64) * 64;
+  a.nchunk = (p.Cs + 31) / 32;
+  a.ttot = a.nchunk * total_taps;
+  fs_tapset_patch(p.Hq, p.Wq, maxR, maxS, &a.Ph, &a.Pw);
+  if ((a.Ph + maxR - 1) * (a.Pw + maxS - 1) > NSMAX) return FS_ERR_ARG;
+  a.tiles_y = cdiv(p.Hq, a.Ph); a.tiles_x = cdiv(p.Wq, a.Pw);
+  a.nx = p.B * a.tiles_y * a.tiles_x;
+  a.ny = a.Npad / 64;
+  const long pack_bytes = fs_tapset_f16_pack_bytes(p.Cs, p.Cd, total_taps);
+  if (pack_bytes >= 2147483647L || (size_t)p.B * p.Hs * p.Ws * p.Cs * 4 >= 4294967000UL || (long)p.B * p.Hd * p.Wd >= 2147483647L)
+    return FS_ERR_ARG;
+  a.src_bytes = (unsigned)((size_t)p.B * p.Hs * p.Ws * p.Cs * 4);
+  a.wp_bytes = (unsigned)pack_bytes;
+  a.drop_scale = p.drop_scale; a.drop_thresh = p.drop_thresh; a.drop_key = p.drop_key;
+  int e = fs_f16_weight_amax(p.w, (long)p.R * p.S * p.Cin * p.Cout, p.ws, stream);
+  if (e != FS_OK) return e;
+  const long total = (long)a.ttot * 2 * a.Npad;
+  hipLaunchKernelGGL(conv_tapset_pack_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.w,
+                     reinterpret_cast<unsigned char*>(p.ws), p.Cin, p.Cout, p.S, p.transposed, p.Cs, p.Cd, a.Npad, a.nchunk, a.ncls, a.cls[0],
+                     a.cls[1], a.cls[2], a.cls[3], a.cls[4], a.cls[5], a.cls[6], a.cls[7], a.cls[8], total);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(conv_tapset_f16_kernel, dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
