@@ -46,6 +46,7 @@ struct ConvArgs {
   float* stats_ = nullptr;          // host only: BN partial-sum slab (affine forward)
   void* ws_ = nullptr;              // host only: caller's scratch for the pre-split weight pack (may be null)
   long ws_bytes_ = 0;
+  const unsigned* w_amax_ = nullptr;   // host only: max|w| bits kept by the caller (f16x2 mode), may be null
 };
 
 template <bool VEC>
@@ -939,7 +940,7 @@ bool use_tapset(const ConvArgs& c) {
 int run_tapset(const FsTapsetProblem& p, hipStream_t stream) { return g_conv_precision == 2 ? fs_tapset_f16_conv(p, stream) : fs_tapset_conv(p, stream); }
 FsTapsetProblem tapset_base(const ConvArgs& c) {
   FsTapsetProblem p{};
-  p.src = c.src; p.w = c.w; p.bias = c.bias; p.dst = c.dst; p.stats = c.stats_; p.ws = c.ws_;
+  p.src = c.src; p.w = c.w; p.bias = c.bias; p.dst = c.dst; p.stats = c.stats_; p.ws = c.ws_; p.w_amax = c.w_amax_;
   p.B = c.B; p.Hs = c.Hs; p.Ws = c.Ws; p.Cs = c.Cs; p.Hd = c.Hd; p.Wd = c.Wd; p.Cd = c.Cd;
   p.Cin = c.transposed ? c.Cd : c.Cs; p.Cout = c.transposed ? c.Cs : c.Cd; p.R = c.R; p.S = c.S;
   p.transposed = c.transposed;
@@ -973,7 +974,7 @@ int launch_affine(const ConvArgs& c, long M) {
     return run_tapset(p, c.stream_);
   }
   if (use_halo(c) && g_conv_precision == 2)
-    return fs_halo_f16_conv3x3(c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.B, c.Hd, c.Wd, c.Cs, c.Cd, c.transposed ? c.Cd : c.Cs,
+    return fs_halo_f16_conv3x3(c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cs, c.Cd, c.transposed ? c.Cd : c.Cs,
                                c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key, c.stream_);
   if (use_halo(c))
     return fs_halo_conv3x3(c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.B, c.Hd, c.Wd, c.Cs, c.Cd, c.transposed ? c.Cd : c.Cs,
@@ -1022,6 +1023,12 @@ int fs_set_conv_precision(int mode) {
 }
 int fs_get_conv_precision(void) { return g_conv_precision; }
 
+// include/fovealseg.h: fs_weight_amax_segments -- max|w| (float bits) of nparams tensors laid out in one arena, one launch.
+int fs_weight_amax_segments(const float* arena, const long* offsets, const long* sizes, int nparams, unsigned* out, hipStream_t stream) {
+  FS_REQUIRE(arena && offsets && sizes && out && nparams > 0 && nparams <= 65535);
+  return fs_weight_amax_segments_impl(arena, offsets, sizes, nparams, out, stream);
+}
+
 // include/fovealseg.h: fs_conv2d_workspace_bytes -- scratch the conv entry points can use for this shape (0 = none).
 // transposed = 0 for fs_conv2d_fwd / fs_conv2d_fwd_stats, 1 for fs_conv2d_bwd_data.
 long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, int transposed) {
@@ -1053,13 +1060,13 @@ int fs_conv2d_stats_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout
 // include/fovealseg.h: fs_conv2d_fwd
 int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin,
                   int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key,
-                  void* ws, long ws_bytes, hipStream_t stream) {
+                  void* ws, long ws_bytes, const unsigned* w_amax, hipStream_t stream) {
   FS_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
   FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
   FS_REQUIRE(drop_p >= 0.f && drop_p < 1.f);
   ConvArgs a{x, w, bias, y, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0, 1.f, 0u, drop_key};
   a.stream_ = stream;
-  a.ws_ = ws; a.ws_bytes_ = ws_bytes;
+  a.ws_ = ws; a.ws_bytes_ = ws_bytes; a.w_amax_ = w_amax;
   if (drop_p > 0.f) {
     a.drop_scale = 1.0f / (float)(1.0 - (double)drop_p);
     a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
@@ -1081,7 +1088,7 @@ int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, i
 // stats = [ceil(B*Ho*Wo/128)][Cout][2] floats.  Requires Cin%4==0 && Cout%4==0 (the affine kernel).
 int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* stats, int B, int H, int W, int Cin,
                         int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key,
-                        void* ws, long ws_bytes, hipStream_t stream) {
+                        void* ws, long ws_bytes, const unsigned* w_amax, hipStream_t stream) {
   FS_REQUIRE(x && w && y && stats && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
   FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
   FS_REQUIRE(drop_p >= 0.f && drop_p < 1.f);
@@ -1089,7 +1096,7 @@ int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float
   ConvArgs a{x, w, bias, y, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0, 1.f, 0u, drop_key};
   a.stream_ = stream;
   a.stats_ = stats;
-  a.ws_ = ws; a.ws_bytes_ = ws_bytes;
+  a.ws_ = ws; a.ws_bytes_ = ws_bytes; a.w_amax_ = w_amax;
   if (drop_p > 0.f) {
     a.drop_scale = 1.0f / (float)(1.0 - (double)drop_p);
     a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
@@ -1101,14 +1108,14 @@ int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float
 
 // include/fovealseg.h: fs_conv2d_bwd_data   (dX has the forward input's shape B,H,W,Cin)
 int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
-                       int Cout, int R, int S, int stride, int pad, int dil, void* ws, long ws_bytes, hipStream_t stream) {
+                       int Cout, int R, int S, int stride, int pad, int dil, void* ws, long ws_bytes, const unsigned* w_amax, hipStream_t stream) {
   FS_REQUIRE(dy && w && dx && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
   FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
   ConvArgs a{dy, w, nullptr, dx, B, Ho, Wo, Cout, H, W, Cin, R, S, stride, pad, dil, 1, 1.f, 0u, 0u};
   FS_REQUIRE(stride == 1 || dil == 1);
   const long M = (long)B * H * W;
   a.stream_ = stream;
-  a.ws_ = ws; a.ws_bytes_ = ws_bytes;
+  a.ws_ = ws; a.ws_bytes_ = ws_bytes; a.w_amax_ = w_amax;
   if ((Cin % 4 == 0) && (Cout % 4 == 0) && R * S <= 32 && (long)B * Ho * Wo * Cout < 2147483647L)
     return launch_affine(a, M);
   dim3 grid(cdiv(M, BM), cdiv(Cin, BN));

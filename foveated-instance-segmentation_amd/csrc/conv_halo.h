@@ -20,9 +20,9 @@ int fs_halo_conv3x3(const float* src, const float* w, const float* bias, float* 
 void fs_halo_patch(int H, int W, int* Ph, int* Pw);
 // conv_halo_f16.hip: the same convolution in f16x2 split precision (3 fp16 MFMAs per product, scaled operands)
 long fs_halo_f16_pack_bytes(int Cs, int Cd);
-int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, int B, int H, int W,
-                        int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,
-                        hipStream_t stream);
+int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
+                        int B, int H, int W, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh,
+                        uint32_t drop_key, hipStream_t stream);
 
 // conv_wgrad_x3.hip: split-precision weight gradient of a 3x3 / stride-1 / pad-1 convolution (dw must be zeroed).
 bool fs_wgrad_x3_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil);
@@ -34,7 +34,7 @@ int fs_wgrad_f16(const float* x, const float* dy, float* dw, int B, int H, int W
 //   source row of (loop row oy, class tap tr) = sm*(oy + tr) + cy,  filter row r = rbase + rstep*tr  (columns alike)
 struct FsTapClass { int cy, cx, nR, nS, rbase, rstep, sbase, sstep; };
 struct FsTapsetProblem {
-  const float* src; const float* w; const float* bias; float* dst; float* stats; void* ws;
+  const float* src; const float* w; const float* bias; float* dst; float* stats; void* ws; const unsigned* w_amax;
   int B, Hs, Ws, Cs, Hd, Wd, Cd;     // source / destination tensors (NHWC)
   int Cin, Cout, R, S;               // logical weight shape [R][S][Cin][Cout]
   int transposed;                    // 0: K = Cin, N = Cout;  1 (bwd-data): K = Cout, N = Cin
@@ -49,5 +49,7 @@ void fs_tapset_patch(int Hq, int Wq, int maxR, int maxS, int* Ph, int* Pw);
 // conv_tapset_f16.hip: the same in f16x2 split precision
 long fs_tapset_f16_pack_bytes(int Cs, int Cd, int total_taps);
 int fs_tapset_f16_conv(const FsTapsetProblem& p, hipStream_t stream);
-// conv_halo_f16.hip: max |w| of a weight tensor as float bits into the first word of ws (memset + atomic-max kernel)
-int fs_f16_weight_amax(const float* w, long n, void* ws, hipStream_t stream);
+// conv_halo_f16.hip: where the kernels read max |w| (float bits) of a weight tensor: w_amax when the caller maintains it,
+// else the first word of ws, filled here by a memset + atomic-max kernel.
+const unsigned* fs_f16_weight_amax(const float* w, long n, void* ws, const unsigned* w_amax, hipStream_t stream, int* err);
+int fs_weight_amax_segments_impl(const float* arena, const long* offsets, const long* sizes, int nparams, unsigned* out, hipStream_t stream);

@@ -51,7 +51,7 @@ __device__ __forceinline__ int row_perm(int l) {       // see conv_halo.hip
 }
 
 struct HaloF16Args {
-  const float* src; const unsigned char* ws; const float* bias; float* dst; float* stats;
+  const float* src; const unsigned char* ws; const unsigned* ew; const float* bias; float* dst; float* stats;
   int B, H, W, Cs, Cd, Npad, nchunk;
   int Ph, Pw, tiles_y, tiles_x;
   int nx, ny;
@@ -68,11 +68,11 @@ __global__ __launch_bounds__(256) void conv_f16_amax_kernel(const float* __restr
 }
 
 // Wp[g = (chunk*9 + tap)*2 + s][plane][n][j] (fp16, scaled by 2^(14-Ew)); layout as conv_pack_x3_kernel with 2 planes.
-__global__ __launch_bounds__(256) void conv_pack_f16_kernel(const float* __restrict__ w, unsigned char* __restrict__ ws, int Cin, int Cout,
+__global__ __launch_bounds__(256) void conv_pack_f16_kernel(const float* __restrict__ w, unsigned char* __restrict__ ws, const unsigned* __restrict__ ew, int Cin, int Cout,
                                                             int transposed, int Ks, int Ns, int Npad, long total) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
-  const float sc = pow2f(14 - exponent_of_bits(*reinterpret_cast<const unsigned*>(ws)));
+  const float sc = pow2f(14 - exponent_of_bits(*ew));
   _Float16* wp = reinterpret_cast<_Float16*>(ws + HDR);
   const int n = (int)(idx % Npad);
   const int g = (int)(idx / Npad);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
   float csum = 0.f, csq = 0.f;
   if (n < a.Cd) {
     const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
-    const int Ew = exponent_of_bits(*reinterpret_cast<const unsigned*>(a.ws));
+    const int Ew = exponent_of_bits(*a.ew);
     const float f1 = pow2f(E - 14), f2 = pow2f(Ew - 14);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -290,11 +290,33 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
 
 }  // namespace
 
-int fs_f16_weight_amax(const float* w, long n, void* ws, hipStream_t stream) {
+const unsigned* fs_f16_weight_amax(const float* w, long n, void* ws, const unsigned* w_amax, hipStream_t stream, int* err) {
+  *err = FS_OK;
+  if (w_amax != nullptr) return w_amax;          // the caller keeps max|w| of this tensor up to date (fs_weight_amax_segments)
   hipError_t e = hipMemsetAsync(ws, 0, 4, stream);
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) { *err = (int)e; return nullptr; }
   int ab = cdiv(n, 256 * 8); if (ab > 256) ab = 256;
   hipLaunchKernelGGL(conv_f16_amax_kernel, dim3(ab), dim3(256), 0, stream, w, n, reinterpret_cast<unsigned*>(ws));
+  if (hipGetLastError() != hipSuccess) { *err = FS_ERR_ARG; return nullptr; }
+  return reinterpret_cast<const unsigned*>(ws);
+}
+
+// max|w| bits of every parameter of a flat arena in one launch: block (p, j) strides over parameter p
+__global__ __launch_bounds__(256) void weight_amax_segments_kernel(const float* __restrict__ arena, const long* __restrict__ offsets,
+                                                                   const long* __restrict__ sizes, unsigned* __restrict__ out) {
+  const int p = blockIdx.x;
+  const float* w = arena + offsets[p];
+  const long n = sizes[p];
+  float m = 0.f;
+  for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < n; i += (long)gridDim.y * 256) m = fmaxf(m, fabsf(w[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&out[p], __builtin_bit_cast(unsigned, m));
+}
+
+int fs_weight_amax_segments_impl(const float* arena, const long* offsets, const long* sizes, int nparams, unsigned* out, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned) * (size_t)nparams, stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(weight_amax_segments_kernel, dim3(nparams, 8), dim3(256), 0, stream, arena, offsets, sizes, out);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -304,9 +326,9 @@ long fs_halo_f16_pack_bytes(int Cs, int Cd) {
   return HDR + nchunk * 18 * 2 * Npad * 16 * 2;
 }
 
-int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, int B, int H, int W,
-                        int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,
-                        hipStream_t stream) {
+int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
+                        int B, int H, int W, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh,
+                        uint32_t drop_key, hipStream_t stream) {
   HaloF16Args a;
   a.src = src; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = dst; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cs = Cs; a.Cd = Cd;
@@ -321,11 +343,12 @@ int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, flo
   if (pack_bytes >= 2147483647L || (size_t)B * H * W * Cs * 4 >= 4294967000UL) return FS_ERR_ARG;
   a.ws_bytes = (unsigned)pack_bytes;
   a.drop_scale = drop_scale; a.drop_thresh = drop_thresh; a.drop_key = drop_key;
-  int e = fs_f16_weight_amax(w, (long)9 * Cin * Cout, ws, stream);
+  int e = FS_OK;
+  a.ew = fs_f16_weight_amax(w, (long)9 * Cin * Cout, ws, w_amax, stream, &e);
   if (e != FS_OK) return e;
   const long total = (long)a.nchunk * 18 * a.Npad;
   hipLaunchKernelGGL(conv_pack_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws),
-                     Cin, Cout, transposed, Cs, Cd, a.Npad, total);
+                     a.ew, Cin, Cout, transposed, Cs, Cd, a.Npad, total);
   FS_LAUNCH_CHECK();
   hipLaunchKernelGGL(conv3x3_halo_f16_kernel, dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();

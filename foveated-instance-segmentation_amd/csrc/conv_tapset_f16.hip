@@ -41,7 +41,7 @@ __device__ __forceinline__ int row_perm(int l) {
 }
 
 struct TsF16Args {
-  const float* src; const unsigned char* ws; const float* bias; float* dst; float* stats;
+  const float* src; const unsigned char* ws; const unsigned* ew; const float* bias; float* dst; float* stats;
   int B, Hs, Ws, Cs, Hd, Wd, Cd;
   int Hq, Wq, os, oy0, ox0, sm;
   int ncls;
@@ -54,14 +54,14 @@ struct TsF16Args {
 
 // Wp[g = 2*T + s2][plane][n][j]: T enumerates (class, chunk, tap) in consumption order; k = 32*chunk + 16*s2 + j.
 //   forward : value = W[r][s][k][n]      bwd-data: value = W[r][s][n][k]      (w is [R][S][Cin][Cout])
-__global__ __launch_bounds__(256) void conv_tapset_pack_f16_kernel(const float* __restrict__ w, unsigned char* __restrict__ ws, int Cin, int Cout, int S,
+__global__ __launch_bounds__(256) void conv_tapset_pack_f16_kernel(const float* __restrict__ w, unsigned char* __restrict__ ws, const unsigned* __restrict__ ew, int Cin, int Cout, int S,
                                                                int transposed, int Ks, int Ns, int Npad, int nchunk, int ncls,
                                                                FsTapClass c0, FsTapClass c1, FsTapClass c2, FsTapClass c3, FsTapClass c4,
                                                                FsTapClass c5, FsTapClass c6, FsTapClass c7, FsTapClass c8, long total) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const FsTapClass cls[9] = {c0, c1, c2, c3, c4, c5, c6, c7, c8};
-  const float sc = pow2f(14 - exponent_of_bits(*reinterpret_cast<const unsigned*>(ws)));
+  const float sc = pow2f(14 - exponent_of_bits(*ew));
   _Float16* wp = reinterpret_cast<_Float16*>(ws + HDR);
   const int n = (int)(idx % Npad);
   const int g = (int)(idx / Npad);
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void conv_tapset_f16_kernel(TsF16Args a) {
   float csum = 0.f, csq = 0.f;
   if (n < a.Cd) {
     const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
-    const int Ew = exponent_of_bits(*reinterpret_cast<const unsigned*>(a.ws));
+    const int Ew = exponent_of_bits(*a.ew);
     const float f1 = pow2f(E - 14), f2 = pow2f(Ew - 14);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -364,11 +364,12 @@ int fs_tapset_f16_conv(const FsTapsetProblem& p, hipStream_t stream) {
   a.src_bytes = (unsigned)((size_t)p.B * p.Hs * p.Ws * p.Cs * 4);
   a.wp_bytes = (unsigned)pack_bytes;
   a.drop_scale = p.drop_scale; a.drop_thresh = p.drop_thresh; a.drop_key = p.drop_key;
-  int e = fs_f16_weight_amax(p.w, (long)p.R * p.S * p.Cin * p.Cout, p.ws, stream);
+  int e = FS_OK;
+  a.ew = fs_f16_weight_amax(p.w, (long)p.R * p.S * p.Cin * p.Cout, p.ws, p.w_amax, stream, &e);
   if (e != FS_OK) return e;
   const long total = (long)a.ttot * 2 * a.Npad;
   hipLaunchKernelGGL(conv_tapset_pack_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.w,
-                     reinterpret_cast<unsigned char*>(p.ws), p.Cin, p.Cout, p.S, p.transposed, p.Cs, p.Cd, a.Npad, a.nchunk, a.ncls, a.cls[0],
+                     reinterpret_cast<unsigned char*>(p.ws), a.ew, p.Cin, p.Cout, p.S, p.transposed, p.Cs, p.Cd, a.Npad, a.nchunk, a.ncls, a.cls[0],
                      a.cls[1], a.cls[2], a.cls[3], a.cls[4], a.cls[5], a.cls[6], a.cls[7], a.cls[8], total);
   FS_LAUNCH_CHECK();
   hipLaunchKernelGGL(conv_tapset_f16_kernel, dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);

@@ -29,9 +29,10 @@ SIGNATURES = {
     "fs_grid_sample_bwd_grid": "ppppiiiiiii",
     "fs_grid_sample_bwd_input": "pppiiiiiii",
     "fs_inverse_index_maps": "ppplii",
-    "fs_conv2d_fwd": "ppppiiiiiiiiiiiifupl",
-    "fs_conv2d_fwd_stats": "pppppiiiiiiiiiiiifupl",
-    "fs_conv2d_bwd_data": "pppiiiiiiiiiiiipl",
+    "fs_conv2d_fwd": "ppppiiiiiiiiiiiifuplp",
+    "fs_conv2d_fwd_stats": "pppppiiiiiiiiiiiifuplp",
+    "fs_conv2d_bwd_data": "pppiiiiiiiiiiiiplp",
+    "fs_weight_amax_segments": "pppip",
     "fs_conv2d_bwd_weight": "pppiiiiiiiiiiii",
     "fs_bn_stats": "pliffppppp",
     "fs_bn_finalize_slab": "piliffpppp",

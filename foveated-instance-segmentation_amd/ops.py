@@ -117,7 +117,16 @@ def _conv_kind(Cs, Cd, R, S, stride, pad, dil):
     return "conv_affine"
 
 
-def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1):
+def weight_amax(w):
+    """Device word holding max|w| bits of parameter w if its optimiser keeps one and w has not been modified since
+    (train.FlatParams.refresh_amax), else None: the library then reduces over the weights itself."""
+    rec = getattr(w, "_fs_amax", None)
+    if rec is None or rec[1] != w._version:
+        return None
+    return rec[0]
+
+
+def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1, w_amax=None):
     B, H, W, Cin = x.shape
     Cout, Cin2, R, S = w.shape
     assert Cin == Cin2, (x.shape, w.shape)
@@ -126,7 +135,8 @@ def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1):
     kind = _conv_kind(Cin, Cout, R, S, stride, pad, dil)
     ws, ws_bytes = _conv_workspace(x.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0)
     _launch(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd", hip.ptr(x), hip.ptr(rsck(w)), hip.ptr(bias),
-            hip.ptr(y), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, float(drop_p), int(drop_key), hip.ptr(ws), ws_bytes)
+            hip.ptr(y), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, float(drop_p), int(drop_key), hip.ptr(ws), ws_bytes,
+            hip.ptr(w_amax))
     return y
 
 
@@ -141,7 +151,7 @@ def _conv_workspace(device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, tra
 FUSE_BN_STATS = True     # BatchNorm batch statistics come out of the conv epilogue (fs_conv2d_fwd_stats)
 
 
-def conv2d_fwd_stats(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1):
+def conv2d_fwd_stats(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1, w_amax=None):
     """Forward conv + per-workgroup BatchNorm partial sums (slab [nwg][Cout][2])."""
     B, H, W, Cin = x.shape
     Cout, Cin2, R, S = w.shape
@@ -153,11 +163,11 @@ def conv2d_fwd_stats(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1):
     slab = torch.empty(nwg * Cout * 2, device=x.device, dtype=torch.float32)
     _launch(_conv_kind(Cin, Cout, R, S, stride, pad, dil), 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd_stats", hip.ptr(x), hip.ptr(rsck(w)),
             hip.ptr(bias), hip.ptr(y), hip.ptr(slab), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, float(drop_p), int(drop_key),
-            hip.ptr(ws), ws_bytes)
+            hip.ptr(ws), ws_bytes, hip.ptr(w_amax))
     return y, slab, nwg
 
 
-def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1):
+def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1, w_amax=None):
     B, H, W, Cin = x_shape
     Cout, _, R, S = w.shape
     _, Ho, Wo, _ = dy.shape
@@ -165,7 +175,7 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1):
     kind = _conv_kind(Cout, Cin, R, S, stride, pad, dil)
     ws, ws_bytes = _conv_workspace(dy.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 1)
     _launch(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx),
-            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, hip.ptr(ws), ws_bytes)
+            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, hip.ptr(ws), ws_bytes, hip.ptr(w_amax))
     return dx
 
 
@@ -218,10 +228,11 @@ class ConvBnAct(Function):
         Cout, Cin = w.shape[0], w.shape[1]
         fused_stats = training and FUSE_BN_STATS and Cin % 4 == 0 and Cout % 4 == 0
         dil = meta.get("dil", 1)
+        wa = weight_amax(w)
         if fused_stats:
-            y, slab, nwg = conv2d_fwd_stats(x, w, bias, meta["stride"], meta["pad"], drop_p, meta["drop_key"], dil)
+            y, slab, nwg = conv2d_fwd_stats(x, w, bias, meta["stride"], meta["pad"], drop_p, meta["drop_key"], dil, w_amax=wa)
         else:
-            y = conv2d_fwd(x, w, bias, meta["stride"], meta["pad"], drop_p, meta["drop_key"], dil)
+            y = conv2d_fwd(x, w, bias, meta["stride"], meta["pad"], drop_p, meta["drop_key"], dil, w_amax=wa)
         B, Ho, Wo, C = y.shape
         M = B * Ho * Wo
         mean = torch.empty(C, device=y.device, dtype=torch.float32)
@@ -247,6 +258,7 @@ class ConvBnAct(Function):
                         drop_key=meta["drop_key"], has_bias=bias is not None, has_res=res is not None)
         ctx.save_for_backward(x, w, gamma, y, z if amask is None else None, mean, invstd, amask)
         ctx.beta_ref = beta
+        ctx.w_amax = wa          # the weights do not change between this forward and its backward
         return z
 
     @staticmethod
@@ -266,7 +278,7 @@ class ConvBnAct(Function):
         hip.call("fs_bn_act_bwd", hip.ptr(dz), hip.ptr(z), hip.ptr(amask), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), M, C,
                  m["act"], 1 if m["training"] else 0, float(m["drop_p"]), int(m["drop_key"]), hip.ptr(dy), hip.ptr(dres),
                  hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums))
-        dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"]) if ctx.needs_input_grad[0] else None
+        dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax) if ctx.needs_input_grad[0] else None
         tgt = _direct_grad_target(w)
         dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"])
         if tgt is not None:

@@ -44,6 +44,22 @@ class FlatParams:
             p.grad = self.grad.as_strided(size, dense, o)
             del stride
         self.offsets = offs
+        # max|w| bits per parameter, kept current by refresh_amax(): the f16x2 conv kernels scale the weights by it
+        self.amax = torch.zeros(len(self.params), device=dev, dtype=torch.int32)
+        self._offs_dev = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self._sizes_dev = torch.tensor([p.numel() for p in self.params], dtype=torch.int64, device=dev)
+        self._amax_words = [self.amax[i:i + 1] for i in range(len(self.params))]
+        self.refresh_amax()
+
+    def refresh_amax(self):
+        """One launch: max|w| of every parameter of the arena.  Parameters remember their word and the torch version counter
+        at this moment (ops.weight_amax drops the word if the tensor is modified through torch afterwards)."""
+        if not self.data.is_cuda:
+            return
+        hip.call("fs_weight_amax_segments", hip.ptr(self.data), hip.ptr(self._offs_dev), hip.ptr(self._sizes_dev), len(self.params),
+                 hip.ptr(self.amax))
+        for i, p in enumerate(self.params):
+            p._fs_amax = (self._amax_words[i], p._version)
 
     @staticmethod
     def _dense_strides(p):
@@ -91,6 +107,7 @@ class FlatAdam:
         hip.call("fs_adam_step", hip.ptr(self.flat.data), hip.ptr(self.flat.grad), hip.ptr(self.m), hip.ptr(self.v),
                  self.flat.numel, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                  float(g["weight_decay"]), self.t, float(self.grad_scale))
+        self.flat.refresh_amax()
 
     def state_dict(self):
         return dict(t=self.t, m=self.m, v=self.v, param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
@@ -167,6 +184,7 @@ def broadcast_parameters(optimizers, module=None, src=0):
         return
     for opt in optimizers:
         dist.broadcast(opt.flat.data, src=src)
+        opt.flat.refresh_amax()          # the arena was rewritten behind the parameters' version counters
     if module is not None:
         for b in module.buffers():
             if b.dtype.is_floating_point:

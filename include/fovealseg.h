@@ -75,22 +75,27 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
 /* Number of [Cout][2] partial-sum slabs fs_conv2d_fwd_stats writes for this shape given ws_bytes of scratch. */
 int fs_conv2d_stats_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                           long ws_bytes);
+/* max|w| as float bits for each of nparams weight tensors stored in one arena (tensor p = sizes[p] floats at arena + offsets[p]),
+ * one launch.  A caller that keeps this up to date (train.FlatAdam does, after every step) hands &out[p] to the conv entry points
+ * as w_amax and saves them the per-call reduction over the weights that the f16x2 mode needs for its weight scale. */
+int fs_weight_amax_segments(const float* arena, const long* offsets, const long* sizes, int nparams, unsigned* out, fs_stream_t stream);
 /* F.conv2d(x, w, bias, stride, pad, dilation=dil) [+ Dropout(drop_p) keyed by drop_key when drop_p > 0].
  * ws / ws_bytes: caller-owned scratch (see fs_conv2d_workspace_bytes), may be NULL / 0.
+ * w_amax: device pointer to max|w| (float bits) of this weight tensor, or NULL (then it is computed per call when needed).
  * models/hrnetv2_nodownsp.py:49-50,54-55 and every nn.Conv2d on the path. */
 int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Ho, int Wo,
                   int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key, void* ws, long ws_bytes,
-                  fs_stream_t stream);
+                  const unsigned* w_amax, fs_stream_t stream);
 /* Same forward conv, additionally writing per-workgroup BatchNorm partial sums of the stored output into
  * stats = [fs_conv2d_stats_slabs(...)][Cout][2] floats (needs Cin%4==0 && Cout%4==0); finalise with
  * fs_bn_finalize_slab.  Fuses the statistics pass of F.batch_norm(training=True)
  * (lib/nn/modules/batchnorm.py:58-61) into the conv. */
 int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* stats, int B, int H, int W, int Cin,
                         int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key,
-                        void* ws, long ws_bytes, fs_stream_t stream);
+                        void* ws, long ws_bytes, const unsigned* w_amax, fs_stream_t stream);
 /* convolution_backward: input gradient / weight gradient (dw overwritten). */
 int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R,
-                       int S, int stride, int pad, int dil, void* ws, long ws_bytes, fs_stream_t stream);
+                       int S, int stride, int pad, int dil, void* ws, long ws_bytes, const unsigned* w_amax, fs_stream_t stream);
 int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
                          int R, int S, int stride, int pad, int dil, fs_stream_t stream);
 

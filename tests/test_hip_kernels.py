@@ -141,7 +141,7 @@ def test_conv_rejects_bad_shapes():
     w = ops.new_rsck_weight(4, 4, 3, 3, device=DEV)
     y = torch.zeros(1, 5, 5, 4, device=DEV)       # wrong output size
     with pytest.raises(fovealseg.hip.HipLibraryError):
-        fovealseg.hip.call("fs_conv2d_fwd", x.data_ptr(), ops.rsck(w).data_ptr(), None, y.data_ptr(), 1, 4, 4, 4, 5, 5, 4, 3, 3, 1, 1, 1, 0.0, 0, None, 0)
+        fovealseg.hip.call("fs_conv2d_fwd", x.data_ptr(), ops.rsck(w).data_ptr(), None, y.data_ptr(), 1, 4, 4, 4, 5, 5, 4, 3, 3, 1, 1, 1, 0.0, 0, None, 0, None)
     with pytest.raises(fovealseg.hip.HipLibraryError):
         ops.conv2d_fwd(torch.zeros(1, 4, 4, 4), w, None, 1, 1)   # CPU tensor: no fallback
 
