@@ -189,7 +189,7 @@ def main():
                         peak, f"conv_wgrad3x3_{tag}_kernel")
                 if "conv_affine" in summ:
                     line["roofline_other_convs"] = entry(
-                        summ["conv_affine"], "conv_tapset_x3_kernel / conv_igemm_x3_kernel (strided 3x3 and 1x1 forward + bwd-data, bf16x3)",
+                        summ["conv_affine"], f"conv_tapset_{tag}_kernel (strided 3x3 forward + bwd-data sub-problems) + conv_igemm_x3_kernel (1x1 and single-tap sub-problems, bf16x3); peak quoted for bf16x3",
                         PEAK_BF16_MFMA_TFLOPS / 6.0, "conv_igemm_x3_kernel")
             elif "conv_affine" in summ:
                 line["roofline"] = entry(summ["conv_affine"], "conv_igemm_affine_kernel<1> (fwd + bwd-data implicit GEMM, fp32 MFMA 32x32x2)",
