@@ -918,7 +918,8 @@ int launch_affine_one(AffArgs& a) {
 long halo_pack_bytes(int Cs, int Cd) { return g_conv_precision == 2 ? fs_halo_f16_pack_bytes(Cs, Cd) : fs_halo_pack_bytes(Cs, Cd); }
 bool use_halo(const ConvArgs& c) {
   return g_conv_precision >= 1 && c.ws_ != nullptr && fs_halo_eligible(c.Hd, c.Wd, c.Cs, c.Cd, c.R, c.S, c.stride, c.pad, c.dil) &&
-         c.Hs == c.Hd && c.Ws == c.Wd && c.ws_bytes_ >= halo_pack_bytes(c.Cs, c.Cd);
+         c.Hs == c.Hd && c.Ws == c.Wd && c.ws_bytes_ >= halo_pack_bytes(c.Cs, c.Cd) &&
+         (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL;      // 32-bit store offsets in the epilogue
 }
 
 // Everything else that is channel-aligned, undilated and has scratch goes to the tap-class kernel (conv_tapset.hip).

@@ -55,7 +55,7 @@ struct HaloF16Args {
   int B, H, W, Cs, Cd, Npad, nchunk;
   int Ph, Pw, tiles_y, tiles_x;
   int nx, ny;
-  unsigned src_bytes, ws_bytes;
+  unsigned src_bytes, ws_bytes, dst_bytes;
   float drop_scale; uint32_t drop_thresh, drop_key;
 };
 
@@ -190,10 +190,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
   f16x8 fa[2][2][2];   // [buffer][mi][plane]
   f16x8 fb[3][2];      // [ring slot][plane]: fragments run 2 steps ahead of the MFMAs
   auto load_b = [&](int g, f16x8 (&dst)[2]) {
-    const int gg = g < G ? g : G - 1;
+    const int gg = g < G ? g : G - 1;            // wave-uniform: the stream position goes in the scalar offset operand
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff + gg * step_bytes + pl * plane_bytes, 0, 0);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff, gg * step_bytes + pl * plane_bytes, 0);
       dst[pl] = __builtin_bit_cast(f16x8, v);
     }
   };
@@ -256,7 +256,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
   if (n < a.Cd) {
     const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
     const int Ew = exponent_of_bits(*a.ew);
-    const float f1 = pow2f(E - 14), f2 = pow2f(Ew - 14);
+    // acc * 2^(E-14) * 2^(Ew-14): one factor when the combined exponent is a normal float, two otherwise
+    const int es = E + Ew - 28;
+    const bool one = es >= -126 && es <= 127;
+    const float f1 = one ? pow2f(es) : pow2f(E - 14), f2 = one ? 1.f : pow2f(Ew - 14);
+    const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -264,12 +268,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
         const i32x4 pix = *reinterpret_cast<const i32x4*>(&rowpix[64 * wm + 32 * mi + 8 * rg + 4 * lh]);
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri) {
-          if (pix[ri] < 0) continue;
           const int r = 4 * rg + ri;
-          float v = (mi == 0 ? acc0[r] : acc1[r]) * f1 * f2 + bv;
-          const long e = (long)pix[ri] * a.Cd + n;
+          const bool live = pix[ri] >= 0;
+          const unsigned e = (unsigned)pix[ri] * (unsigned)a.Cd + (unsigned)n;      // element index (< 2^30: dst_bytes < 4 GB)
+          float v = fmaf((mi == 0 ? acc0[r] : acc1[r]) * f2, f1, bv);
           if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-          a.dst[e] = v;
+          v = live ? v : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
           csum += v; csq += v * v;
         }
       }
@@ -339,8 +344,9 @@ int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, flo
   a.nx = B * a.tiles_y * a.tiles_x;
   a.ny = a.Npad / 64;
   a.src_bytes = (unsigned)((size_t)B * H * W * Cs * 4);
+  a.dst_bytes = (unsigned)((size_t)B * H * W * Cd * 4);
   const long pack_bytes = fs_halo_f16_pack_bytes(Cs, Cd);
-  if (pack_bytes >= 2147483647L || (size_t)B * H * W * Cs * 4 >= 4294967000UL) return FS_ERR_ARG;
+  if (pack_bytes >= 2147483647L || (size_t)B * H * W * Cs * 4 >= 4294967000UL || (size_t)B * H * W * Cd * 4 >= 4294967000UL) return FS_ERR_ARG;
   a.ws_bytes = (unsigned)pack_bytes;
   a.drop_scale = drop_scale; a.drop_thresh = drop_thresh; a.drop_key = drop_key;
   int e = FS_OK;
