@@ -936,7 +936,7 @@ long tapset_pack_bytes(int Cs, int Cd, int taps) {
 }
 bool use_tapset(const ConvArgs& c) {
   return g_conv_precision >= 1 && c.ws_ != nullptr && tapset_shape_ok(c.Cs, c.Cd, c.R, c.S, c.stride, c.dil) &&
-         c.ws_bytes_ >= tapset_pack_bytes(c.Cs, c.Cd, c.R * c.S);
+         c.ws_bytes_ >= tapset_pack_bytes(c.Cs, c.Cd, c.R * c.S) && (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL;
 }
 int run_tapset(const FsTapsetProblem& p, hipStream_t stream) { return g_conv_precision == 2 ? fs_tapset_f16_conv(p, stream) : fs_tapset_conv(p, stream); }
 FsTapsetProblem tapset_base(const ConvArgs& c) {
@@ -1128,13 +1128,15 @@ int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H,
   return FS_OK;
 }
 
-// include/fovealseg.h: fs_conv2d_bwd_weight   (dw is overwritten)
+// include/fovealseg.h: fs_conv2d_bwd_weight   (dw is overwritten, or added to when accumulate != 0)
 int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo,
-                         int Cout, int R, int S, int stride, int pad, int dil, hipStream_t stream) {
+                         int Cout, int R, int S, int stride, int pad, int dil, int accumulate, hipStream_t stream) {
   FS_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
   FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
-  hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)R * S * Cin * Cout, stream);
-  if (e != hipSuccess) return (int)e;
+  if (!accumulate) {         // every kernel below adds its split-K partials atomically: dw = 0 first, unless the caller accumulates
+    hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)R * S * Cin * Cout, stream);
+    if (e != hipSuccess) return (int)e;
+  }
   const long P = (long)B * Ho * Wo;
   if (g_conv_precision >= 1 && H == Ho && W == Wo && fs_wgrad_x3_eligible(Cin, Cout, R, S, stride, pad, dil) &&
       (size_t)B * H * W * Cin * 4 < 4294967000UL && (size_t)P * Cout * 4 < 4294967000UL)

@@ -48,7 +48,7 @@ struct TsF16Args {
   FsTapClass cls[9];
   int Npad, nchunk, ttot;
   int Ph, Pw, tiles_y, tiles_x, nx, ny;
-  unsigned src_bytes, wp_bytes;
+  unsigned src_bytes, wp_bytes, dst_bytes;
   float drop_scale; uint32_t drop_thresh, drop_key;
 };
 
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_tapset_f16_kernel(TsF16Args a) {
     const int gg = g < G ? g : G - 1;
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff + gg * step_bytes + pl * plane_bytes, 0, 0);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff, gg * step_bytes + pl * plane_bytes, 0);
       dst[pl] = __builtin_bit_cast(f16x8, v);
     }
   };
@@ -293,7 +293,10 @@ __global__ __launch_bounds__(256) void conv_tapset_f16_kernel(TsF16Args a) {
   if (n < a.Cd) {
     const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
     const int Ew = exponent_of_bits(*a.ew);
-    const float f1 = pow2f(E - 14), f2 = pow2f(Ew - 14);
+    const int es = E + Ew - 28;
+    const bool one = es >= -126 && es <= 127;
+    const float f1 = one ? pow2f(es) : pow2f(E - 14), f2 = one ? 1.f : pow2f(Ew - 14);
+    const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -301,12 +304,13 @@ __global__ __launch_bounds__(256) void conv_tapset_f16_kernel(TsF16Args a) {
         const i32x4 pix = *reinterpret_cast<const i32x4*>(&rowpix[64 * wm + 32 * mi + 8 * rg + 4 * lh]);
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri) {
-          if (pix[ri] < 0) continue;
           const int r = 4 * rg + ri;
-          float v = (mi == 0 ? acc0[r] : acc1[r]) * f1 * f2 + bv;
-          const long e = (long)pix[ri] * a.Cd + n;
+          const bool live = pix[ri] >= 0;
+          const unsigned e = (unsigned)pix[ri] * (unsigned)a.Cd + (unsigned)n;
+          float v = fmaf((mi == 0 ? acc0[r] : acc1[r]) * f2, f1, bv);
           if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-          a.dst[e] = v;
+          v = live ? v : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
           csum += v; csq += v * v;
         }
       }
@@ -362,6 +366,8 @@ int fs_tapset_f16_conv(const FsTapsetProblem& p, hipStream_t stream) {
   if (pack_bytes >= 2147483647L || (size_t)p.B * p.Hs * p.Ws * p.Cs * 4 >= 4294967000UL || (long)p.B * p.Hd * p.Wd >= 2147483647L)
     return FS_ERR_ARG;
   a.src_bytes = (unsigned)((size_t)p.B * p.Hs * p.Ws * p.Cs * 4);
+  if ((size_t)p.B * p.Hd * p.Wd * p.Cd * 4 >= 4294967000UL) return FS_ERR_ARG;
+  a.dst_bytes = (unsigned)((size_t)p.B * p.Hd * p.Wd * p.Cd * 4);
   a.wp_bytes = (unsigned)pack_bytes;
   a.drop_scale = p.drop_scale; a.drop_thresh = p.drop_thresh; a.drop_key = p.drop_key;
   int e = FS_OK;

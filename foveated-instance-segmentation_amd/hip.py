@@ -33,7 +33,7 @@ SIGNATURES = {
     "fs_conv2d_fwd_stats": "pppppiiiiiiiiiiiifuplp",
     "fs_conv2d_bwd_data": "pppiiiiiiiiiiiiplp",
     "fs_weight_amax_segments": "pppip",
-    "fs_conv2d_bwd_weight": "pppiiiiiiiiiiii",
+    "fs_conv2d_bwd_weight": "pppiiiiiiiiiiiii",
     "fs_bn_stats": "pliffppppp",
     "fs_bn_finalize_slab": "piliffpppp",
     "fs_bn_eval_prepare": "ppifpp",

@@ -195,7 +195,9 @@ def _direct_grad_target(p):
     return None
 
 
-def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None, dil=1):
+def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None, dil=1, accumulate=False):
+    """dW of conv2d.  out = a gradient buffer in the weight's layout; accumulate=True adds into it (the DIRECT_GRAD arena
+    is zeroed once per step by zero_grad, so the per-layer memset is skipped and repeated backwards accumulate like .grad)."""
     B, H, W, Cin = x.shape
     Cout, _, R, S = w_shape
     _, Ho, Wo, _ = dy.shape
@@ -203,7 +205,7 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None, dil=1):
     k3 = R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 16 and Cout >= 16
     _launch("wgrad3x3" if (k3 and hip.get_conv_precision() != "f32") else "conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin,
             "fs_conv2d_bwd_weight", hip.ptr(x), hip.ptr(dy), hip.ptr(dw),
-            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)
+            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 1 if accumulate else 0)
     return out if out is not None else dw.permute(3, 2, 0, 1)
 
 
@@ -280,7 +282,7 @@ class ConvBnAct(Function):
                  hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums))
         dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax) if ctx.needs_input_grad[0] else None
         tgt = _direct_grad_target(w)
-        dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"])
+        dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"], accumulate=tgt is not None)
         if tgt is not None:
             dw = None
         dbias = colsum(dy, C) if m["has_bias"] else None
@@ -305,7 +307,7 @@ class ConvBias(Function):
         dy = dy.contiguous()
         dx = conv2d_bwd_data(dy, w, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
         tgt = _direct_grad_target(w)
-        dw = conv2d_bwd_weight(x, dy, w.shape, stride, pad, out=tgt)
+        dw = conv2d_bwd_weight(x, dy, w.shape, stride, pad, out=tgt, accumulate=tgt is not None)
         if tgt is not None:
             dw = None
         db = colsum(dy, dy.shape[-1]) if has_bias else None

@@ -96,8 +96,10 @@ int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float
 /* convolution_backward: input gradient / weight gradient (dw overwritten). */
 int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R,
                        int S, int stride, int pad, int dil, void* ws, long ws_bytes, const unsigned* w_amax, fs_stream_t stream);
+/* accumulate = 0: dw is overwritten; 1: the gradient is ADDED to dw (torch's .grad accumulation; saves the memset when the caller
+ * keeps a zeroed gradient arena). */
 int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                         int R, int S, int stride, int pad, int dil, fs_stream_t stream);
+                         int R, int S, int stride, int pad, int dil, int accumulate, fs_stream_t stream);
 
 /* ---- BatchNorm / activation / residual ------------------------------------------------------ */
 /* F.batch_norm(training=True) statistics over M rows; running stats updated in place (nullable).
