@@ -4,8 +4,8 @@ Host side mirrors the reference plugin surface (`ModelBuilder`, `DeformSegmentat
 /root/reference/models/models.py:476-1230); every op below that surface is a hand-written HIP
 kernel for gfx950 reached through the C-ABI library declared in include/fovealseg.h.
 """
-from . import config, weights, hip, ops, modules, models  # noqa: F401
+from . import config, weights, hip, ops, modules, models, data  # noqa: F401
 from .models import ModelBuilder, DeformSegmentationModule  # noqa: F401
 from .config import lvis50_cfg  # noqa: F401
 
-__all__ = ["config", "weights", "hip", "ops", "modules", "models", "ModelBuilder", "DeformSegmentationModule", "lvis50_cfg"]
+__all__ = ["config", "weights", "hip", "ops", "modules", "models", "data", "ModelBuilder", "DeformSegmentationModule", "lvis50_cfg"]

@@ -483,7 +483,35 @@ __global__ void inverse_index_kernel(const float* __restrict__ grid, long long* 
 
 }  // namespace
 
+// ---- input pipeline: decoded uint8 sample -> padded float planes of the batch, on the device ----
+// img (H,W,Ci) uint8 HWC (PIL 'RGBA' / 'RGB' memory order) -> X[b] (Cx,HP,WP) = ToTensor (u8 / 255) + F.pad(zeros);
+// mask (H,W) uint8 -> Y[b] (1,HP,WP) = float + F.pad.  DynamicFocus/e_preprocess_scripts/dataset.py:127-142.
+__global__ __launch_bounds__(256) void ingest_sample_kernel(const unsigned char* __restrict__ img, const unsigned char* __restrict__ mask,
+                                                            float* __restrict__ X, float* __restrict__ Y, int H, int W, int Ci, int Cx,
+                                                            int HP, int WP, int pad_left, int pad_top) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)HP * WP) return;
+  const int y = (int)(idx / WP), x = (int)(idx - (long)y * WP);
+  const int sy = y - pad_top, sx = x - pad_left;
+  const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
+  const unsigned char* px = img + ((long)sy * W + sx) * Ci;
+  for (int c = 0; c < Cx; ++c) X[(long)c * HP * WP + idx] = in ? (float)px[c] / 255.0f : 0.f;
+  if (Y != nullptr) Y[idx] = in ? (float)mask[(long)sy * W + sx] : 0.f;
+}
+
 extern "C" {
+
+int fs_ingest_sample(const unsigned char* img, const unsigned char* mask, float* X, float* Y, int b, int H, int W, int Ci, int Cx,
+                     int pad_left, int pad_right, int pad_top, int pad_bottom, hipStream_t stream) {
+  FS_REQUIRE(img && X && b >= 0 && H > 0 && W > 0 && Ci >= 1 && Cx >= 1 && Cx <= Ci && (Y == nullptr || mask != nullptr));
+  FS_REQUIRE(pad_left >= 0 && pad_right >= 0 && pad_top >= 0 && pad_bottom >= 0);
+  const int HP = H + pad_top + pad_bottom, WP = W + pad_left + pad_right;
+  const long plane = (long)HP * WP;
+  hipLaunchKernelGGL(ingest_sample_kernel, dim3(cdiv(plane, 256)), dim3(256), 0, stream, img, mask, X + (long)b * Cx * plane,
+                     Y ? Y + (long)b * plane : nullptr, H, W, Ci, Cx, HP, WP, pad_left, pad_top);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
 
 int fs_gaze_lowres_fwd(const float* x, const float* focus, float* out, int B, int H, int W, int hs, int ws,
                        hipStream_t stream) {

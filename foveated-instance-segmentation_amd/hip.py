@@ -16,6 +16,7 @@ _P, _I, _L, _F, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_floa
 # name -> argument type string (p pointer, i int, l long, f float, u uint32); the trailing stream
 # pointer is appended automatically.
 SIGNATURES = {
+    "fs_ingest_sample": "ppppiiiiiiiii",
     "fs_gaze_lowres_fwd": "pppiiiii",
     "fs_compress_softmax_fwd": "ppppiii",
     "fs_compress_softmax_bwd": "pppppppiii",

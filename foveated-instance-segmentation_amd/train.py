@@ -270,3 +270,86 @@ def build_module(cfg, device="cuda", init="name_keyed"):
     module.to(device)
     nets = (module.encoder, module.decoder, None, module.localization, module.net_compress)
     return module, nets
+
+
+# ----------------------------------------------------------------------------------------------
+# metrics step after the path
+# ----------------------------------------------------------------------------------------------
+class DeviceMeter:
+    """Running averages of the step outputs (loss, acc, edge loss, ...) kept ON the device: `update` is an in-place add of
+    0-d tensors (no `.item()` sync per iteration, unlike utils.AverageMeter at train_deform_semantic.py:100-123), and
+    `averages(reduce=True)` makes the one host read, after ONE all-reduce of [sums..., count] over the ranks -- the
+    reference keeps its meters per rank and never reduces them."""
+
+    def __init__(self, names, device):
+        self.names = list(names)
+        self.acc = torch.zeros(len(self.names) + 1, device=device, dtype=torch.float64)
+
+    def update(self, values, weight=1.0):
+        dev = self.acc.device
+        v = torch.stack([(x.detach().to(device=dev, dtype=torch.float64) if torch.is_tensor(x) else torch.tensor(float(x), dtype=torch.float64, device=dev)).reshape(())
+                         for x in values])
+        self.acc[:-1] += v * weight
+        self.acc[-1] += weight
+
+    def averages(self, reduce=True):
+        tot = self.acc.clone()
+        if reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        tot = tot.cpu()
+        n = float(tot[-1])
+        return {k: (float(tot[i]) / n if n > 0 else float("nan")) for i, k in enumerate(self.names)}
+
+
+# ----------------------------------------------------------------------------------------------
+# checkpoint / resume (SURVEY.md §8(f)-4)
+# ----------------------------------------------------------------------------------------------
+_NET_FILES = ("encoder", "decoder", "saliency", "compress")
+
+
+def save_checkpoint(dirpath, epoch, nets, optimizers=None, extra=None):
+    """train_deform_semantic.py:166-184 -- `{encoder,decoder,saliency,compress}_epoch_{N}.pth` hold plain state_dicts with the
+    reference's keys and shapes (they load into the reference and vice versa).  In addition (the reference saves neither, so a
+    resumed run restarts Adam from zero) `train_state_epoch_{N}.pth` keeps the four Adam states, the dropout step counter and
+    the torch RNG state.  epoch may be 'last' (checkpoint_last, :188-208)."""
+    from .ops import DropoutState
+    net_encoder, net_decoder, _crit, net_saliency, net_compress = nets
+    os.makedirs(dirpath, exist_ok=True)
+    for name, net in zip(_NET_FILES, (net_encoder, net_decoder, net_saliency, net_compress)):
+        torch.save({k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()}, os.path.join(dirpath, f"{name}_epoch_{epoch}.pth"))
+    state = {"epoch": epoch, "dropout": {"seed": DropoutState.seed, "step": DropoutState.step}, "rng": torch.get_rng_state(),
+             "extra": extra}
+    if optimizers is not None:
+        state["optimizers"] = [{"t": o.t, "m": o.m.cpu(), "v": o.v.cpu(), "lr": o.param_groups[0]["lr"]} for o in optimizers]
+    torch.save(state, os.path.join(dirpath, f"train_state_epoch_{epoch}.pth"))
+
+
+def load_checkpoint(dirpath, epoch, nets, optimizers=None, strict=True):
+    """Inverse of save_checkpoint; also accepts a directory written by the reference (no train_state file: weights only).
+    Returns the `extra` object (or None)."""
+    from .ops import DropoutState
+    net_encoder, net_decoder, _crit, net_saliency, net_compress = nets
+    for name, net in zip(_NET_FILES, (net_encoder, net_decoder, net_saliency, net_compress)):
+        sd = torch.load(os.path.join(dirpath, f"{name}_epoch_{epoch}.pth"), map_location="cpu", weights_only=True)
+        net.load_state_dict(sd, strict=strict)
+    path = os.path.join(dirpath, f"train_state_epoch_{epoch}.pth")
+    if not os.path.exists(path):
+        if optimizers is not None:
+            for o in optimizers:
+                o.flat.refresh_amax()
+        return None
+    state = torch.load(path, map_location="cpu", weights_only=False)
+    DropoutState.seed, DropoutState.step = state["dropout"]["seed"], state["dropout"]["step"]
+    torch.set_rng_state(state["rng"])
+    if optimizers is not None:
+        for o, sd in zip(optimizers, state.get("optimizers", [])):
+            o.load_state_dict(sd)
+            o.param_groups[0]["lr"] = sd["lr"]
+            o.flat.refresh_amax()          # the parameters were rewritten through load_state_dict
+    return state.get("extra")
+
+
+def history_path(dirpath, epoch, rank=0, kind="csv"):
+    """The reference writes `history_epoch_last_{rank}.csv` / `history_epoch_{N}_{rank}.pth` (train…:230-235) but resumes from
+    `history_epoch_{N}.csv` (:416), which never exists.  Writers and readers here share this one function."""
+    return os.path.join(dirpath, f"history_epoch_{epoch}_{rank}.{kind}")

@@ -25,6 +25,13 @@ extern "C" {
 typedef void* fs_stream_t;
 
 /* ---- foveation front-end ------------------------------------------------------------------ */
+/* Input pipeline step in front of the path: one decoded sample, uint8 on the device, becomes slot b of the
+ * float batch.  img (H,W,Ci) uint8 in PIL memory order ('RGBA': Ci=4, 'RGB': 3); X (B,Cx,HP,WP) with Cx <= Ci leading channels,
+ * X = img/255 (transforms.ToTensor) zero-padded by (left,right,top,bottom) (F.pad); mask (H,W) uint8 -> Y (B,1,HP,WP) float,
+ * same padding (Y / mask nullable).  Bit-identical to DynamicFocus/e_preprocess_scripts/dataset.py:127-142 + default collate,
+ * at a quarter of the H2D bytes. */
+int fs_ingest_sample(const unsigned char* img, const unsigned char* mask, float* X, float* Y, int b, int H, int W, int Ci, int Cx,
+                     int pad_left, int pad_right, int pad_top, int pad_bottom, fs_stream_t stream);
 /* x (B,3,H,W) NCHW, focus (B,2)=(row,col) -> out (B,hs,ws,5): bilinear RGB + 2x squared gaze distance.
  * models/models.py:684-705 (gen_grid_mtx_2xHxW, sqrt/square, b_imresize, 2x cat). */
 int fs_gaze_lowres_fwd(const float* x, const float* focus, float* out, int B, int H, int W, int hs, int ws, fs_stream_t stream);

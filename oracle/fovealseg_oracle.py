@@ -538,3 +538,19 @@ def layer_key(seed: int, layer_id: int) -> int:
     x = (x * 0x297A2D39) & 0xFFFFFFFF
     x ^= x >> 15
     return x
+
+
+# ----------------------------------------------------------------------------------------------
+# input pipeline step
+# ----------------------------------------------------------------------------------------------
+def ingest_sample_ref(img_u8_hwc, mask_u8_hw, pads, focus, frame, cls):
+    """DynamicFocus/e_preprocess_scripts/dataset.py:127-142 for one decoded LVIS sample: torchvision ToTensor on a uint8 HWC
+    image is `permute(2,0,1).float().div(255)` (transforms/functional.py:to_tensor), then F.pad with zeros by
+    (left, right, top, bottom); the mask is cast to float and padded alike; F_2 = (idx_H/HC, idx_W/WC); cls int64."""
+    import torch.nn.functional as F
+    x = torch.as_tensor(img_u8_hwc).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+    y = torch.as_tensor(mask_u8_hw)[None].to(torch.float32)
+    x = F.pad(x, tuple(pads))
+    y = F.pad(y, tuple(pads)).to(torch.float32)
+    f2 = torch.tensor([focus[0] / frame[0], focus[1] / frame[1]], dtype=torch.float32)
+    return x, f2, y, torch.tensor([cls], dtype=torch.int64)
