@@ -481,6 +481,86 @@ __global__ void inverse_index_kernel(const float* __restrict__ grid, long long* 
   v[i] = (long long)(int)fv;
 }
 
+// ---- inverse (un-foveating) warp, SURVEY §8(f)-3 -------------------------------------------------------------------
+// models/models.py:639-655: every grid point i = (yi, xi) of the (h,w) sampling grid claims the full-resolution pixel
+// (v,u) it was sampled from; duplicate claims resolve as ATen-CPU index_put_ does (the LAST index wins = largest i).
+__global__ void inverse_owner_kernel(const float* __restrict__ grid, int* __restrict__ owner, int B, int hw, int Hs, int Ws) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * hw) return;
+  const int b = (int)(i / hw), p = (int)(i - (long)b * hw);
+  const float gx = grid[2 * i], gy = grid[2 * i + 1];
+  const int u = (int)__fmul_rn(__fmul_rn(__fadd_rn(gx, 1.f), 0.5f), (float)(Ws - 1));
+  const int v = (int)__fmul_rn(__fmul_rn(__fadd_rn(gy, 1.f), 0.5f), (float)(Hs - 1));
+  if (u < 0 || u >= Ws || v < 0 || v >= Hs) return;
+  atomicMax(&owner[((long)b * Hs + v) * Ws + u], p);
+}
+// grid_inv[b,v,u] = (xi/w*2-1, yi/h*2-1) of the owning grid point, 0 where nobody claims the pixel (the reference writes NaN
+// and replaces it by 0 before sampling, models.py:931-932; the hole mask is owner < 0).
+__global__ void inverse_grid_kernel(const int* __restrict__ owner, float* __restrict__ inv, long n, int h, int w) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int p = owner[i];
+  float gx = 0.f, gy = 0.f;
+  if (p >= 0) {
+    const int yi = p / w, xi = p - yi * w;
+    gx = __fsub_rn(__fmul_rn(__fdiv_rn((float)xi, (float)w), 2.f), 1.f);
+    gy = __fsub_rn(__fmul_rn(__fdiv_rn((float)yi, (float)h), 2.f), 1.f);
+  }
+  inv[2 * i] = gx; inv[2 * i + 1] = gy;
+}
+// Nearest-valid fill (models.py:159-286 with rev_deform_interp='nearest'): exact Euclidean nearest claimed pixel, ties to
+// the smallest (row, col).  Pass A: nearest claimed column in the same row; pass B: minimise (y-y')^2 + (x-x'(y'))^2 over rows.
+__global__ void fill_row_nearest_kernel(const int* __restrict__ owner, int* __restrict__ rowx, int Ws) {
+  const long row = blockIdx.x;
+  const int* o = owner + row * Ws;
+  int* r = rowx + row * Ws;
+  for (int x = threadIdx.x; x < Ws; x += blockDim.x) {
+    int best = -1;
+    for (int d = 0; d < Ws; ++d) {
+      const int xl = x - d, xr = x + d;
+      if (xl >= 0 && o[xl] >= 0) { best = xl; break; }
+      if (xr < Ws && o[xr] >= 0) { best = xr; break; }
+      if (xl < 0 && xr >= Ws) break;
+    }
+    r[x] = best;
+  }
+}
+__global__ void fill_col_nearest_kernel(const int* __restrict__ rowx, int* __restrict__ src, long n, int Hs, int Ws) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long per = (long)Hs * Ws;
+  const long b = i / per;
+  const long rem = i - b * per;
+  const int y = (int)(rem / Ws), x = (int)(rem - (long)y * Ws);
+  const int* rx = rowx + b * per;
+  long best = -1;
+  int bsrc = -1;
+  for (int d = 0; d < Hs; ++d) {                       // rows by increasing |y - y'|: stop once dy^2 alone exceeds the best
+    if (best >= 0 && (long)d * d > best) break;
+    for (int sgn = 0; sgn < 2; ++sgn) {
+      const int yy = sgn == 0 ? y - d : y + d;
+      if (yy < 0 || yy >= Hs || (d == 0 && sgn == 1)) continue;
+      const int xx = rx[(long)yy * Ws + x];
+      if (xx < 0) continue;
+      const long dd = (long)d * d + (long)(x - xx) * (x - xx);
+      const int cand = yy * Ws + xx;
+      if (best < 0 || dd < best || (dd == best && cand < bsrc)) { best = dd; bsrc = cand; }
+    }
+  }
+  src[i] = bsrc;
+}
+__global__ void fill_copy_kernel(float* __restrict__ vals, const int* __restrict__ owner, const int* __restrict__ src, int C, long per,
+                                 long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;       // over (b, c, pixel)
+  if (i >= total) return;
+  const long pix = i % per;
+  const long bc = i / per;
+  const long b = bc / C;
+  if (owner[b * per + pix] >= 0) return;               // claimed pixels keep their sampled value
+  const int sp = src[b * per + pix];
+  if (sp >= 0) vals[bc * per + pix] = vals[bc * per + sp];
+}
+
 }  // namespace
 
 // ---- input pipeline: decoded uint8 sample -> padded float planes of the batch, on the device ----
@@ -615,6 +695,33 @@ int fs_grid_sample_bwd_input(const float* gout, const float* grid, float* dx, in
   hipError_t e = hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * C * H * W, stream);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(grid_sample_bwd_input_kernel, dim3(cdiv((long)B * h * w, 256)), dim3(256), 0, stream, gout, grid, dx, B, C, H, W, h, w, nhwc);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_inverse_grid(const float* grid, int* owner, float* grid_inv, int B, int h, int w, int Hs, int Ws, hipStream_t stream) {
+  FS_REQUIRE(grid && owner && grid_inv && B > 0 && h > 0 && w > 0 && Hs > 0 && Ws > 0 && (long)h * w < 2147483647L);
+  const long n = (long)B * Hs * Ws;
+  hipError_t e = hipMemsetAsync(owner, 0xFF, sizeof(int) * (size_t)n, stream);      // -1
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(inverse_owner_kernel, dim3(cdiv((long)B * h * w, 256)), dim3(256), 0, stream, grid, owner, B, h * w, Hs, Ws);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(inverse_grid_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, owner, grid_inv, n, h, w);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_fill_nearest(float* vals, const int* owner, int* scratch, int B, int C, int Hs, int Ws, hipStream_t stream) {
+  FS_REQUIRE(vals && owner && scratch && B > 0 && C > 0 && Hs > 0 && Ws > 0 && (long)Hs * Ws < 2147483647L);
+  const long per = (long)Hs * Ws, n = (long)B * per;
+  int* rowx = scratch;          // [B*Hs*Ws]
+  int* src = scratch + n;       // [B*Hs*Ws]
+  hipLaunchKernelGGL(fill_row_nearest_kernel, dim3((unsigned)((long)B * Hs)), dim3(256), 0, stream, owner, rowx, Ws);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(fill_col_nearest_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, rowx, src, n, Hs, Ws);
+  FS_LAUNCH_CHECK();
+  const long total = n * C;
+  hipLaunchKernelGGL(fill_copy_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, vals, owner, src, C, per, total);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -30,6 +30,8 @@ SIGNATURES = {
     "fs_grid_sample_bwd_grid": "ppppiiiiiii",
     "fs_grid_sample_bwd_input": "pppiiiiiii",
     "fs_inverse_index_maps": "ppplii",
+    "fs_inverse_grid": "pppiiiii",
+    "fs_fill_nearest": "pppiiii",
     "fs_conv2d_fwd": "ppppiiiiiiiiiiiifuplp",
     "fs_conv2d_fwd_stats": "pppppiiiiiiiiiiiifuplp",
     "fs_conv2d_bwd_data": "pppiiiiiiiiiiiiplp",

@@ -138,6 +138,15 @@ class DeformSegmentationModule(nn.Module):
         """xs (B,1,hs,ws) -> grid (B,hs,ws,2); replication pad folded in (models/models.py:594-637,821)."""
         return ops.GaussGrid.apply(xs, self.g1d, self.padding_size_x)
 
+    @torch.no_grad()
+    def unwarp(self, pred, grid, seg_size):
+        """Full-resolution prediction from the foveated one: the inverse grid of `create_grid(..., segSize, x_inv)`
+        (models/models.py:639-655), `F.grid_sample(pred, grid_inv)` (:933) and the nearest-neighbour hole filling of
+        `fillMissingValues_tensor(..., interp_mode='nearest')` (:159-286), all on the device (the
+        'tri' default of the reference calls an undefined name).  pred (B,C,h,w) logical NCHW, grid (B,h,w,2) as returned by
+        create_grid; returns (pred_full (B,C,H,W), hole mask (B,H,W))."""
+        return ops.unwarp_nearest(pred.contiguous(), grid, int(seg_size[0]), int(seg_size[1]))
+
     def forward(self, feed_dict, *, writer=None, segSize=None, F_Xlr_acc_map=False, count=None, epoch=None,
                 feed_dict_info=None, feed_batch_count=None, cur_iter=None, is_inference=False, rank=None):
         if segSize is not None:

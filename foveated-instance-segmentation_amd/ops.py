@@ -664,6 +664,28 @@ def inverse_index_maps(grid, H, W):
     return u, v
 
 
+def inverse_grid(grid, Hs, Ws):
+    """models/models.py:639-655: (owner (B,Hs,Ws) int32 with -1 in holes, grid_inv (B,Hs,Ws,2) with 0 in holes)."""
+    B, h, w, _ = grid.shape
+    owner = torch.empty(B, Hs, Ws, device=grid.device, dtype=torch.int32)
+    inv = torch.empty(B, Hs, Ws, 2, device=grid.device, dtype=torch.float32)
+    hip.call("fs_inverse_grid", hip.ptr(grid.contiguous()), hip.ptr(owner), hip.ptr(inv), B, h, w, Hs, Ws)
+    return owner, inv
+
+
+def unwarp_nearest(pred, grid, Hs, Ws):
+    """Full-resolution prediction from the foveated one (no autograd): pred (B,C,h,w) is sampled through the inverse grid
+    (F.grid_sample(pred, grid_inv), models/models.py:933) and the never-claimed pixels take their nearest claimed
+    neighbour (rev_deform_interp='nearest').  Returns (pred_full (B,C,Hs,Ws), hole mask (B,Hs,Ws) bool)."""
+    B, C, h, w = pred.shape
+    owner, inv = inverse_grid(grid, Hs, Ws)
+    out = torch.empty(B, C, Hs, Ws, device=pred.device, dtype=torch.float32)
+    hip.call("fs_grid_sample_fwd", hip.ptr(pred.contiguous()), hip.ptr(inv), hip.ptr(out), B, C, h, w, Hs, Ws, 0)
+    scratch = torch.empty(2 * B * Hs * Ws, device=pred.device, dtype=torch.int32)
+    hip.call("fs_fill_nearest", hip.ptr(out), hip.ptr(owner), hip.ptr(scratch), B, C, Hs, Ws)
+    return out, owner < 0
+
+
 # ----------------------------------------------------------------------------------------------
 # SegFormer pieces (tokens = NHWC rows)
 # ----------------------------------------------------------------------------------------------

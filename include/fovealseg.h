@@ -63,6 +63,13 @@ int fs_grid_sample_bwd_grid(const float* gout, const float* x, const float* grid
                             int w, int nhwc, fs_stream_t stream);
 int fs_grid_sample_bwd_input(const float* gout, const float* grid, float* dx, int B, int C, int H, int W, int h, int w, int nhwc,
                              fs_stream_t stream);
+/* Inverse (un-foveating) warp, SURVEY §8(f)-3.  fs_inverse_grid: owner[b,v,u] = index yi*w+xi of the grid point that claims
+ * full-resolution pixel (v,u) (-1 = hole; duplicates: the largest index wins, as ATen-CPU index_put_ does), grid_inv[b,v,u] =
+ * (xi/w*2-1, yi/h*2-1), 0 in holes: feed it to fs_grid_sample_fwd(pred, grid_inv).  models/models.py:639-655,930-934.
+ * fs_fill_nearest: every hole of vals (B,C,Hs,Ws) takes the value of the Euclidean-nearest claimed pixel (ties: smallest row,
+ * then column) -- fillMissingValues_tensor(..., interp_mode='nearest'), models/models.py:159-286.  scratch = 2*B*Hs*Ws ints. */
+int fs_inverse_grid(const float* grid, int* owner, float* grid_inv, int B, int h, int w, int Hs, int Ws, fs_stream_t stream);
+int fs_fill_nearest(float* vals, const int* owner, int* scratch, int B, int C, int Hs, int Ws, fs_stream_t stream);
 /* u=int((gx+1)/2*(W-1)), v=int((gy+1)/2*(H-1)) for n grid points.  models/models.py:644-645. */
 int fs_inverse_index_maps(const float* grid, long long* u, long long* v, long n, int H, int W, fs_stream_t stream);
 

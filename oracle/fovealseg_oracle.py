@@ -554,3 +554,58 @@ def ingest_sample_ref(img_u8_hwc, mask_u8_hw, pads, focus, frame, cls):
     y = F.pad(y, tuple(pads)).to(torch.float32)
     f2 = torch.tensor([focus[0] / frame[0], focus[1] / frame[1]], dtype=torch.float32)
     return x, f2, y, torch.tensor([cls], dtype=torch.int64)
+
+
+# ----------------------------------------------------------------------------------------------
+# inverse warp + nearest hole filling
+# ----------------------------------------------------------------------------------------------
+def inverse_grid_ref(grid: torch.Tensor, Hs: int, Ws: int):
+    """models/models.py:639-655.  Several grid points can claim one full-resolution pixel; the reference resolves that with two
+    ATen index_put_ calls whose winner depends on the CPU thread schedule (it can even differ between the x and the y channel).
+    The restatement fixes the rule a sequential index_put_ gives -- the LAST claimant wins, for both channels -- via numpy's
+    advanced assignment (documented: with repeated indices the last value is assigned)."""
+    B, h, w, _ = grid.shape
+    u = (((grid[..., 0] + 1) / 2) * (Ws - 1)).int().long().view(B, -1).numpy()
+    v = (((grid[..., 1] + 1) / 2) * (Hs - 1)).int().long().view(B, -1).numpy()
+    x_cor = np.tile(np.arange(w, dtype=np.float32)[None, :], (h, 1)).reshape(-1)
+    y_cor = np.tile(np.arange(h, dtype=np.float32)[:, None], (1, w)).reshape(-1)
+    inv = np.full((2, B, Hs, Ws), np.nan, dtype=np.float32)
+    for b in range(B):
+        inv[0, b][v[b], u[b]] = x_cor
+        inv[1, b][v[b], u[b]] = y_cor
+    inv = torch.from_numpy(inv)
+    inv[0] = inv[0] / w * 2 - 1
+    inv[1] = inv[1] / h * 2 - 1
+    return inv.permute(1, 2, 3, 0)
+
+
+def unwarp_nearest_ref(pred: torch.Tensor, grid: torch.Tensor, Hs: int, Ws: int):
+    """models/models.py:930-940 with rev_deform_interp='nearest': grid_sample through the inverse grid (NaN -> 0), then every
+    hole takes the value of its Euclidean-nearest sampled pixel.  The reference asks scipy's NearestNDInterpolator, whose
+    choice among equidistant neighbours is unspecified; this restatement takes the smallest (row, col), and
+    `nearest_distance_map` lets tests check optimality independently of the tie rule."""
+    inv = inverse_grid_ref(grid, Hs, Ws)
+    hole = torch.isnan(inv[..., 0])
+    out = F.grid_sample(pred, torch.nan_to_num(inv, nan=0.0), align_corners=False)
+    B = pred.shape[0]
+    for b in range(B):
+        ys, xs = torch.where(~hole[b])
+        hy, hx = torch.where(hole[b])
+        if len(ys) == 0 or len(hy) == 0:
+            continue
+        d = (hy[:, None] - ys[None, :]) ** 2 + (hx[:, None] - xs[None, :]) ** 2        # valid pixels come in (row, col) order
+        j = d.argmin(dim=1)                                                              # first minimum = smallest (row, col)
+        out[b][:, hy, hx] = out[b][:, ys[j], xs[j]]
+    return out, hole
+
+
+def nearest_distance_map(hole: torch.Tensor):
+    """Squared distance of every pixel to the nearest non-hole pixel of its image (brute force, small inputs)."""
+    B, H, W = hole.shape
+    out = torch.zeros(B, H, W, dtype=torch.long)
+    for b in range(B):
+        ys, xs = torch.where(~hole[b])
+        yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        d = (yy.reshape(-1, 1) - ys[None]) ** 2 + (xx.reshape(-1, 1) - xs[None]) ** 2
+        out[b] = d.min(dim=1).values.view(H, W)
+    return out

@@ -154,3 +154,117 @@ def test_checkpoint_roundtrip_and_reference_file_names(tmp_path):
     os.remove(tmp_path / "train_state_epoch_5.pth")
     assert train.load_checkpoint(str(tmp_path), 5, _toy_nets(2)) is None
     assert train.history_path("d", "last", 3) == os.path.join("d", "history_epoch_last_3.csv")
+
+
+# ---------------------------------------------------------------------------- f-3 ------------------------
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _g14():
+    return {k: v for k, v in np.load(os.path.join(GOLD, "g14_inverse.npz")).items()}
+
+
+def _claims(grid, Hs, Ws):
+    """per image: {pixel linear index: [grid point indices claiming it, ascending]}"""
+    B, h, w, _ = grid.shape
+    u = (((grid[..., 0] + 1) / 2) * (Ws - 1)).int().long().view(B, -1)
+    v = (((grid[..., 1] + 1) / 2) * (Hs - 1)).int().long().view(B, -1)
+    out = []
+    for b in range(B):
+        d = {}
+        for i, p in enumerate((v[b] * Ws + u[b]).tolist()):
+            d.setdefault(p, []).append(i)
+        out.append(d)
+    return out
+
+
+def _check_inverse_grid(inv, ref, grid, Hs, Ws):
+    """inv: ours (0 in holes), ref: the reference's grid_inv (NaN in holes).  Pixels claimed once must agree bit for bit.  For
+    pixels claimed by several grid points the reference is not reproducible -- its two index_put_ calls (x and y channel,
+    models/models.py:650-651) run on ATen's parallel CPU loop and may even pick different claimants per channel -- so there the
+    reference value must come from SOME claimant and ours from the LAST one (the sequential index_put_ result)."""
+    B, h, w, _ = grid.shape
+    assert torch.equal(torch.isnan(ref[..., 0]), (inv == 0).all(-1) & torch.isnan(ref[..., 0])) and not torch.isnan(inv).any()
+    claims = _claims(grid, Hs, Ws)
+    fx = lambda i: torch.tensor(float(i % w)) / w * 2 - 1      # noqa: E731
+    fy = lambda i: torch.tensor(float(i // w)) / h * 2 - 1     # noqa: E731
+    ndup = 0
+    for b in range(B):
+        hole = torch.isnan(ref[b, ..., 0]).view(-1)
+        assert set(torch.nonzero(~hole).view(-1).tolist()) == set(claims[b])
+        for p, idx in claims[b].items():
+            y, x = divmod(p, Ws)
+            mine, theirs = inv[b, y, x], ref[b, y, x]
+            assert float(mine[0]) == float(fx(idx[-1])) and float(mine[1]) == float(fy(idx[-1]))
+            if len(idx) == 1:
+                assert torch.equal(mine, theirs)
+            else:
+                ndup += 1
+                assert float(theirs[0]) in {float(fx(i)) for i in idx} and float(theirs[1]) in {float(fy(i)) for i in idx}
+    assert ndup > 100
+
+
+def test_inverse_grid_oracle_vs_reference_golden():
+    g = _g14()
+    Hs, Ws = (int(v) for v in g["seg"])
+    grid = torch.from_numpy(g["grid"])
+    inv = O.inverse_grid_ref(grid, Hs, Ws)
+    ref = torch.from_numpy(g["grid_inv"])
+    assert torch.equal(torch.isnan(inv), torch.isnan(ref))
+    _check_inverse_grid(torch.nan_to_num(inv), ref, grid, Hs, Ws)
+    out, hole = O.unwarp_nearest_ref(torch.from_numpy(g["pred"]), torch.from_numpy(g["grid"]), Hs, Ws)
+    assert torch.equal(hole, torch.from_numpy(g["unfilled"]))
+    sampled = torch.from_numpy(g["sampled"])
+    same = (torch.nan_to_num(inv) == torch.nan_to_num(ref)).all(-1) & ~hole      # claimed, and by the same grid point as in the reference
+    keep = same[:, None].expand_as(out)
+    assert torch.equal(out[keep], sampled[keep])                                # there: the reference's grid_sample values, bit for bit
+    sampled = torch.where(keep, sampled, out)                                   # (elsewhere compare the fill against our own samples)
+    # the fill is a nearest-neighbour fill whatever the tie rule: scipy's NearestNDInterpolator must see the same distances
+    from scipy.interpolate import NearestNDInterpolator
+    for b in range(out.shape[0]):
+        pts = np.argwhere(~hole[b].numpy())
+        q = np.argwhere(hole[b].numpy())
+        sc = NearestNDInterpolator(pts, sampled[b, 0].numpy()[~hole[b].numpy()])(q)
+        mine = out[b, 0].numpy()[hole[b].numpy()]
+        d2 = O.nearest_distance_map(hole[b:b + 1])[0].numpy()[hole[b].numpy()]
+        differ = sc != mine
+        # where the two disagree, both picked a pixel at the same (minimal) distance: check mine is at distance d2
+        vals = sampled[b, 0].numpy()
+        for (y, x), m_, dd in zip(q[differ], mine[differ], d2[differ]):
+            cand = [(yy, xx) for yy, xx in pts if (yy - y) ** 2 + (xx - x) ** 2 == dd]
+            assert any(vals[yy, xx] == m_ for yy, xx in cand)
+        assert differ.mean() < 0.5          # integer lattices have many equidistant pairs; each disagreement was checked above
+
+
+@pytest.mark.gpu
+def test_unwarp_nearest_matches_golden_and_oracle():
+    g = _g14()
+    Hs, Ws = (int(v) for v in g["seg"])
+    grid, pred = torch.from_numpy(g["grid"]).cuda(), torch.from_numpy(g["pred"]).cuda()
+    owner, inv = fovealseg.ops.inverse_grid(grid, Hs, Ws)
+    ref_inv = torch.from_numpy(g["grid_inv"])
+    assert torch.equal((owner < 0).cpu(), torch.isnan(ref_inv[..., 0]))
+    _check_inverse_grid(inv.cpu(), ref_inv, torch.from_numpy(g["grid"]), Hs, Ws)
+    assert torch.equal(inv.cpu(), torch.nan_to_num(O.inverse_grid_ref(torch.from_numpy(g["grid"]), Hs, Ws)))   # and = the sequential rule
+    out, hole = fovealseg.ops.unwarp_nearest(pred, grid, Hs, Ws)
+    want, whole = O.unwarp_nearest_ref(torch.from_numpy(g["pred"]), torch.from_numpy(g["grid"]), Hs, Ws)
+    assert torch.equal(hole.cpu(), whole)
+    assert torch.equal(out.cpu(), want)                                         # same samples, same nearest pixel, same tie rule
+
+
+@pytest.mark.gpu
+def test_fill_nearest_properties_full_size():
+    # BASELINE-size frame: 1024 x 1024 from an 80 x 80 grid (99.4 % holes); size-independent properties
+    torch.manual_seed(0)
+    B, C, Hs, Ws = 2, 3, 1024, 1024
+    grid = (torch.rand(B, 80, 80, 2) * 2 - 1).cuda()
+    pred = torch.randn(B, C, 80, 80).cuda()
+    out, hole = fovealseg.ops.unwarp_nearest(pred, grid, Hs, Ws)
+    assert not torch.isnan(out).any() and float(hole.float().mean()) > 0.99
+    out2 = out.clone()
+    owner, _ = fovealseg.ops.inverse_grid(grid, Hs, Ws)
+    scratch = torch.empty(2 * B * Hs * Ws, device="cuda", dtype=torch.int32)
+    fovealseg.hip.call("fs_fill_nearest", out2.data_ptr(), owner.data_ptr(), scratch.data_ptr(), B, C, Hs, Ws)
+    assert torch.equal(out, out2)                                               # idempotent
+    vals = set(out[0, 0][~hole[0]].cpu().tolist())
+    assert set(out[0, 0].unique().cpu().tolist()) <= vals                       # holes only ever take claimed values
