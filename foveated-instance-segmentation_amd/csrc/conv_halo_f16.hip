@@ -44,6 +44,8 @@ __device__ __forceinline__ void split2(float xs, _Float16& a, _Float16& b) {
   a = (_Float16)xs;
   b = (_Float16)(xs - (float)a);
 }
+// n / d for 0 <= n < 65536 with m = 2^32 / d + 1 precomputed on the host (exact for d <= 65535): two VALU instead of ~25
+__device__ __forceinline__ int div_small(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }
 __device__ __forceinline__ int row_perm(int l) {       // see conv_halo.hip
   const bool g1 = (l >= 4 && l < 12) || (l >= 16 && l < 20) || l >= 28;
   if (!g1) return l < 4 ? l : (l < 16 ? l - 8 : l - 12);
@@ -56,6 +58,7 @@ struct HaloF16Args {
   int Ph, Pw, tiles_y, tiles_x;
   int nx, ny;
   unsigned src_bytes, ws_bytes, dst_bytes;
+  unsigned magic_pw, magic_wh;      // 2^32 / Pw + 1, 2^32 / (Pw + 2) + 1
   float drop_scale; uint32_t drop_thresh, drop_key;
 };
 
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
 
   if (tid < 128) {
     const int p = (tid & ~31) + row_perm(tid & 31);
-    const int py = p / a.Pw, px = p - py * a.Pw;
+    const int py = div_small(p, a.magic_pw), px = p - py * a.Pw;
     const bool live = p < a.Ph * a.Pw && y0 + py < a.H && x0 + px < a.W;
     rowpix[tid] = live ? ((b * a.H + y0 + py) * a.W + x0 + px) : -1;
   }
@@ -126,8 +129,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
   const int q = tid & 7;
   int goff[NITEM];
   {
-    const int q32 = 32 / Wh, r32 = 32 - q32 * Wh;
-    int hy = (tid >> 3) / Wh, hx = (tid >> 3) - hy * Wh;
+    const int q32 = div_small(32, a.magic_wh), r32 = 32 - q32 * Wh;
+    int hy = div_small(tid >> 3, a.magic_wh), hx = (tid >> 3) - hy * Wh;
 #pragma unroll
     for (int i = 0; i < NITEM; ++i) {
       const int iy = y0 + hy - 1, ix = x0 + hx - 1;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
   for (int mi = 0; mi < 2; ++mi) {
     const int p = 64 * wm + 32 * mi + row_perm(l31);
     const bool live = p < a.Ph * a.Pw;
-    const int py = live ? p / a.Pw : 0, px = live ? p - py * a.Pw : 0;
+    const int py = live ? div_small(p, a.magic_pw) : 0, px = live ? p - py * a.Pw : 0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) rowbase[mi][r] = ((py + r) * Wh + px) * XLD + 8 * lh;
   }
@@ -210,10 +213,12 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
     __syncthreads();                      // amax complete; every wave has finished reading the previous image
     const int ec = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[chunk & 1]));
     if (ec > E) {
-      const int d = E - ec;               // accumulators move to the new unit 2^(ec-14)
-      const float f = d < -126 ? 0.f : pow2f(d);
+      if (chunk > 0) {                    // accumulators (still zero in the first chunk) move to the new unit 2^(ec-14)
+        const int d = E - ec;
+        const float f = d < -126 ? 0.f : pow2f(d);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[r] *= f; acc1[r] *= f; }
+        for (int r = 0; r < 16; ++r) { acc0[r] *= f; acc1[r] *= f; }
+      }
       E = ec;
     }
     store_halo(pow2f(14 - E));
@@ -343,6 +348,8 @@ int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, flo
   a.tiles_y = cdiv(H, a.Ph); a.tiles_x = cdiv(W, a.Pw);
   a.nx = B * a.tiles_y * a.tiles_x;
   a.ny = a.Npad / 64;
+  a.magic_pw = (unsigned)(4294967296ULL / (unsigned)a.Pw + 1ULL);
+  a.magic_wh = (unsigned)(4294967296ULL / (unsigned)(a.Pw + 2) + 1ULL);
   a.src_bytes = (unsigned)((size_t)B * H * W * Cs * 4);
   a.dst_bytes = (unsigned)((size_t)B * H * W * Cd * 4);
   const long pack_bytes = fs_halo_f16_pack_bytes(Cs, Cd);
