@@ -114,6 +114,59 @@ def test_conv_fwd_bwd(case, prec):
     assert relerr(dw.cpu(), wr.grad) <= 5e-5
 
 
+SPLIT_SHAPES = [(2, 24, 24, 64, 64, 1), (1, 20, 20, 128, 96, 1), (2, 24, 24, 64, 128, 2)]   # halo 3x3, 2-chunk 3x3, tap-class stride 2
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("shape", SPLIT_SHAPES)
+def test_split_precision_range_properties(mode, shape):
+    """Size-independent properties of the scaled split-precision kernels: exact homogeneity under power-of-two
+    scaling over 80 binades, zeros in -> zeros out, outliers, non-finite inputs."""
+    fovealseg.hip.set_conv_precision(mode)
+    try:
+        B, H, W, Ci, Co, s = shape
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(B, Ci, H, W, generator=g)
+        w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+        Ho = (H + 2 - 3) // s + 1
+        dy = torch.randn(B, Co, Ho, Ho, generator=g)
+        xd, wd, dyd = nhwc(x), rsck_param(w), nhwc(dy)
+        y0 = ops.conv2d_fwd(xd, wd, None, s, 1)
+        dx0 = ops.conv2d_bwd_data(dyd, wd, xd.shape, s, 1)
+        dw0 = ops.conv2d_bwd_weight(xd, dyd, w.shape, s, 1)
+        ref = F.conv2d(x.double(), w.double(), None, s, 1)
+        assert relerr(nchw(y0).double(), ref) <= 2e-6
+        # 1. y(2^a x, 2^b w) = 2^(a+b) y(x, w) bit for bit: the tile / tensor exponents absorb the scale exactly
+        for a, b in ((-40, 0), (30, -35), (0, 40), (-20, -20)):
+            xa, wb = xd * 2.0 ** a, rsck_param(w * 2.0 ** b)
+            assert torch.equal(ops.conv2d_fwd(xa, wb, None, s, 1), y0 * 2.0 ** (a + b)), (a, b)
+            assert torch.equal(ops.conv2d_bwd_data(dyd * 2.0 ** a, wb, xd.shape, s, 1), dx0 * 2.0 ** (a + b)), (a, b)
+            # bwd-weight sums its split-K partials with float atomics, whose order varies from launch to launch: same value up to that
+            assert relerr(ops.conv2d_bwd_weight(xa, dyd * 2.0 ** b, w.shape, s, 1), dw0 * 2.0 ** (a + b)) <= 2e-6, (a, b)
+        # 2. zeros in -> exact zeros out (all-zero tiles have no exponent of their own)
+        z = torch.zeros_like(xd)
+        assert float(ops.conv2d_fwd(z, wd, None, s, 1).abs().max()) == 0.0
+        assert float(ops.conv2d_bwd_weight(z, dyd, w.shape, s, 1).abs().max()) == 0.0
+        half = xd.clone(); half[0] = 0                          # one image all zero, the other not
+        yh = ops.conv2d_fwd(half, wd, None, s, 1)
+        assert float(yh[0].abs().max()) == 0.0 and torch.equal(yh[1:], y0[1:])
+        # 3. one outlier 2^30 above the rest: pixels outside its 3x3 reach keep an error far below their own magnitude
+        xo = x.clone(); xo[0, 3, 5, 5] = 2.0 ** 30
+        yo = nchw(ops.conv2d_fwd(nhwc(xo), wd, None, s, 1)).double()
+        ro = F.conv2d(xo.double(), w.double(), None, s, 1)
+        mask = torch.ones_like(ro, dtype=torch.bool)
+        lo, hi = (5 - 1) // s, (5 + 1) // s
+        mask[0, :, max(lo, 0):hi + 1, max(lo, 0):hi + 1] = False
+        assert float((yo - ro)[mask].abs().max()) <= 2.0 ** 30 * 2.0 ** -36     # <= 2^-36 of the tile maximum (bound 2^-39 per term)
+        assert float(((yo - ro)[~mask].abs() / ro[~mask].abs().clamp_min(1)).max()) <= 1e-5
+        # 4. non-finite inputs propagate (no hang, no silent number)
+        xn = xd.clone(); xn[0, 2, 2, 0] = float("inf")
+        yn = ops.conv2d_fwd(xn, wd, None, s, 1)
+        assert not torch.isfinite(yn[0]).all() and torch.isfinite(yn[1:]).all()
+    finally:
+        fovealseg.hip.set_conv_precision("f16x2")
+
+
 def test_maxpool_and_dropout():
     g = torch.Generator().manual_seed(31)
     x = torch.randn(2, 16, 13, 11, generator=g)
