@@ -1,5 +1,5 @@
-// Implicit-GEMM 2-D convolution on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32), NHWC activations,
-// RSCK weights ([R][S][Cin][Cout]).  Replaces ATen conv2d / convolution_backward on the path
+// 2-D convolution entry points of the C ABI (fs_conv2d_fwd / _fwd_stats / _bwd_data / _bwd_weight) and kernel selection.
+// NHWC fp32 activations, RSCK weights ([R][S][Cin][Cout]).  Replaces ATen conv2d / convolution_backward on the path
 // (reference call sites: models/hrnetv2_nodownsp.py:26-29,72-78,190-216,278-282,327-346;
 //  saliency_network.py:308-310; models/model_utils.py:6-13,228-232,260).
 //
@@ -7,9 +7,15 @@
 //   bwd-data  : dX[m][n] = sum_{tap,co} dY[(pix(m)+pad-tap)/s][co] * W[tap][n][co] M=B*H*W   N=Cin
 //   bwd-weight: dW[tap][ci][co] = sum_pix X[pix+tap][ci] * dY[pix][co]             K=B*Ho*Wo (split)
 //
-// Tiling: 256 threads = 4 waves; forward/bwd-data workgroup tile 128 (pixels) x 64 (channels),
-// K-step 32 inside one filter tap; each wave owns 32 x 64 = two 32x32 accumulators.  Operands are
-// staged global -> registers -> LDS with the next stage's loads in flight under the MFMAs.
+// Which kernel runs (precision mode g_conv_precision: 0 = f32, 1 = bf16x3, 2 = f16x2):
+//   3x3 stride 1 pad 1, aligned channels, modes 1/2, scratch given : conv_halo(_f16).hip / conv_wgrad_x3|f16.hip
+//   other multi-tap filters / strided bwd-data sub-problems, modes 1/2 : conv_tapset(_f16).hip
+//   1x1 and single-tap sub-problems, modes 1/2                     : conv_igemm_x3_kernel   (this file, bf16x3)
+//   everything in mode 0, strided / 1x1 bwd-weight                 : conv_igemm_affine_kernel, conv_wgrad_taps_kernel (fp32 MFMA)
+//   channel counts that are not multiples of 4                     : conv_igemm_kernel, conv_wgrad_kernel (generic)
+// The kernels in this file share one tiling: 256 threads = 4 waves, workgroup tile 128 (pixels) x 64 (channels), K-step 32
+// inside one filter tap; each wave owns 32 x 64 = two 32x32 accumulators; operands are staged global -> registers -> LDS
+// with the next stage's loads in flight under the MFMAs.
 #include "common.h"
 #include "conv_halo.h"
 #include <stdlib.h>
