@@ -1144,6 +1144,9 @@ int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
     if (e != hipSuccess) return (int)e;
   }
   const long P = (long)B * Ho * Wo;
+  if (g_conv_precision == 2 && fs_wgrad_f16_eligible(Cin, Cout, R, S, stride, pad, dil) &&
+      (size_t)B * H * W * Cin * 4 < 4294967000UL && (size_t)P * Cout * 4 < 4294967000UL)
+    return fs_wgrad_f16_general(x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, stream);
   if (g_conv_precision >= 1 && H == Ho && W == Wo && fs_wgrad_x3_eligible(Cin, Cout, R, S, stride, pad, dil) &&
       (size_t)B * H * W * Cin * 4 < 4294967000UL && (size_t)P * Cout * 4 < 4294967000UL)
     return g_conv_precision == 2 ? fs_wgrad_f16(x, dy, dw, B, H, W, Cin, Cout, stream) : fs_wgrad_x3(x, dy, dw, B, H, W, Cin, Cout, stream);

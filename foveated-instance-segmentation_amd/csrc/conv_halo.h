@@ -29,6 +29,10 @@ bool fs_wgrad_x3_eligible(int Cin, int Cout, int R, int S, int stride, int pad, 
 int fs_wgrad_x3(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t stream);
 // conv_wgrad_f16.hip: the same in f16x2 split precision
 int fs_wgrad_f16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t stream);
+// any square filter / stride whose tap classes have at most 2 taps per dimension (3x3 s2/s4, 1x1 any stride), plus 3x3 s1
+bool fs_wgrad_f16_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil);
+int fs_wgrad_f16_general(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S,
+                         int stride, int pad, hipStream_t stream);
 
 // conv_tapset.hip: general halo-tiled split-precision convolution over a list of tap classes.
 //   source row of (loop row oy, class tap tr) = sm*(oy + tr) + cy,  filter row r = rbase + rstep*tr  (columns alike)

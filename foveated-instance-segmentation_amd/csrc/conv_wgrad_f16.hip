@@ -48,16 +48,20 @@ __device__ __forceinline__ int exponent_of_bits(unsigned bits) {
 }
 
 struct WgF16Args {
-  const float* x;    // (B,H,W,Cin)
+  const float* x;    // (B,Hx,Wx,Cin)
   const float* dy;   // (B,H,W,Cout)
-  float* dw;         // [3][3][Cin][Cout], zero-initialised
-  int B, H, W, Cin, Cout;
+  float* dw;         // [R][S][Cin][Cout], zero-initialised or accumulated into
+  int B, H, W, Hx, Wx, Cin, Cout;
+  // tap class (conv_halo.h FsTapClass): X row of (dY row oy, class tap tr) = sm*(oy + tr) + cy, filter row rbase + rstep*tr
+  int sm, cy, cx, rbase, rstep, sbase, sstep, S;
   int Ph, Pw, tiles_y, tiles_x, npatch, patches_per_split;
   int tiles_ci, tiles_co;
   unsigned x_bytes, dy_bytes;
 };
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_f16_kernel(WgF16Args a) {
+template <int NR, int NS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_class_f16_kernel(WgF16Args a) {
+  constexpr int NT = NR * NS;
   __shared__ __attribute__((aligned(16))) unsigned char Xl[2 * X_PLANE];
   __shared__ __attribute__((aligned(16))) unsigned char Yl[2 * Y_PLANE];
   __shared__ unsigned amax_cell[2][2];      // [patch parity][X, dY]
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_f16_kernel(WgF16Args a) 
   const int ci0 = tci * 64, co0 = tco * 64;
   const int p_begin = split * a.patches_per_split;
   const int p_end = (p_begin + a.patches_per_split < a.npatch) ? p_begin + a.patches_per_split : a.npatch;
-  const int Wh = a.Pw + 2, nslots = (a.Ph + 2) * Wh, npix = a.Ph * a.Pw, nk = (npix + 15) >> 4;
+  const int Wh = a.Pw + NS - 1, nslots = (a.Ph + NR - 1) * Wh, npix = a.Ph * a.Pw, nk = (npix + 15) >> 4;
   const int tpi = a.tiles_y * a.tiles_x;
 
   // ---- loader constants: item i of a thread = (row (tid>>4) + 16 i, channel quad cq) ----
@@ -112,11 +116,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_f16_kernel(WgF16Args a) 
       xb[ks][t] = wm * X_HALF + (py * Wh + px) * 64 + (cb + 4 * pp) * 2;
     }
   const int yb = wn * Y_HALF + (8 * lh + q) * 64 + (cb + 4 * pp) * 2;      // + ks*1024 + t*256 + plane*Y_PLANE
-  const int rowoff1 = Wh * 64, rowoff2 = 2 * Wh * 64;
+  const int rowoff1 = Wh * 64;
 
-  f32x16 acc[9];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -138,9 +142,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_f16_kernel(WgF16Args a) 
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
       const int hy = xcode[i] >> 16, hx = xcode[i] & 0xffff;
-      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-      const bool ok = xcode[i] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const unsigned off = (unsigned)(((b * a.H + iy) * a.W + ix) * a.Cin + ci0 + 4 * cq) * 4u;
+      const int iy = a.sm * (y0 + hy) + a.cy, ix = a.sm * (x0 + hx) + a.cx;
+      const bool ok = xcode[i] >= 0 && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx;
+      const unsigned off = (unsigned)(((b * a.Hx + iy) * a.Wx + ix) * a.Cin + ci0 + 4 * cq) * 4u;
       rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? (int)off : (int)OOB, 0, 0));
     }
 #pragma unroll
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_f16_kernel(WgF16Args a) 
     if (ex + ey > E) {
       const float f = pow2f(E - ex - ey);
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] *= f;
       E = ex + ey;
@@ -205,13 +209,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_f16_kernel(WgF16Args a) 
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) fa[0][pl] = cat(tr(Xl, xb[ks][0] + pl * X_PLANE), tr(Xl, xb[ks][1] + pl * X_PLANE));
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          if (tap + 1 < 9) {
-            const int r = (tap + 1) / 3, s = (tap + 1) - 3 * r;
-            const int ro = r == 0 ? 0 : (r == 1 ? rowoff1 : rowoff2);
+        for (int tap = 0; tap < NT; ++tap) {
+          if (tap + 1 < NT) {
+            const int r = (tap + 1) / NS, s = (tap + 1) - NS * r;
+            const int ro = r * rowoff1 + s * 64;
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl)
-              fa[(tap + 1) & 1][pl] = cat(tr(Xl, xb[ks][0] + ro + s * 64 + pl * X_PLANE), tr(Xl, xb[ks][1] + ro + s * 64 + pl * X_PLANE));
+              fa[(tap + 1) & 1][pl] = cat(tr(Xl, xb[ks][0] + ro + pl * X_PLANE), tr(Xl, xb[ks][1] + ro + pl * X_PLANE));
           }
           __builtin_amdgcn_sched_barrier(0);
           const f16x8(&A)[2] = fa[tap & 1];
@@ -229,11 +233,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_f16_kernel(WgF16Args a) 
   const float fo1 = pow2f(Eo / 2), fo2 = pow2f(Eo - Eo / 2);
   if (co < a.Cout && p_begin < p_end) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < NT; ++tap) {
+      const int tr_ = tap / NS, ts_ = tap - NS * tr_;
+      const long ftap = (long)(a.rbase + a.rstep * tr_) * a.S + (a.sbase + a.sstep * ts_);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (ci < a.Cin) atomicAdd(&a.dw[((long)tap * a.Cin + ci) * a.Cout + co], acc[tap][r] * fo1 * fo2);
+        if (ci < a.Cin) atomicAdd(&a.dw[(ftap * a.Cin + ci) * a.Cout + co], acc[tap][r] * fo1 * fo2);
       }
     }
   }
@@ -241,35 +247,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_f16_kernel(WgF16Args a) 
 
 // Patch choice: Ph*Pw <= 64 pixels (padded to a multiple of 16 for the k-steps), halo (Ph+2)(Pw+2) <= 112 slots;
 // minimise patches * (k-steps per patch + 1.5).
-void choose_wgrad_patch(int H, int W, int& Ph, int& Pw) {
+void choose_wgrad_patch(int H, int W, int NR, int NS, int& Ph, int& Pw) {
   if (const char* e = getenv("FS_WGRAD_PATCH")) {       // kernel experiments: "PhxPw"
     int ph = 0, pw = 0;
-    if (sscanf(e, "%dx%d", &ph, &pw) == 2 && ph >= 1 && pw >= 1 && ph * pw <= YP && (ph + 2) * (pw + 2) <= XS) { Ph = ph; Pw = pw; return; }
+    if (sscanf(e, "%dx%d", &ph, &pw) == 2 && ph >= 1 && pw >= 1 && ph * pw <= YP && (ph + NR - 1) * (pw + NS - 1) <= XS) { Ph = ph; Pw = pw; return; }
   }
   long best = -1;
   Ph = 8; Pw = 8;
   for (int pw = 2; pw <= 64 && pw <= W + 1; ++pw)
     for (int ph = 1; ph <= 64 && ph <= H + 1; ++ph) {
-      if (ph * pw > YP || (ph + 2) * (pw + 2) > XS) continue;
+      if (ph * pw > YP || (ph + NR - 1) * (pw + NS - 1) > XS) continue;
       const long patches = (long)cdiv(H, ph) * cdiv(W, pw);
       // measured on 20x20 x 256 ch: time ~ patches * (k-steps per patch + 1.5) -- every patch pays a load/split/barrier round
-      const long cost = patches * (2 * cdiv(ph * pw, 16) + 3) * 10000 + ((pw & 3) ? 5000 : 0) + (ph + 2) * (pw + 2);
+      const long cost = patches * (2 * cdiv(ph * pw, 16) + 3) * 10000 + ((pw & 3) ? 5000 : 0) + (ph + NR - 1) * (pw + NS - 1);
       if (best < 0 || cost < best) { best = cost; Ph = ph; Pw = pw; }
     }
 }
 
 }  // namespace
 
-int fs_wgrad_f16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t stream) {
-  if ((size_t)B * H * W * Cin * 4 >= 4294967000UL || (size_t)B * H * W * Cout * 4 >= 4294967000UL) return FS_ERR_ARG;
-  WgF16Args a;
-  a.x = x; a.dy = dy; a.dw = dw;
-  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-  choose_wgrad_patch(H, W, a.Ph, a.Pw);
-  a.tiles_y = cdiv(H, a.Ph); a.tiles_x = cdiv(W, a.Pw);
-  a.npatch = B * a.tiles_y * a.tiles_x;
-  a.tiles_ci = cdiv(Cin, 64); a.tiles_co = cdiv(Cout, 64);
-  const int ntile = a.tiles_ci * a.tiles_co;
+namespace {
+template <int NR, int NS>
+int launch_class(WgF16Args a, int ntile, hipStream_t stream) {
+  choose_wgrad_patch(a.H, a.W, NR, NS, a.Ph, a.Pw);
+  a.tiles_y = cdiv(a.H, a.Ph); a.tiles_x = cdiv(a.W, a.Pw);
+  a.npatch = a.B * a.tiles_y * a.tiles_x;
   // two workgroups fit per CU (LDS, registers): one full round of 512 workgroups, never a short second round.
   // (A wave-specialised variant -- 4 producer + 4 consumer waves, double-buffered LDS, one workgroup per CU -- measured
   // +14 % on this kernel alone and -1 % on the training step, where kernels of other HRNet branches share the CUs.)
@@ -278,9 +280,47 @@ int fs_wgrad_f16(const float* x, const float* dy, float* dw, int B, int H, int W
   if (nsplit > a.npatch) nsplit = a.npatch;
   a.patches_per_split = cdiv(a.npatch, nsplit);
   nsplit = cdiv(a.npatch, a.patches_per_split);
-  a.x_bytes = (unsigned)((size_t)B * H * W * Cin * 4);
-  a.dy_bytes = (unsigned)((size_t)B * H * W * Cout * 4);
-  hipLaunchKernelGGL(conv_wgrad3x3_f16_kernel, dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((conv_wgrad_class_f16_kernel<NR, NS>), dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;
+}
+}  // namespace
+
+bool fs_wgrad_f16_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil) {
+  (void)pad;
+  if (dil != 1 || Cin % 4 || Cout % 4 || Cin < 16 || Cout < 16 || R != S) return false;
+  if (R == 3 && stride == 1) return true;                                   // one class of 3 x 3 taps
+  const int nr = (R + stride - 1) / stride;                                // taps per class and dimension
+  return nr <= 2 && (stride < R ? stride : R) <= 3;                        // classes of 1 or 2 taps per dimension, at most 9 classes
+}
+
+// dW of any conv2d with square filter: one launch per tap class (dw zeroed by the caller or accumulated into)
+int fs_wgrad_f16_general(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S,
+                         int stride, int pad, hipStream_t stream) {
+  if ((size_t)B * H * W * Cin * 4 >= 4294967000UL || (size_t)B * Ho * Wo * Cout * 4 >= 4294967000UL) return FS_ERR_ARG;
+  WgF16Args a;
+  a.x = x; a.dy = dy; a.dw = dw;
+  a.B = B; a.H = Ho; a.W = Wo; a.Hx = H; a.Wx = W; a.Cin = Cin; a.Cout = Cout;
+  a.sm = stride; a.S = S;
+  a.tiles_ci = cdiv(Cin, 64); a.tiles_co = cdiv(Cout, 64);
+  a.x_bytes = (unsigned)((size_t)B * H * W * Cin * 4);
+  a.dy_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * 4);
+  const int ntile = a.tiles_ci * a.tiles_co;
+  for (int r0 = 0; r0 < stride && r0 < R; ++r0)
+    for (int s0 = 0; s0 < stride && s0 < S; ++s0) {
+      const int nR = (R - r0 + stride - 1) / stride, nS = (S - s0 + stride - 1) / stride;
+      a.cy = r0 - pad; a.cx = s0 - pad; a.rbase = r0; a.rstep = stride; a.sbase = s0; a.sstep = stride;
+      int e = FS_ERR_ARG;
+      if (nR == 3 && nS == 3) e = launch_class<3, 3>(a, ntile, stream);
+      else if (nR == 2 && nS == 2) e = launch_class<2, 2>(a, ntile, stream);
+      else if (nR == 2 && nS == 1) e = launch_class<2, 1>(a, ntile, stream);
+      else if (nR == 1 && nS == 2) e = launch_class<1, 2>(a, ntile, stream);
+      else if (nR == 1 && nS == 1) e = launch_class<1, 1>(a, ntile, stream);
+      if (e != FS_OK) return e;
+    }
+  return FS_OK;
+}
+
+int fs_wgrad_f16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t stream) {
+  return fs_wgrad_f16_general(x, dy, dw, B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, stream);
 }
