@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256) void conv_pack_f16_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a) {
+// NW = 32-column sub-tiles per wave: the workgroup covers 64*NW output channels, so the halo image is loaded, scaled and split
+// once for twice the MFMAs when NW = 2 (layers with >= 128 output channels), and an A fragment feeds 2 MFMA groups.
+template <int NW>
+__global__ __launch_bounds__(256, NW == 1 ? 3 : 2) void conv3x3_halo_f16_kernel(HaloF16Args a) {
   __shared__ __attribute__((aligned(16))) _Float16 Ah[2 * PLANE];
   __shared__ __attribute__((aligned(16))) int rowpix[128];
   __shared__ unsigned amax_cell[2];
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
   const int qd = nwg >> 3, rm = nwg & 7;
   const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
   const int mt = wg / a.ny;
-  const int n0 = (wg - mt * a.ny) * 64;
+  const int n0 = (wg - mt * a.ny) * 64 * NW;
   const int tpi = a.tiles_y * a.tiles_x;
   const int b = mt / tpi;
   const int trem = mt - b * tpi;
@@ -185,23 +188,31 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
 #pragma unroll
     for (int r = 0; r < 3; ++r) rowbase[mi][r] = ((py + r) * Wh + px) * XLD + 8 * lh;
   }
-  const int bvoff = HDR + ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2;
+  const int bvoff = HDR + ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2;      // sub-tile j: + j * 64 columns = j * 2048 bytes
   const int plane_bytes = a.Npad * 32;
   const int step_bytes = 2 * plane_bytes;
   const int G = a.nchunk * 18;
 
-  f16x8 fa[2][2][2];   // [buffer][mi][plane]
-  f16x8 fb[3][2];      // [ring slot][plane]: fragments run 2 steps ahead of the MFMAs
-  auto load_b = [&](int g, f16x8 (&dst)[2]) {
+  f16x8 fa[2][2][2];       // [buffer][mi][plane]
+  f16x8 fb[3][NW][2];      // [ring slot][sub-tile][plane]: fragments run 2 steps ahead of the MFMAs
+  auto load_b = [&](int g, f16x8 (&dst)[NW][2]) {
     const int gg = g < G ? g : G - 1;            // wave-uniform: the stream position goes in the scalar offset operand
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff, gg * step_bytes + pl * plane_bytes, 0);
-      dst[pl] = __builtin_bit_cast(f16x8, v);
-    }
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff + j * 2048, gg * step_bytes + pl * plane_bytes, 0);
+        dst[j][pl] = __builtin_bit_cast(f16x8, v);
+      }
   };
 
-  f32x16 acc0 = {0}, acc1 = {0};
+  f32x16 acc[2][NW];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.f;
   int E = EMIN;
   load_b(0, fb[0]);
   load_b(1, fb[1]);
@@ -217,7 +228,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
         const int d = E - ec;
         const float f = d < -126 ? 0.f : pow2f(d);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] *= f; acc1[r] *= f; }
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int j = 0; j < NW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][j][r] *= f;
       }
       E = ec;
     }
@@ -242,13 +257,16 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
       load_b(g + 2, fb[(step + 2) % 3]);
       __builtin_amdgcn_sched_barrier(0);
       const f16x8(&A)[2][2] = fa[step & 1];
-      const f16x8(&Bf)[2] = fb[step % 3];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][0], Bf[1], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][0], Bf[1], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][1], Bf[0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][1], Bf[0], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][0], Bf[0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][0], Bf[0], acc1, 0, 0, 0);
+      const f16x8(&Bf)[NW][2] = fb[step % 3];
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][0], Bf[j][1], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][0], Bf[j][1], acc[1][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][1], Bf[j][0], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][1], Bf[j][0], acc[1][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0][0], Bf[j][0], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1][0], Bf[j][0], acc[1][j], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       ++g;
     }
@@ -256,16 +274,19 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
 
   // ---- epilogue ----
   __syncthreads();
-  const int n = n0 + 32 * wn + l31;
-  float csum = 0.f, csq = 0.f;
-  if (n < a.Cd) {
+  const int Ew = exponent_of_bits(*a.ew);
+  // acc * 2^(E-14) * 2^(Ew-14): one factor when the combined exponent is a normal float, two otherwise
+  const int es = E + Ew - 28;
+  const bool one = es >= -126 && es <= 127;
+  const float f1 = one ? pow2f(es) : pow2f(E - 14), f2 = one ? 1.f : pow2f(Ew - 14);
+  const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
+  float csum[NW], csq[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    csum[j] = 0.f; csq[j] = 0.f;
+    const int n = n0 + 64 * j + 32 * wn + l31;
+    if (n >= a.Cd) continue;
     const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
-    const int Ew = exponent_of_bits(*a.ew);
-    // acc * 2^(E-14) * 2^(Ew-14): one factor when the combined exponent is a normal float, two otherwise
-    const int es = E + Ew - 28;
-    const bool one = es >= -126 && es <= 127;
-    const float f1 = one ? pow2f(es) : pow2f(E - 14), f2 = one ? 1.f : pow2f(Ew - 14);
-    const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -276,23 +297,27 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_f16_kernel(HaloF16Args a)
           const int r = 4 * rg + ri;
           const bool live = pix[ri] >= 0;
           const unsigned e = (unsigned)pix[ri] * (unsigned)a.Cd + (unsigned)n;      // element index (< 2^30: dst_bytes < 4 GB)
-          float v = fmaf((mi == 0 ? acc0[r] : acc1[r]) * f2, f1, bv);
+          float v = fmaf(acc[mi][j][r] * f2, f1, bv);
           if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
           v = live ? v : 0.f;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
-          csum += v; csq += v * v;
+          csum[j] += v; csq[j] += v * v;
         }
       }
     }
   }
   if (a.stats != nullptr) {
-    float* red = reinterpret_cast<float*>(&Ah[0]);     // the halo image is dead since the barrier above
-    const float s1 = csum + __shfl_xor(csum, 32, 64), s2 = csq + __shfl_xor(csq, 32, 64);
-    if (lh == 0) { red[(wm * 64 + 32 * wn + l31) * 2] = s1; red[(wm * 64 + 32 * wn + l31) * 2 + 1] = s2; }
+    float* red = reinterpret_cast<float*>(&Ah[0]);     // [wm][64*NW cols][2]; the halo image is dead since the barrier above
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const float s1 = csum[j] + __shfl_xor(csum[j], 32, 64), s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
+      const int col = 64 * j + 32 * wn + l31;
+      if (lh == 0) { red[(wm * 64 * NW + col) * 2] = s1; red[(wm * 64 * NW + col) * 2 + 1] = s2; }
+    }
     __syncthreads();
-    if (tid < 128) {
-      const int col = tid >> 1, which = tid & 1;
-      const float v = red[col * 2 + which] + red[(64 + col) * 2 + which];
+    for (int t = tid; t < 128 * NW; t += 256) {
+      const int col = t >> 1, which = t & 1;
+      const float v = red[col * 2 + which] + red[(64 * NW + col) * 2 + which];
       if (n0 + col < a.Cd) a.stats[((long)mt * a.Cd + n0 + col) * 2 + which] = v;
     }
   }
@@ -331,8 +356,11 @@ int fs_weight_amax_segments_impl(const float* arena, const long* offsets, const 
   return FS_OK;
 }
 
+static inline int halo_f16_nw(int Cd) { return Cd >= 128 ? 2 : 1; }      // 32-column sub-tiles per wave
+
 long fs_halo_f16_pack_bytes(int Cs, int Cd) {
-  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 63) / 64) * 64;
+  const int nw = halo_f16_nw(Cd);
+  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 64 * nw - 1) / (64 * nw)) * 64 * nw;
   return HDR + nchunk * 18 * 2 * Npad * 16 * 2;
 }
 
@@ -342,12 +370,16 @@ int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, flo
   HaloF16Args a;
   a.src = src; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = dst; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cs = Cs; a.Cd = Cd;
-  a.Npad = ((Cd + 63) / 64) * 64;
+  const int nwp = halo_f16_nw(Cd);
+  a.Npad = ((Cd + 64 * nwp - 1) / (64 * nwp)) * 64 * nwp;      // row count of the pack (fs_halo_f16_pack_bytes)
   a.nchunk = (Cs + 31) / 32;
   fs_halo_patch(H, W, &a.Ph, &a.Pw);
   a.tiles_y = cdiv(H, a.Ph); a.tiles_x = cdiv(W, a.Pw);
   a.nx = B * a.tiles_y * a.tiles_x;
-  a.ny = a.Npad / 64;
+  // 128-column workgroups (two sub-tiles per wave) when they still fill the chip twice over; measured on 512->512 @ 10x10
+  // (256 such workgroups): 144 us against 130 us with 512 workgroups of 64 columns
+  const int nw = (nwp == 2 && (long)a.nx * (a.Npad / 128) >= 512) ? 2 : 1;
+  a.ny = nw == 2 ? a.Npad / 128 : (Cd + 63) / 64;
   a.magic_pw = (unsigned)(4294967296ULL / (unsigned)a.Pw + 1ULL);
   a.magic_wh = (unsigned)(4294967296ULL / (unsigned)(a.Pw + 2) + 1ULL);
   a.src_bytes = (unsigned)((size_t)B * H * W * Cs * 4);
@@ -363,7 +395,8 @@ int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, flo
   hipLaunchKernelGGL(conv_pack_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws),
                      a.ew, Cin, Cout, transposed, Cs, Cd, a.Npad, total);
   FS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(conv3x3_halo_f16_kernel, dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+  if (nw == 2) hipLaunchKernelGGL(conv3x3_halo_f16_kernel<2>, dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(conv3x3_halo_f16_kernel<1>, dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
