@@ -33,8 +33,11 @@ def _profiled_traffic(kernel):
     path = os.path.join(ROOT, "profiles", "r01", "hbm_traffic_serial.json")
     try:
         with open(path) as f:
-            t = json.load(f)[kernel]
-        return {"hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "source": "profiles/r01/hbm_traffic_serial.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+            table = json.load(f)
+        hits = [v for k, v in table.items() if k == kernel or k.startswith(kernel + "<")]      # template instances of one kernel
+        n = sum(v["launches"] for v in hits)
+        avg = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n
+        return {"hbm_bytes_per_launch": int(avg), "source": "profiles/r01/hbm_traffic_serial.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
     except Exception:
         return None
 
@@ -185,8 +188,8 @@ def main():
                 line["roofline"]["measured"] = "second pass of the same K steps with branch streams serialised, HIP events per launch"
                 if "wgrad3x3" in summ:
                     line["roofline_wgrad"] = entry(
-                        summ["wgrad3x3"], f"conv_wgrad3x3_{tag}_kernel (3x3 stride-1 bwd-weight, 9 taps per workgroup, split-K atomics; {how})",
-                        peak, f"conv_wgrad3x3_{tag}_kernel")
+                        summ["wgrad3x3"], f"conv_wgrad_class_{tag}_kernel<3,3> (3x3 stride-1 bwd-weight, 9 taps per workgroup, split-K atomics; {how})",
+                        peak, "conv_wgrad_class_f16_kernel<3, 3>" if tag == "f16" else "conv_wgrad3x3_x3_kernel")
                 if "conv_affine" in summ:
                     line["roofline_other_convs"] = entry(
                         summ["conv_affine"], f"conv_tapset_{tag}_kernel (strided 3x3 forward + bwd-data sub-problems) + conv_igemm_x3_kernel (1x1 and single-tap sub-problems, bf16x3); peak quoted for bf16x3",
