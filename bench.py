@@ -133,20 +133,24 @@ def main():
     # kernel lifetimes overlap and a per-launch duration is not separable; the same K steps are
     # therefore repeated with the branch streams serialised and every conv launch bracketed by HIP
     # events on the launch stream (this pass is NOT part of `value`).
-    timer = None
+    timer, timer_error = None, None
     if not args.no_kernel_timer and world == 1:      # single-GPU only: the step contains collectives
         saved = Mods.PARALLEL_BRANCHES
         Mods.PARALLEL_BRANCHES = False
         timer = ops.KernelTimer()
         ops.TIMER = timer
-        torch.cuda.synchronize()
-        tr0 = time.perf_counter()
-        for i in range(args.steps):
-            T.train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=args.warmup + args.steps + i)
-        torch.cuda.synchronize()
-        serial_elapsed = time.perf_counter() - tr0
-        ops.TIMER = None
-        Mods.PARALLEL_BRANCHES = saved
+        try:
+            torch.cuda.synchronize()
+            tr0 = time.perf_counter()
+            for i in range(args.steps):
+                T.train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=args.warmup + args.steps + i)
+            torch.cuda.synchronize()
+            serial_elapsed = time.perf_counter() - tr0
+        except Exception as exc:                       # the throughput line must survive a failure of the diagnostic pass
+            timer, timer_error = None, repr(exc)
+        finally:
+            ops.TIMER = None
+            Mods.PARALLEL_BRANCHES = saved
     if world > 1:
         dist.barrier()
 
@@ -165,6 +169,9 @@ def main():
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": round(loss_val, 5)},
     }
     if rank == 0:
+        if timer_error is not None:
+            line["roofline"] = None
+            line["roofline_error"] = timer_error
         if timer is not None:
             summ = timer.summary()
             def entry(kk, desc, peak, kname):
