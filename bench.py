@@ -209,7 +209,11 @@ def main():
                     line["roofline_wgrad"] = entry(summ["conv_wgrad"], "conv_wgrad_taps_kernel<3|9> + conv_wgrad_kernel (bwd-weight, fp32 MFMA)",
                                                    PEAK_F32_MFMA_TFLOPS, "conv_wgrad_taps_kernel")
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as exc:
+                line["cpu_baseline"] = None
+                line["cpu_baseline_error"] = repr(exc)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
