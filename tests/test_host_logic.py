@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_header_is_plain_c(tmp_path):
     """The drop-in boundary is a C ABI: include/fovealseg.h must compile as C99 on its own (no torch, no HIP headers)."""
     src = tmp_path / "t.c"
-    src.write_text('#include "fovealseg.h"\nint main(void) { return fs_get_conv_precision == 0; }\n')
+    src.write_text('#include "fovealseg.h"\nint main(void) { int (*f)(void) = fs_get_conv_precision; return f != 0 ? 0 : 1; }\n')
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
