@@ -20,6 +20,7 @@ int fs_halo_conv3x3(const float* src, const float* w, const float* bias, float* 
 void fs_halo_patch(int H, int W, int* Ph, int* Pw);
 // conv_halo_f16.hip: the same convolution in f16x2 split precision (3 fp16 MFMAs per product, scaled operands)
 long fs_halo_f16_pack_bytes(int Cs, int Cd);
+int fs_halo_f16_stats_slabs(int B, int H, int W);      // pixel tiles (= BatchNorm slabs) of the f16x2 kernel
 int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
                         int B, int H, int W, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh,
                         uint32_t drop_key, hipStream_t stream);

@@ -59,6 +59,10 @@ struct HaloF16Args {
   int nx, ny;
   unsigned src_bytes, ws_bytes, dst_bytes;
   unsigned magic_pw, magic_wh;      // 2^32 / Pw + 1, 2^32 / (Pw + 2) + 1
+  // stacked = 1: the batch is tiled as ONE image of B*(H+1) rows, a zero row after every image (the vertical padding the two
+  // neighbours share), so patches need not divide H: 20x20 and 10x10 layers fill 87 % of their tile rows instead of 78 %
+  int stacked, Hv;                  // Hv = H + 1
+  unsigned magic_hv;
   float drop_scale; uint32_t drop_thresh, drop_key;
 };
 
@@ -115,18 +119,31 @@ __global__ __launch_bounds__(256, NW == 1 ? 3 : 2) void conv3x3_halo_f16_kernel(
   const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
   const int mt = wg / a.ny;
   const int n0 = (wg - mt * a.ny) * 64 * NW;
+  // plain: tile (b, ty, tx) of image b.  stacked: tile (ty, tx) of the virtual image, y0 is a virtual row.
   const int tpi = a.tiles_y * a.tiles_x;
-  const int b = mt / tpi;
-  const int trem = mt - b * tpi;
+  const int b0 = a.stacked ? 0 : mt / tpi;
+  const int trem = mt - b0 * tpi;
   const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
   const int y0 = ty * a.Ph, x0 = tx * a.Pw;
   const int Wh = a.Pw + 2, nslots = (a.Ph + 2) * Wh;
+  // (image, row) of virtual row vy; rows outside every image (gap rows, beyond the batch) get row = H (invalid)
+  auto image_row = [&](int vy, int& bb, int& yy) {
+    if (a.stacked) {
+      const bool in = vy >= 0 && vy < a.B * a.Hv;
+      bb = in ? div_small(vy, a.magic_hv) : 0;
+      yy = in ? vy - bb * a.Hv : a.H;
+    } else {
+      bb = b0; yy = (vy >= 0 && vy < a.H) ? vy : a.H;
+    }
+  };
 
   if (tid < 128) {
     const int p = (tid & ~31) + row_perm(tid & 31);
     const int py = div_small(p, a.magic_pw), px = p - py * a.Pw;
-    const bool live = p < a.Ph * a.Pw && y0 + py < a.H && x0 + px < a.W;
-    rowpix[tid] = live ? ((b * a.H + y0 + py) * a.W + x0 + px) : -1;
+    int bb, yy;
+    image_row(y0 + py, bb, yy);
+    const bool live = p < a.Ph * a.Pw && yy < a.H && x0 + px < a.W;
+    rowpix[tid] = live ? ((bb * a.H + yy) * a.W + x0 + px) : -1;
   }
   if (tid < 2) amax_cell[tid] = 0u;
   const int q = tid & 7;
@@ -136,9 +153,11 @@ __global__ __launch_bounds__(256, NW == 1 ? 3 : 2) void conv3x3_halo_f16_kernel(
     int hy = div_small(tid >> 3, a.magic_wh), hx = (tid >> 3) - hy * Wh;
 #pragma unroll
     for (int i = 0; i < NITEM; ++i) {
-      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-      const bool ok = (tid >> 3) + 32 * i < nslots && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      goff[i] = ok ? ((b * a.H + iy) * a.W + ix) * a.Cs + 4 * q : -1;
+      const int ix = x0 + hx - 1;
+      int bb, iy;
+      image_row(y0 + hy - 1, bb, iy);
+      const bool ok = (tid >> 3) + 32 * i < nslots && iy < a.H && ix >= 0 && ix < a.W;
+      goff[i] = ok ? ((bb * a.H + iy) * a.W + ix) * a.Cs + 4 * q : -1;
       hx += r32; hy += q32;
       if (hx >= Wh) { hx -= Wh; ++hy; }
     }
@@ -358,6 +377,29 @@ int fs_weight_amax_segments_impl(const float* arena, const long* offsets, const 
 
 static inline int halo_f16_nw(int Cd) { return Cd >= 128 ? 2 : 1; }      // 32-column sub-tiles per wave
 
+// Tiling of the output pixels: per image (fs_halo_patch) or over the stacked batch, whichever needs fewer 128-row tiles.
+static void halo_f16_plan(int B, int H, int W, int& Ph, int& Pw, int& stacked, int& tiles_y, int& tiles_x, int& nx) {
+  fs_halo_patch(H, W, &Ph, &Pw);
+  stacked = 0;
+  tiles_y = cdiv(H, Ph); tiles_x = cdiv(W, Pw);
+  nx = B * tiles_y * tiles_x;
+  const long rows = (long)B * (H + 1);
+  if (rows >= 65536) return;                       // div_small range
+  for (int pw = 4; pw <= 64 && pw <= W + 3; ++pw) {
+    int ph = 128 / pw;
+    while (ph > 1 && (ph + 2) * (pw + 2) > NSMAX) --ph;
+    if (ph < 1 || (ph + 2) * (pw + 2) > NSMAX) continue;
+    const long t = (long)cdiv(rows, ph) * cdiv(W, pw);
+    if (t < nx) { nx = (int)t; stacked = 1; Ph = ph; Pw = pw; tiles_y = cdiv(rows, ph); tiles_x = cdiv(W, pw); }
+  }
+}
+
+int fs_halo_f16_stats_slabs(int B, int H, int W) {
+  int Ph, Pw, st, ty, tx, nx;
+  halo_f16_plan(B, H, W, Ph, Pw, st, ty, tx, nx);
+  return nx;
+}
+
 long fs_halo_f16_pack_bytes(int Cs, int Cd) {
   const int nw = halo_f16_nw(Cd);
   const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 64 * nw - 1) / (64 * nw)) * 64 * nw;
@@ -373,9 +415,9 @@ int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, flo
   const int nwp = halo_f16_nw(Cd);
   a.Npad = ((Cd + 64 * nwp - 1) / (64 * nwp)) * 64 * nwp;      // row count of the pack (fs_halo_f16_pack_bytes)
   a.nchunk = (Cs + 31) / 32;
-  fs_halo_patch(H, W, &a.Ph, &a.Pw);
-  a.tiles_y = cdiv(H, a.Ph); a.tiles_x = cdiv(W, a.Pw);
-  a.nx = B * a.tiles_y * a.tiles_x;
+  halo_f16_plan(B, H, W, a.Ph, a.Pw, a.stacked, a.tiles_y, a.tiles_x, a.nx);
+  a.Hv = H + 1;
+  a.magic_hv = (unsigned)(4294967296ULL / (unsigned)a.Hv + 1ULL);
   // 128-column workgroups (two sub-tiles per wave) when they still fill the chip twice over; measured on 512->512 @ 10x10
   // (256 such workgroups): 144 us against 130 us with 512 workgroups of 64 columns
   const int nw = (nwp == 2 && (long)a.nx * (a.Npad / 128) >= 512) ? 2 : 1;
