@@ -418,9 +418,9 @@ int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, flo
   halo_f16_plan(B, H, W, a.Ph, a.Pw, a.stacked, a.tiles_y, a.tiles_x, a.nx);
   a.Hv = H + 1;
   a.magic_hv = (unsigned)(4294967296ULL / (unsigned)a.Hv + 1ULL);
-  // 128-column workgroups (two sub-tiles per wave) when they still fill the chip twice over; measured on 512->512 @ 10x10
-  // (256 such workgroups): 144 us against 130 us with 512 workgroups of 64 columns
-  const int nw = (nwp == 2 && (long)a.nx * (a.Npad / 128) >= 512) ? 2 : 1;
+  // 128-column workgroups (two sub-tiles per wave) while there are still ~1.75 of them per CU; measured on 512->512 @ 10x10
+  // (256 such workgroups): 144 us against 130 us with 512 workgroups of 64 columns; 448 on 256->256 @ 20x20: +0.7 % on the step
+  const int nw = (nwp == 2 && (long)a.nx * (a.Npad / 128) >= 440) ? 2 : 1;
   a.ny = nw == 2 ? a.Npad / 128 : (Cd + 63) / 64;
   a.magic_pw = (unsigned)(4294967296ULL / (unsigned)a.Pw + 1ULL);
   a.magic_wh = (unsigned)(4294967296ULL / (unsigned)(a.Pw + 2) + 1ULL);
