@@ -921,7 +921,7 @@ int launch_affine_one(AffArgs& a) {
 
 // The halo-tiled 3x3 kernel (conv_halo.hip) runs when the split-precision mode is on, the shape qualifies and the
 // caller handed over enough scratch for the weight pack.
-long halo_pack_bytes(int Cs, int Cd) { return g_conv_precision == 2 ? fs_halo_f16_pack_bytes(Cs, Cd) : fs_halo_pack_bytes(Cs, Cd); }
+long halo_pack_bytes(int Cs, int Cd) { return fs_halo_pack_bytes(g_conv_precision, Cs, Cd); }
 bool use_halo(const ConvArgs& c) {
   return g_conv_precision >= 1 && c.ws_ != nullptr && fs_halo_eligible(c.Hd, c.Wd, c.Cs, c.Cd, c.R, c.S, c.stride, c.pad, c.dil) &&
          c.Hs == c.Hd && c.Ws == c.Wd && c.ws_bytes_ >= halo_pack_bytes(c.Cs, c.Cd) &&
@@ -980,12 +980,10 @@ int launch_affine(const ConvArgs& c, long M) {
     p.cls[0] = FsTapClass{c.pad - (c.R - 1), c.pad - (c.S - 1), c.R, c.S, c.R - 1, -1, c.S - 1, -1};
     return run_tapset(p, c.stream_);
   }
-  if (use_halo(c) && g_conv_precision == 2)
-    return fs_halo_f16_conv3x3(c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cs, c.Cd, c.transposed ? c.Cd : c.Cs,
-                               c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key, c.stream_);
   if (use_halo(c))
-    return fs_halo_conv3x3(c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.B, c.Hd, c.Wd, c.Cs, c.Cd, c.transposed ? c.Cd : c.Cs,
-                           c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key, c.stream_);
+    return fs_halo_conv3x3(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cs, c.Cd,
+                           c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key,
+                           c.stream_);
   if (!c.transposed || c.stride == 1) return launch_affine_one(a);
   // stride>1 bwd-data: one dense sub-problem per output parity class (oy0, ox0).  dX pixel y receives
   // tap r iff (y + pad - r) % stride == 0, i.e. r = r0 + stride*t with r0 = (oy0 + pad) % stride, and then
@@ -1057,9 +1055,9 @@ int fs_conv2d_stats_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout
   const long need = fs_conv2d_workspace_bytes(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0);
   if (need > 0 && ws_bytes >= need) {
     const bool halo = H == Ho && W == Wo && fs_halo_eligible(H, W, Cin, Cout, R, S, stride, pad, dil);
-    if (halo && !g_tapset_all) return g_conv_precision == 2 ? fs_halo_f16_stats_slabs(B, Ho, Wo) : fs_halo_stats_slabs(B, Ho, Wo);
+    if (halo && !g_tapset_all) return fs_halo_stats_slabs(B, Ho, Wo);
     if (tapset_shape_ok(Cin, Cout, R, S, stride, dil)) return fs_tapset_slabs(B, Ho, Wo, (R + stride - 1) / stride, (S + stride - 1) / stride);
-    if (halo) return g_conv_precision == 2 ? fs_halo_f16_stats_slabs(B, Ho, Wo) : fs_halo_stats_slabs(B, Ho, Wo);
+    if (halo) return fs_halo_stats_slabs(B, Ho, Wo);
   }
   return cdiv((long)B * Ho * Wo, 128);
 }

@@ -4,26 +4,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ---- conv_halo.hip: halo-tiled 3x3 / stride 1 / pad 1 kernel.  mode: 1 = bf16x3, 2 = f16x2 (conv_split.h) ----------------
 // 3x3, stride 1, pad 1, dilation 1, channel counts multiples of 4, K >= 32
 bool fs_halo_eligible(int H, int W, int Cs, int Cd, int R, int S, int stride, int pad, int dil);
-// bytes of the pre-split weight pack for K = Cs source channels and N = Cd destination channels
-long fs_halo_pack_bytes(int Cs, int Cd);
-// number of pixel tiles (= BatchNorm partial-sum slabs) the halo kernel uses for a (B,H,W) output
+// bytes of the pre-split weight pack (header included) for K = Cs source channels and N = Cd destination channels
+long fs_halo_pack_bytes(int mode, int Cs, int Cd);
+// number of pixel tiles (= BatchNorm partial-sum slabs) the kernel uses for a (B,H,W) output
 int fs_halo_stats_slabs(int B, int H, int W);
-// pack w (RSCK fp32, logical Cin x Cout) into ws, then run the conv.  transposed = 1: bwd-data (src = dY with
-// Cs = Cout channels, dst = dX with Cd = Cin channels).  stats may be null.
-int fs_halo_conv3x3(const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, int B, int H, int W,
-                    int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,
-                    hipStream_t stream);
-
-// patch (Ph x Pw output pixels per workgroup) the halo kernels use for an H x W image
-void fs_halo_patch(int H, int W, int* Ph, int* Pw);
-// conv_halo_f16.hip: the same convolution in f16x2 split precision (3 fp16 MFMAs per product, scaled operands)
-long fs_halo_f16_pack_bytes(int Cs, int Cd);
-int fs_halo_f16_stats_slabs(int B, int H, int W);      // pixel tiles (= BatchNorm slabs) of the f16x2 kernel
-int fs_halo_f16_conv3x3(const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
-                        int B, int H, int W, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh,
-                        uint32_t drop_key, hipStream_t stream);
+// pack w (RSCK fp32, logical Cin x Cout) into ws, then run the conv.  transposed = 1: bwd-data (src = dY with Cs = Cout channels,
+// dst = dX with Cd = Cin channels).  stats may be null.  w_amax: max|w| bits kept by the caller, or null (f16x2 only).
+int fs_halo_conv3x3(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
+                    int B, int H, int W, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh,
+                    uint32_t drop_key, hipStream_t stream);
+// where the f16x2 kernels read max |w| (float bits) of a weight tensor: w_amax when the caller maintains it, else the first
+// word of ws, filled here by a memset + atomic-max kernel.
+const unsigned* fs_f16_weight_amax(const float* w, long n, void* ws, const unsigned* w_amax, hipStream_t stream, int* err);
+int fs_weight_amax_segments_impl(const float* arena, const long* offsets, const long* sizes, int nparams, unsigned* out, hipStream_t stream);
 
 // conv_wgrad_x3.hip: split-precision weight gradient of a 3x3 / stride-1 / pad-1 convolution (dw must be zeroed).
 bool fs_wgrad_x3_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil);

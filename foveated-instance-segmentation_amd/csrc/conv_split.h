@@ -1,0 +1,74 @@
+// Split-precision arithmetic shared by the halo-tiled convolution kernels (conv_halo.hip, conv_tapset.hip, conv_wgrad.hip).
+// An fp32 operand reaches the matrix cores as NPL 16-bit planes; a product is the sum of the plane products that matter:
+//   PrecF16 ("f16x2"): x * 2^s = h1 + h2 (two fp16, 22 bits), product = h1 g2 + h2 g1 + h1 g1  (3 MFMAs), operands scaled
+//   PrecX3 ("bf16x3"): x = x1 + x2 + x3 (three bf16, 24 bits), product = x1y3 + x2y2 + x3y1 + x1y2 + x2y1 + x1y1 (6 MFMAs)
+// Both accumulate in fp32 (v_mfma_f32_32x32x16_{f16,bf16}); DESIGN.md "Precision modes".
+#pragma once
+#include "common.h"
+
+namespace fs_split {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOB = 0xFFFFFFF0u;      // raw-buffer offset past every tensor: the load returns 0, the store is dropped
+constexpr int HDR = 256;                   // bytes of pack header (max|w| bits at offset 0 when the library computes them)
+constexpr int EMIN = -100;                 // exponent floor (all-zero tiles)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float pow2f(int e) {          // 2^e, 0 below the normal range
+  return e < -126 ? 0.f : __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
+__device__ __forceinline__ int exponent_of_bits(unsigned bits) {
+  const int e = (int)((bits >> 23) & 0xffu) - 127;
+  return e < EMIN ? EMIN : e;
+}
+// n / d for 0 <= n < 65536 with m = 2^32 / d + 1 precomputed on the host (exact for d <= 65535): two VALU instead of ~25
+__device__ __forceinline__ int div_small(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }
+static inline unsigned div_magic(int d) { return (unsigned)(4294967296ULL / (unsigned)d + 1ULL); }
+// ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (per 32-lane half).  Map the 32 rows of
+// an MFMA tile to patch pixels so that each group reads 16 CONSECUTIVE pixels (conflict-free 80-byte rows).
+__device__ __forceinline__ int row_perm(int l) {
+  const bool g1 = (l >= 4 && l < 12) || (l >= 16 && l < 20) || l >= 28;
+  if (!g1) return l < 4 ? l : (l < 16 ? l - 8 : l - 12);
+  return 16 + (l < 12 ? l - 4 : (l < 20 ? l - 8 : l - 16));
+}
+
+struct PrecF16 {
+  typedef _Float16 T;
+  typedef _Float16 x8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 x4 __attribute__((ext_vector_type(4)));
+  static constexpr int NPL = 2;
+  static constexpr bool SCALED = true;
+  static __device__ __forceinline__ void split(float xs, T (&p)[NPL]) {
+    p[0] = (T)xs;
+    p[1] = (T)(xs - (float)p[0]);
+  }
+  // product terms (A plane, B plane), smallest first; kernels interleave them over their accumulators
+  static constexpr int NTERM = 3;
+  static __device__ __forceinline__ constexpr int ta(int t) { return t == 1 ? 1 : 0; }
+  static __device__ __forceinline__ constexpr int tb(int t) { return t == 0 ? 1 : 0; }
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+struct PrecX3 {
+  typedef __bf16 T;
+  typedef __bf16 x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 x4 __attribute__((ext_vector_type(4)));
+  static constexpr int NPL = 3;
+  static constexpr bool SCALED = false;
+  static __device__ __forceinline__ void split(float x, T (&p)[NPL]) {
+    p[0] = (T)x;
+    const float r = x - (float)p[0];
+    p[1] = (T)r;
+    p[2] = (T)(r - (float)p[1]);
+  }
+  static constexpr int NTERM = 6;            // (0,2) (1,1) (2,0) (0,1) (1,0) (0,0)
+  static __device__ __forceinline__ constexpr int ta(int t) { return t < 3 ? t : (t == 4 ? 1 : 0); }
+  static __device__ __forceinline__ constexpr int tb(int t) { return t < 3 ? 2 - t : (t == 3 ? 1 : 0); }
+  static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+}  // namespace fs_split
