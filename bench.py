@@ -182,24 +182,24 @@ def main():
                         "avg_launch_us": round(1000.0 * kk["total_ms"] / kk["launches"], 2),
                         "gflop_per_launch": round(kk["flops"] / kk["launches"] / 1e9, 3),
                         "share_of_serial_step": round(kk["total_ms"] / (1000.0 * serial_elapsed), 3)}
-            split = {"f16x2": ("f16", PEAK_F16_MFMA_TFLOPS / 3.0, "two scaled fp16 terms per operand, 3 x v_mfma_f32_32x32x16_f16 per product"),
-                     "bf16x3": ("x3", PEAK_BF16_MFMA_TFLOPS / 6.0, "three bf16 terms per operand, 6 x v_mfma_f32_32x32x16_bf16 per product")}
+            split = {"f16x2": ("PrecF16", PEAK_F16_MFMA_TFLOPS / 3.0, "two scaled fp16 terms per operand, 3 x v_mfma_f32_32x32x16_f16 per product"),
+                     "bf16x3": ("PrecX3", PEAK_BF16_MFMA_TFLOPS / 6.0, "three bf16 terms per operand, 6 x v_mfma_f32_32x32x16_bf16 per product")}
             if args.conv_precision in split and "conv3x3" in summ:
                 tag, peak, how = split[args.conv_precision]
                 line["roofline"] = entry(
                     summ["conv3x3"],
-                    f"conv3x3_halo_{tag}_kernel (3x3 stride-1 forward + bwd-data, halo-tiled implicit GEMM; {how}, fp32 accumulate; "
+                    f"conv3x3_halo_kernel<{tag}> (3x3 stride-1 forward + bwd-data, halo-tiled implicit GEMM; {how}, fp32 accumulate; "
                     "achieved = algorithmic fp32 FLOP/s over the C-ABI call incl. its weight pack pre-kernels, peak = dense MFMA peak / "
-                    "MFMAs per product)", peak, f"conv3x3_halo_{tag}_kernel")
+                    "MFMAs per product)", peak, "conv3x3_halo_kernel")
                 line["roofline"]["serial_ms_per_step"] = round(1000.0 * serial_elapsed / args.steps, 2)
                 line["roofline"]["measured"] = "second pass of the same K steps with branch streams serialised, HIP events per launch"
                 if "wgrad3x3" in summ:
                     line["roofline_wgrad"] = entry(
-                        summ["wgrad3x3"], f"conv_wgrad_class_{tag}_kernel<3,3> (3x3 stride-1 bwd-weight, 9 taps per workgroup, split-K atomics; {how})",
-                        peak, "conv_wgrad_class_f16_kernel<3, 3>" if tag == "f16" else "conv_wgrad3x3_x3_kernel")
+                        summ["wgrad3x3"], f"conv_wgrad_class_kernel<{tag},3,3> (3x3 stride-1 bwd-weight, 9 taps per workgroup, split-K atomics; {how})",
+                        peak, f"conv_wgrad_class_kernel<fs_split::{tag}, 3, 3>")
                 if "conv_affine" in summ:
                     line["roofline_other_convs"] = entry(
-                        summ["conv_affine"], f"conv_tapset_{tag}_kernel (strided 3x3 forward + bwd-data sub-problems) + conv_igemm_x3_kernel (1x1 and single-tap sub-problems, bf16x3); peak quoted for bf16x3",
+                        summ["conv_affine"], f"conv_tapset_kernel<{tag}> (strided 3x3 forward + bwd-data sub-problems) + conv_igemm_x3_kernel (1x1 and single-tap sub-problems, bf16x3); peak quoted for bf16x3",
                         PEAK_BF16_MFMA_TFLOPS / 6.0, "conv_igemm_x3_kernel")
             elif "conv_affine" in summ:
                 line["roofline"] = entry(summ["conv_affine"], "conv_igemm_affine_kernel<1> (fwd + bwd-data implicit GEMM, fp32 MFMA 32x32x2)",

@@ -8,10 +8,10 @@
 //   bwd-weight: dW[tap][ci][co] = sum_pix X[pix+tap][ci] * dY[pix][co]             K=B*Ho*Wo (split)
 //
 // Which kernel runs (precision mode g_conv_precision: 0 = f32, 1 = bf16x3, 2 = f16x2):
-//   3x3 stride 1 pad 1, aligned channels, modes 1/2, scratch given : conv_halo(_f16).hip / conv_wgrad_x3|f16.hip
-//   other multi-tap filters / strided bwd-data sub-problems, modes 1/2 : conv_tapset(_f16).hip
+//   3x3 stride 1 pad 1, aligned channels, modes 1/2, scratch given : conv_halo.hip (fwd, bwd-data), conv_wgrad.hip (bwd-weight)
+//   other multi-tap filters / strided bwd-data sub-problems, modes 1/2 : conv_tapset.hip; bwd-weight per tap class: conv_wgrad.hip
 //   1x1 and single-tap sub-problems, modes 1/2                     : conv_igemm_x3_kernel   (this file, bf16x3)
-//   everything in mode 0, strided / 1x1 bwd-weight                 : conv_igemm_affine_kernel, conv_wgrad_taps_kernel (fp32 MFMA)
+//   everything in mode 0                                           : conv_igemm_affine_kernel, conv_wgrad_taps_kernel (fp32 MFMA)
 //   channel counts that are not multiples of 4                     : conv_igemm_kernel, conv_wgrad_kernel (generic)
 // The kernels in this file share one tiling: 256 threads = 4 waves, workgroup tile 128 (pixels) x 64 (channels), K-step 32
 // inside one filter tap; each wave owns 32 x 64 = two 32x32 accumulators; operands are staged global -> registers -> LDS
@@ -937,14 +937,12 @@ bool tapset_shape_ok(int Cs, int Cd, int R, int S, int stride, int dil) {
   return dil == 1 && (R * S > 1 || g_tapset_1x1) && Cs % 4 == 0 && Cd % 4 == 0 && Cs >= 16 && cr * cs <= 9 &&
          ((R + stride - 1) / stride) * ((S + stride - 1) / stride) <= 64;
 }
-long tapset_pack_bytes(int Cs, int Cd, int taps) {
-  return g_conv_precision == 2 ? fs_tapset_f16_pack_bytes(Cs, Cd, taps) : fs_tapset_pack_bytes(Cs, Cd, taps);
-}
+long tapset_pack_bytes(int Cs, int Cd, int taps) { return fs_tapset_pack_bytes(g_conv_precision, Cs, Cd, taps); }
 bool use_tapset(const ConvArgs& c) {
   return g_conv_precision >= 1 && c.ws_ != nullptr && tapset_shape_ok(c.Cs, c.Cd, c.R, c.S, c.stride, c.dil) &&
          c.ws_bytes_ >= tapset_pack_bytes(c.Cs, c.Cd, c.R * c.S) && (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL;
 }
-int run_tapset(const FsTapsetProblem& p, hipStream_t stream) { return g_conv_precision == 2 ? fs_tapset_f16_conv(p, stream) : fs_tapset_conv(p, stream); }
+int run_tapset(const FsTapsetProblem& p, hipStream_t stream) { return fs_tapset_conv(g_conv_precision, p, stream); }
 FsTapsetProblem tapset_base(const ConvArgs& c) {
   FsTapsetProblem p{};
   p.src = c.src; p.w = c.w; p.bias = c.bias; p.dst = c.dst; p.stats = c.stats_; p.ws = c.ws_; p.w_amax = c.w_amax_;
@@ -1142,12 +1140,9 @@ int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
     if (e != hipSuccess) return (int)e;
   }
   const long P = (long)B * Ho * Wo;
-  if (g_conv_precision == 2 && fs_wgrad_f16_eligible(Cin, Cout, R, S, stride, pad, dil) &&
+  if (g_conv_precision >= 1 && fs_wgrad_split_eligible(Cin, Cout, R, S, stride, pad, dil) &&
       (size_t)B * H * W * Cin * 4 < 4294967000UL && (size_t)P * Cout * 4 < 4294967000UL)
-    return fs_wgrad_f16_general(x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, stream);
-  if (g_conv_precision >= 1 && H == Ho && W == Wo && fs_wgrad_x3_eligible(Cin, Cout, R, S, stride, pad, dil) &&
-      (size_t)B * H * W * Cin * 4 < 4294967000UL && (size_t)P * Cout * 4 < 4294967000UL)
-    return g_conv_precision == 2 ? fs_wgrad_f16(x, dy, dw, B, H, W, Cin, Cout, stream) : fs_wgrad_x3(x, dy, dw, B, H, W, Cin, Cout, stream);
+    return fs_wgrad_split(g_conv_precision, x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, stream);
   const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);
   // one filter row per workgroup for narrow layers (more workgroups, fewer atomics each), the whole 3x3
   // filter per workgroup once there are >= 9 channel tiles (measured: 64^2/128^2 87-90 TF with 3,

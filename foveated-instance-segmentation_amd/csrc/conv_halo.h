@@ -21,15 +21,11 @@ int fs_halo_conv3x3(int mode, const float* src, const float* w, const float* bia
 const unsigned* fs_f16_weight_amax(const float* w, long n, void* ws, const unsigned* w_amax, hipStream_t stream, int* err);
 int fs_weight_amax_segments_impl(const float* arena, const long* offsets, const long* sizes, int nparams, unsigned* out, hipStream_t stream);
 
-// conv_wgrad_x3.hip: split-precision weight gradient of a 3x3 / stride-1 / pad-1 convolution (dw must be zeroed).
-bool fs_wgrad_x3_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil);
-int fs_wgrad_x3(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t stream);
-// conv_wgrad_f16.hip: the same in f16x2 split precision
-int fs_wgrad_f16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t stream);
+// ---- conv_wgrad.hip: split-precision weight gradient, one launch per tap class (dw zeroed by the caller or accumulated into) ----
 // any square filter / stride whose tap classes have at most 2 taps per dimension (3x3 s2/s4, 1x1 any stride), plus 3x3 s1
-bool fs_wgrad_f16_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil);
-int fs_wgrad_f16_general(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S,
-                         int stride, int pad, hipStream_t stream);
+bool fs_wgrad_split_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil);
+int fs_wgrad_split(int mode, const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S,
+                   int stride, int pad, hipStream_t stream);
 
 // conv_tapset.hip: general halo-tiled split-precision convolution over a list of tap classes.
 //   source row of (loop row oy, class tap tr) = sm*(oy + tr) + cy,  filter row r = rbase + rstep*tr  (columns alike)
@@ -43,14 +39,7 @@ struct FsTapsetProblem {
   int ncls; FsTapClass cls[9];
   float drop_scale; uint32_t drop_thresh, drop_key;
 };
-long fs_tapset_pack_bytes(int Cs, int Cd, int total_taps);
+long fs_tapset_pack_bytes(int mode, int Cs, int Cd, int total_taps);
 int fs_tapset_slabs(int B, int Hq, int Wq, int maxR, int maxS);
-int fs_tapset_conv(const FsTapsetProblem& p, hipStream_t stream);
+int fs_tapset_conv(int mode, const FsTapsetProblem& p, hipStream_t stream);      // mode: 1 = bf16x3, 2 = f16x2
 void fs_tapset_patch(int Hq, int Wq, int maxR, int maxS, int* Ph, int* Pw);
-// conv_tapset_f16.hip: the same in f16x2 split precision
-long fs_tapset_f16_pack_bytes(int Cs, int Cd, int total_taps);
-int fs_tapset_f16_conv(const FsTapsetProblem& p, hipStream_t stream);
-// conv_halo_f16.hip: where the kernels read max |w| (float bits) of a weight tensor: w_amax when the caller maintains it,
-// else the first word of ws, filled here by a memset + atomic-max kernel.
-const unsigned* fs_f16_weight_amax(const float* w, long n, void* ws, const unsigned* w_amax, hipStream_t stream, int* err);
-int fs_weight_amax_segments_impl(const float* arena, const long* offsets, const long* sizes, int nparams, unsigned* out, hipStream_t stream);

@@ -51,6 +51,11 @@ struct PrecF16 {
   static __device__ __forceinline__ constexpr int ta(int t) { return t == 1 ? 1 : 0; }
   static __device__ __forceinline__ constexpr int tb(int t) { return t == 0 ? 1 : 0; }
   static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  // ds_read_b64_tr_b16: 4 rows x 16 columns of an LDS image, delivered column-major (cdna_hip_programming.md T10)
+  static __device__ __forceinline__ x4 tr_read(const unsigned char* lds) {
+    typedef __fp16 v4 __attribute__((vector_size(8)));
+    return __builtin_bit_cast(x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) v4*)lds));
+  }
 };
 
 struct PrecX3 {
@@ -69,6 +74,9 @@ struct PrecX3 {
   static __device__ __forceinline__ constexpr int ta(int t) { return t < 3 ? t : (t == 4 ? 1 : 0); }
   static __device__ __forceinline__ constexpr int tb(int t) { return t < 3 ? 2 - t : (t == 3 ? 1 : 0); }
   static __device__ __forceinline__ f32x16 mfma(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ x4 tr_read(const unsigned char* lds) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) x4*)lds);
+  }
 };
 
 }  // namespace fs_split

@@ -1,4 +1,4 @@
-// General halo-tiled split-precision (bf16x3) convolution: forward with any stride, and every bwd-data
+// General halo-tiled split-precision convolution (conv_split.h: f16x2 or bf16x3): forward with any stride, and every bwd-data
 // sub-problem, written as a list of "tap classes".  A class is a set of filter taps whose source pixels form a
 // dense grid in units of `sm` source pixels per output pixel:
 //     source row of (output row oy, class tap tr) = sm * (oy + tr) + cy,      filter row r = rbase + rstep * tr
@@ -6,63 +6,45 @@
 // (the input parity planes); 3x3 stride 4 = nine 1-tap classes; 1x1 stride s = one 1-tap class; the bwd-data
 // sub-problem of one output parity class = one class with rstep = -stride.
 // For each (class, 32-channel chunk) the workgroup loads the class's (Ph+nR-1) x (Pw+nS-1) source halo of its
-// Ph x Pw output patch once, splits it into three bf16 planes in LDS, and all taps of the class read it at
-// shifted slot offsets.  Weights come pre-split from conv_tapset_pack_kernel in consumption order, as 16-byte
+// Ph x Pw output patch once, (scales and) splits it into 16-bit planes in LDS, and all taps of the class read it at
+// shifted slot offsets.  Weights come pre-split from conv_tapset_pack_kernel in consumption order (scaled by the tensor exponent in f16x2; the running
+// activation exponent of conv_halo.hip is updated at every LDS refill), as 16-byte
 // global loads straight into MFMA B fragments.  Same tiling as conv_halo.hip (128 x 64 tile, wave tile 64 x 32).
-#include "common.h"
+#include "conv_split.h"
 #include "conv_halo.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
+using namespace fs_split;
 
-constexpr int XLD = 40;            // bf16 per LDS slot (80 bytes)
+constexpr int XLD = 40;            // 16-bit elements per LDS slot (80 bytes)
 constexpr int NSMAX = 224;         // halo slots per plane
 constexpr int NITEM = 7;           // NSMAX * 8 quads / 256 threads
 constexpr int PLANE = NSMAX * XLD;
-constexpr unsigned OOB = 0xFFFFFFF0u;
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c) {
-  a = (__bf16)x;
-  const float r = x - (float)a;
-  b = (__bf16)r;
-  c = (__bf16)(r - (float)b);
-}
-// ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (per 32-lane half).  Map the
-// 32 rows of an MFMA tile to patch pixels so that each group reads 16 CONSECUTIVE pixels (conflict-free 80-B rows).
-__device__ __forceinline__ int row_perm(int l) {
-  const bool g1 = (l >= 4 && l < 12) || (l >= 16 && l < 20) || l >= 28;
-  if (!g1) return l < 4 ? l : (l < 16 ? l - 8 : l - 12);
-  return 16 + (l < 12 ? l - 4 : (l < 20 ? l - 8 : l - 16));
-}
-
 struct TsArgs {
-  const float* src; const __bf16* wp; const float* bias; float* dst; float* stats;
+  const float* src; const unsigned char* ws; const unsigned* ew; const float* bias; float* dst; float* stats;
   int B, Hs, Ws, Cs, Hd, Wd, Cd;
   int Hq, Wq, os, oy0, ox0, sm;
   int ncls;
   FsTapClass cls[9];
   int Npad, nchunk, ttot;
   int Ph, Pw, tiles_y, tiles_x, nx, ny;
-  unsigned src_bytes, wp_bytes;
+  unsigned src_bytes, wp_bytes, dst_bytes;
   float drop_scale; uint32_t drop_thresh, drop_key;
 };
 
 // Wp[g = 2*T + s2][plane][n][j]: T enumerates (class, chunk, tap) in consumption order; k = 32*chunk + 16*s2 + j.
 //   forward : value = W[r][s][k][n]      bwd-data: value = W[r][s][n][k]      (w is [R][S][Cin][Cout])
-__global__ __launch_bounds__(256) void conv_tapset_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int Cin, int Cout, int S,
+template <class P>
+__global__ __launch_bounds__(256) void conv_tapset_pack_kernel(const float* __restrict__ w, unsigned char* __restrict__ ws, const unsigned* __restrict__ ew, int Cin, int Cout, int S,
                                                                int transposed, int Ks, int Ns, int Npad, int nchunk, int ncls,
                                                                FsTapClass c0, FsTapClass c1, FsTapClass c2, FsTapClass c3, FsTapClass c4,
                                                                FsTapClass c5, FsTapClass c6, FsTapClass c7, FsTapClass c8, long total) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const FsTapClass cls[9] = {c0, c1, c2, c3, c4, c5, c6, c7, c8};
+  const float sc = P::SCALED ? pow2f(14 - exponent_of_bits(*ew)) : 1.f;
+  typename P::T* wp = reinterpret_cast<typename P::T*>(ws + HDR);
   const int n = (int)(idx % Npad);
   const int g = (int)(idx / Npad);
   const int s2 = g & 1;
@@ -80,26 +62,32 @@ __global__ __launch_bounds__(256) void conv_tapset_pack_kernel(const float* __re
     T -= nt * nchunk;
   }
   const int k0 = chunk * 32 + s2 * 16;
-  bf16x8 p[3][2];
+  typename P::x8 p[P::NPL][2];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int k = k0 + j;
     float v = 0.f;
     if (n < Ns && k < Ks) v = transposed ? w[((long)(r * S + s) * Cin + n) * Cout + k] : w[((long)(r * S + s) * Cin + k) * Cout + n];
-    __bf16 x, y, z;
-    split3(v, x, y, z);
-    p[0][j >> 3][j & 7] = x; p[1][j >> 3][j & 7] = y; p[2][j >> 3][j & 7] = z;
+    typename P::T t[P::NPL];
+    P::split(v * sc, t);
+#pragma unroll
+    for (int pl = 0; pl < P::NPL; ++pl) p[pl][j >> 3][j & 7] = t[pl];
   }
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) {
-    bf16x8* o = reinterpret_cast<bf16x8*>(wp + (((long)g * 3 + pl) * Npad + n) * 16);
+  for (int pl = 0; pl < P::NPL; ++pl) {
+    typename P::x8* o = reinterpret_cast<typename P::x8*>(wp + (((long)g * P::NPL + pl) * Npad + n) * 16);
     o[0] = p[pl][0]; o[1] = p[pl][1];
   }
 }
 
-__global__ __launch_bounds__(256) void conv_tapset_x3_kernel(TsArgs a) {
-  __shared__ __attribute__((aligned(16))) __bf16 Ah[3 * PLANE];
+template <class P>
+__global__ __launch_bounds__(256) void conv_tapset_kernel(TsArgs a) {
+  typedef typename P::x8 X8;
+  typedef typename P::x4 X4;
+  constexpr int NPL = P::NPL;
+  __shared__ __attribute__((aligned(16))) typename P::T Ah[NPL * PLANE];
   __shared__ __attribute__((aligned(16))) int rowpix[128];
+  __shared__ unsigned amax_cell[2];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -136,7 +124,8 @@ __global__ __launch_bounds__(256) void conv_tapset_x3_kernel(TsArgs a) {
 
   const int q = tid & 7;
   const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(a.src, a.src_bytes);
-  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.wp, a.wp_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.ws, a.wp_bytes);
+  if (tid < 2) amax_cell[tid] = 0u;
 
   // ---- halo loader state (runs one (class, chunk) ahead of the MFMA loop) ----
   int goff[NITEM];
@@ -166,73 +155,92 @@ __global__ __launch_bounds__(256) void conv_tapset_x3_kernel(TsArgs a) {
       ra[i] = __builtin_bit_cast(f32x4, v);
     }
   };
-  auto store_halo = [&]() {
+  auto tile_amax = [&](int cell) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(ra[i][e]));
+    m = wave_max(m);
+    if (lane == 0) atomicMax(&amax_cell[cell], __builtin_bit_cast(unsigned, m));
+  };
+  auto store_halo = [&](float sc) {
 #pragma unroll
     for (int i = 0; i < NITEM; ++i) {
       const int slot = (tid >> 3) + 32 * i;
-      bf16x4 p0, p1, p2;
+      X4 p[NPL];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { __bf16 x, y, z; split3(ra[i][e], x, y, z); p0[e] = x; p1[e] = y; p2[e] = z; }
+      for (int e = 0; e < 4; ++e) {
+        typename P::T t[NPL];
+        P::split(P::SCALED ? ra[i][e] * sc : ra[i][e], t);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) p[pl][e] = t[pl];
+      }
       const int o = slot * XLD + 4 * q;
-      *reinterpret_cast<bf16x4*>(&Ah[o]) = p0;
-      *reinterpret_cast<bf16x4*>(&Ah[PLANE + o]) = p1;
-      *reinterpret_cast<bf16x4*>(&Ah[2 * PLANE + o]) = p2;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Ah[pl * PLANE + o]) = p[pl];
     }
   };
 
   // ---- B fragments ----
-  const int bvoff = ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2;
+  const int bvoff = HDR + ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2;
   const int plane_bytes = a.Npad * 32;
-  const int step_bytes = 3 * plane_bytes;
+  const int step_bytes = NPL * plane_bytes;
   const int G = 2 * a.ttot;
-  auto load_b = [&](int g, bf16x8 (&dst)[3]) {
+  auto load_b = [&](int g, X8 (&dst)[NPL]) {
     const int gg = g < G ? g : G - 1;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff + gg * step_bytes + pl * plane_bytes, 0, 0);
-      dst[pl] = __builtin_bit_cast(bf16x8, v);
+    for (int pl = 0; pl < NPL; ++pl) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff, gg * step_bytes + pl * plane_bytes, 0);
+      dst[pl] = __builtin_bit_cast(X8, v);
     }
   };
 
   f32x16 acc0 = {0}, acc1 = {0};
-  bf16x8 fa[2][2][3];        // [k16 step][mi][plane]
-  bf16x8 fbA[2][3], fbB[2][3];
+  X8 fa[2][2][NPL];         // [k16 step][mi][plane]
+  X8 fbA[2][NPL], fbB[2][NPL];
+  int E = EMIN, par = 0;
   // MFMA-loop state
   int c = 0, chunk = 0, tap = 0, tr = 0, ts = 0;
   int ntaps = a.cls[0].nR * a.cls[0].nS, nS = a.cls[0].nS, Wh = a.Pw + a.cls[0].nS - 1;
   int rowbase[2];
   int T = 0;
 
-  auto read_a = [&](int toff, int s2, bf16x8 (&dst)[2][3]) {
+  auto read_a = [&](int toff, int s2, X8 (&dst)[2][NPL]) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) dst[mi][pl] = *reinterpret_cast<const bf16x8*>(&Ah[pl * PLANE + rowbase[mi] + toff + 16 * s2]);
+      for (int pl = 0; pl < NPL; ++pl) dst[mi][pl] = *reinterpret_cast<const X8*>(&Ah[pl * PLANE + rowbase[mi] + toff + 16 * s2]);
   };
-  auto mfma12 = [&](const bf16x8 (&A)[2][3], const bf16x8 (&Bf)[3]) {
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][0], Bf[2], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][0], Bf[2], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][1], Bf[1], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][1], Bf[1], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][2], Bf[0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][2], Bf[0], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][0], Bf[1], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][0], Bf[1], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][1], Bf[0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][1], Bf[0], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][0], Bf[0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][0], Bf[0], acc1, 0, 0, 0);
+  auto mfmas = [&](const X8 (&A)[2][NPL], const X8 (&Bf)[NPL]) {
+#pragma unroll
+    for (int t = 0; t < P::NTERM; ++t) {           // smallest terms first, the two pixel halves interleaved
+      acc0 = P::mfma(A[0][P::ta(t)], Bf[P::tb(t)], acc0);
+      acc1 = P::mfma(A[1][P::ta(t)], Bf[P::tb(t)], acc1);
+    }
   };
   // one filter tap = two k16 steps; `cur` holds this tap's B fragments, `nxt` receives the next tap's
-  auto tap_body = [&](bf16x8 (&cur)[2][3], bf16x8 (&nxt)[2][3]) {
+  auto tap_body = [&](X8 (&cur)[2][NPL], X8 (&nxt)[2][NPL]) {
     if (tap == 0) {                      // first tap of a (class, chunk): refill LDS
       if (chunk == 0) {
         ntaps = a.cls[c].nR * a.cls[c].nS; nS = a.cls[c].nS; Wh = a.Pw + nS - 1;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) rowbase[mi] = (fpy[mi] * Wh + fpx[mi]) * XLD + 8 * lh;
       }
-      __syncthreads();
-      store_halo();
+      if (P::SCALED) tile_amax(par);
+      __syncthreads();                      // amax complete; every wave has finished reading the previous image
+      if (P::SCALED) {
+        const int ec = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[par]));
+        if (ec > E) {
+          const float f = pow2f(E - ec);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc0[r] *= f; acc1[r] *= f; }
+          E = ec;
+        }
+        par ^= 1;
+        if (tid == 0) amax_cell[par] = 0u;
+      }
+      store_halo(pow2f(14 - E));
       __syncthreads();
       if (++pchunk == a.nchunk) { pchunk = 0; ++pc; if (pc < a.ncls) class_offsets(pc); }
       if (pc < a.ncls) load_halo(pchunk);
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(256) void conv_tapset_x3_kernel(TsArgs a) {
     read_a(toff, 1, fa[1]);
     load_b(2 * T + 2, nxt[0]);
     __builtin_amdgcn_sched_barrier(0);
-    mfma12(fa[0], cur[0]);
+    mfmas(fa[0], cur[0]);
     __builtin_amdgcn_sched_barrier(0);
     // step 1
     int ntr = tr, nts = ts + 1;
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256) void conv_tapset_x3_kernel(TsArgs a) {
     if (tap + 1 < ntaps) read_a((ntr * Wh + nts) * XLD, 0, fa[0]);
     load_b(2 * T + 3, nxt[1]);
     __builtin_amdgcn_sched_barrier(0);
-    mfma12(fa[1], cur[1]);
+    mfmas(fa[1], cur[1]);
     __builtin_amdgcn_sched_barrier(0);
     tr = ntr; ts = nts;
     ++T;
@@ -264,6 +272,7 @@ __global__ __launch_bounds__(256) void conv_tapset_x3_kernel(TsArgs a) {
     load_b(1, fbA[1]);
     class_offsets(0);
     load_halo(0);
+    __syncthreads();                        // amax cells zeroed before the first atomic
     while (T < a.ttot) {
       tap_body(fbA, fbB);
       if (T < a.ttot) tap_body(fbB, fbA);
@@ -276,6 +285,15 @@ __global__ __launch_bounds__(256) void conv_tapset_x3_kernel(TsArgs a) {
   float csum = 0.f, csq = 0.f;
   if (n < a.Cd) {
     const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
+    float f1 = 1.f, f2 = 1.f;
+    if (P::SCALED) {
+      const int Ew = exponent_of_bits(*a.ew);
+      const int es = E + Ew - 28;
+      const bool one = es >= -126 && es <= 127;
+      f1 = one ? pow2f(es) : pow2f(E - 14);
+      f2 = one ? 1.f : pow2f(Ew - 14);
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -283,12 +301,13 @@ __global__ __launch_bounds__(256) void conv_tapset_x3_kernel(TsArgs a) {
         const i32x4 pix = *reinterpret_cast<const i32x4*>(&rowpix[64 * wm + 32 * mi + 8 * rg + 4 * lh]);
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri) {
-          if (pix[ri] < 0) continue;
           const int r = 4 * rg + ri;
-          float v = (mi == 0 ? acc0[r] : acc1[r]) + bv;
-          const long e = (long)pix[ri] * a.Cd + n;
+          const bool live = pix[ri] >= 0;
+          const unsigned e = (unsigned)pix[ri] * (unsigned)a.Cd + (unsigned)n;
+          float v = P::SCALED ? fmaf((mi == 0 ? acc0[r] : acc1[r]) * f2, f1, bv) : (mi == 0 ? acc0[r] : acc1[r]) + bv;
           if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-          a.dst[e] = v;
+          v = live ? v : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
           csum += v; csq += v * v;
         }
       }
@@ -325,9 +344,9 @@ void fs_tapset_patch(int Hq, int Wq, int maxR, int maxS, int* Ph, int* Pw) {
   }
 }
 
-long fs_tapset_pack_bytes(int Cs, int Cd, int total_taps) {
+long fs_tapset_pack_bytes(int mode, int Cs, int Cd, int total_taps) {
   const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 63) / 64) * 64;
-  return nchunk * total_taps * 2 * 3 * Npad * 16 * 2;
+  return HDR + nchunk * total_taps * 2 * (mode == 2 ? 2 : 3) * Npad * 16 * 2;
 }
 
 int fs_tapset_slabs(int B, int Hq, int Wq, int maxR, int maxS) {
@@ -336,9 +355,26 @@ int fs_tapset_slabs(int B, int Hq, int Wq, int maxR, int maxS) {
   return B * cdiv(Hq, Ph) * cdiv(Wq, Pw);
 }
 
-int fs_tapset_conv(const FsTapsetProblem& p, hipStream_t stream) {
+namespace {
+template <class P>
+int run_tapset(TsArgs& a, const FsTapsetProblem& p, hipStream_t stream) {
+  int e = FS_OK;
+  a.ew = P::SCALED ? fs_f16_weight_amax(p.w, (long)p.R * p.S * p.Cin * p.Cout, p.ws, p.w_amax, stream, &e) : nullptr;
+  if (e != FS_OK) return e;
+  const long total = (long)a.ttot * 2 * a.Npad;
+  hipLaunchKernelGGL((conv_tapset_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.w,
+                     reinterpret_cast<unsigned char*>(p.ws), a.ew, p.Cin, p.Cout, p.S, p.transposed, p.Cs, p.Cd, a.Npad, a.nchunk, a.ncls,
+                     a.cls[0], a.cls[1], a.cls[2], a.cls[3], a.cls[4], a.cls[5], a.cls[6], a.cls[7], a.cls[8], total);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL((conv_tapset_kernel<P>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+}  // namespace
+
+int fs_tapset_conv(int mode, const FsTapsetProblem& p, hipStream_t stream) {
   TsArgs a;
-  a.src = p.src; a.wp = reinterpret_cast<const __bf16*>(p.ws); a.bias = p.bias; a.dst = p.dst; a.stats = p.stats;
+  a.src = p.src; a.ws = reinterpret_cast<const unsigned char*>(p.ws); a.bias = p.bias; a.dst = p.dst; a.stats = p.stats;
   a.B = p.B; a.Hs = p.Hs; a.Ws = p.Ws; a.Cs = p.Cs; a.Hd = p.Hd; a.Wd = p.Wd; a.Cd = p.Cd;
   a.Hq = p.Hq; a.Wq = p.Wq; a.os = p.os; a.oy0 = p.oy0; a.ox0 = p.ox0; a.sm = p.sm;
   a.ncls = p.ncls;
@@ -361,18 +397,12 @@ int fs_tapset_conv(const FsTapsetProblem& p, hipStream_t stream) {
   a.tiles_y = cdiv(p.Hq, a.Ph); a.tiles_x = cdiv(p.Wq, a.Pw);
   a.nx = p.B * a.tiles_y * a.tiles_x;
   a.ny = a.Npad / 64;
-  const long pack_bytes = fs_tapset_pack_bytes(p.Cs, p.Cd, total_taps);
-  if (pack_bytes >= 2147483647L || (size_t)p.B * p.Hs * p.Ws * p.Cs * 4 >= 4294967000UL || (long)p.B * p.Hd * p.Wd >= 2147483647L)
+  const long pack_bytes = fs_tapset_pack_bytes(mode, p.Cs, p.Cd, total_taps);
+  if (pack_bytes >= 2147483647L || (size_t)p.B * p.Hs * p.Ws * p.Cs * 4 >= 4294967000UL || (size_t)p.B * p.Hd * p.Wd * p.Cd * 4 >= 4294967000UL)
     return FS_ERR_ARG;
   a.src_bytes = (unsigned)((size_t)p.B * p.Hs * p.Ws * p.Cs * 4);
+  a.dst_bytes = (unsigned)((size_t)p.B * p.Hd * p.Wd * p.Cd * 4);
   a.wp_bytes = (unsigned)pack_bytes;
   a.drop_scale = p.drop_scale; a.drop_thresh = p.drop_thresh; a.drop_key = p.drop_key;
-  const long total = (long)a.ttot * 2 * a.Npad;
-  hipLaunchKernelGGL(conv_tapset_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.w, reinterpret_cast<__bf16*>(p.ws),
-                     p.Cin, p.Cout, p.S, p.transposed, p.Cs, p.Cd, a.Npad, a.nchunk, a.ncls, a.cls[0], a.cls[1], a.cls[2], a.cls[3],
-                     a.cls[4], a.cls[5], a.cls[6], a.cls[7], a.cls[8], total);
-  FS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(conv_tapset_x3_kernel, dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
-  FS_LAUNCH_CHECK();
-  return FS_OK;
+  return mode == 2 ? run_tapset<PrecF16>(a, p, stream) : run_tapset<PrecX3>(a, p, stream);
 }

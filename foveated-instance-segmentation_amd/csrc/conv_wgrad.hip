@@ -1,26 +1,31 @@
-// Weight gradient of a 3x3 / stride-1 / pad-1 convolution in the f16x2 split precision (see conv_halo_f16.hip for the
-// arithmetic; conv_wgrad_x3.hip for the tiling, which is identical: 64(ci) x 64(co) tile of all 9 taps per workgroup,
-// split-K over pixel patches, X halo and dY patch kept in LDS in [pixel][channel] order and read transposed with
-// ds_read_b64_tr_b16).  Two fp16 planes per operand, three MFMAs per product.
+// Weight gradient of a convolution on the 16-bit MFMA pipe in split precision (conv_split.h: f16x2 or bf16x3), one launch
+// per tap class (conv_halo.h FsTapClass; 3x3 stride 1 = one class of 9 taps):
+//     dW[r][s][ci][co] = sum_{b,y,x} X[b][sm*(y+tr)+cy][sm*(x+ts)+cx][ci] * dY[b][y][x][co],   (r, s) = class tap (tr, ts)
 //
-// Scaling: per patch the workgroup takes max|X| over the halo tile and max|dY| over the patch (exponents ex, ey) and
-// keeps a running exponent E of the accumulators' unit (products are accumulated in units of 2^(E-28)).  If
-// ex + ey > E the nine accumulators are rescaled by the exact power of two and E = ex + ey; dY is scaled by 2^(14-ey)
-// and X by 2^(14-(E-ey)) (<= 2^(14-ex): never overflows; a patch far below the running magnitude loses low-order bits
-// only relative to what is already accumulated).  The atomics at the end add acc * 2^(E-28).
-#include "common.h"
+// GEMM view: M = ci, N = co, K = pixels.  A workgroup owns one 64(ci) x 64(co) tile of ALL taps of the class (NR*NS 32x32
+// accumulators per wave) and a contiguous range of pixel patches (split-K over patches, fp32 atomics at the end).
+// Per patch (Ph x Pw <= 64 pixels of one image) it loads the dY patch and the (Ph+NR-1) x (Pw+NS-1) X halo once, (scales and)
+// splits both into 16-bit planes while writing them to LDS in their natural [pixel][channel] order, and every tap reads the
+// SAME X image at a slot offset of (tr*(Pw+NS-1) + ts).  Both MFMA operands need K (= pixel) contiguous per lane, i.e. the
+// transpose of the LDS image: that is what ds_read_b64_tr_b16 delivers (4 pixel rows x 16 channels per 16-lane group,
+// column-major), two of them per 8-deep fragment.
+//
+// LDS: X  [NPL planes][2 channel halves][112 slots][32 ch]  (64-B rows: 4 consecutive slots of one half cover all 64 banks
+//      dY [NPL planes][2 channel halves][ 64 pix  ][32 ch]   exactly once)  -> 45 KB (f16x2) / 67.5 KB (bf16x3): two per CU
+//
+// f16x2 scaling: per patch the workgroup takes max|X| over the halo tile and max|dY| over the patch (exponents ex, ey) and keeps
+// a running exponent E of the accumulators' unit (products are accumulated in units of 2^(E-28)).  If ex + ey > E the
+// accumulators are rescaled by the exact power of two and E = ex + ey; dY is scaled by 2^(14-ey) and X by 2^(14-(E-ey))
+// (<= 2^(14-ex): never overflows; a patch far below the running magnitude loses low-order bits only relative to what is already
+// accumulated).  The atomics at the end add acc * 2^(E-28).
+#include "conv_split.h"
 #include "conv_halo.h"
 #include <stdio.h>
 #include <stdlib.h>
 
 namespace {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __fp16 fp16v4 __attribute__((vector_size(8)));
-typedef __attribute__((address_space(3))) fp16v4* lds_f16x4_ptr;
-constexpr int EMIN = -100;
+using namespace fs_split;
 
 constexpr int XS = 112;               // halo slots per patch (max)
 constexpr int YP = 64;                // pixels per patch (max)
@@ -30,24 +35,7 @@ constexpr int Y_HALF = YP * 64;
 constexpr int Y_PLANE = 2 * Y_HALF;
 constexpr int NXI = XS * 16 / 256;    // 7 float4 loads per thread for the X halo
 constexpr int NYI = YP * 16 / 256;    // 4 for the dY patch
-constexpr unsigned OOB = 0xFFFFFFF0u;
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ void split2(float xs, _Float16& a, _Float16& b) {
-  a = (_Float16)xs;
-  b = (_Float16)(xs - (float)a);
-}
-__device__ __forceinline__ float pow2f(int e) {          // 2^e, 0 below the normal range
-  return e < -126 ? 0.f : __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
-}
-__device__ __forceinline__ int exponent_of_bits(unsigned bits) {
-  const int e = (int)((bits >> 23) & 0xffu) - 127;
-  return e < EMIN ? EMIN : e;
-}
-
-struct WgF16Args {
+struct WgArgs {
   const float* x;    // (B,Hx,Wx,Cin)
   const float* dy;   // (B,H,W,Cout)
   float* dw;         // [R][S][Cin][Cout], zero-initialised or accumulated into
@@ -59,11 +47,13 @@ struct WgF16Args {
   unsigned x_bytes, dy_bytes;
 };
 
-template <int NR, int NS>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_class_f16_kernel(WgF16Args a) {
-  constexpr int NT = NR * NS;
-  __shared__ __attribute__((aligned(16))) unsigned char Xl[2 * X_PLANE];
-  __shared__ __attribute__((aligned(16))) unsigned char Yl[2 * Y_PLANE];
+template <class P, int NR, int NS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
+  typedef typename P::x8 X8;
+  typedef typename P::x4 X4;
+  constexpr int NT = NR * NS, NPL = P::NPL;
+  __shared__ __attribute__((aligned(16))) unsigned char Xl[NPL * X_PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char Yl[NPL * Y_PLANE];
   __shared__ unsigned amax_cell[2][2];      // [patch parity][X, dY]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -124,10 +114,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_f16_kernel(WgF16Args 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  auto tr = [&](const unsigned char* base, int off) -> f16x4 {
-    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4_ptr)(base + off)));
-  };
-  auto cat = [](f16x4 lo, f16x4 hi) -> f16x8 { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); };
+  auto tr = [&](const unsigned char* base, int off) -> X4 { return P::tr_read(base + off); };
+  auto cat = [](X4 lo, X4 hi) -> X8 { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); };
   if (tid < 4) amax_cell[tid >> 1][tid & 1] = 0u;
   __syncthreads();
   int E = 2 * EMIN - 1, par = 0;
@@ -155,7 +143,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_f16_kernel(WgF16Args 
       const unsigned off = (unsigned)(((b * a.H + y) * a.W + x) * a.Cout + co0 + 4 * cq) * 4u;
       ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, ok ? (int)off : (int)OOB, 0, 0));
     }
-    {   // tile maxima -> LDS cells of this patch's parity
+    float sx = 1.f, sy = 1.f;
+    if (P::SCALED) {   // tile maxima -> LDS cells of this patch's parity
       float mx = 0.f, my = 0.f;
 #pragma unroll
       for (int i = 0; i < NXI; ++i)
@@ -169,59 +158,70 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_f16_kernel(WgF16Args 
       if (lane == 0) { atomicMax(&amax_cell[par][0], __builtin_bit_cast(unsigned, mx)); atomicMax(&amax_cell[par][1], __builtin_bit_cast(unsigned, my)); }
     }
     __syncthreads();     // maxima complete; every wave has finished reading the previous patch
-    const int ex = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[par][0]));
-    const int ey = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[par][1]));
-    if (ex + ey > E) {
-      const float f = pow2f(E - ex - ey);
+    if (P::SCALED) {
+      const int ex = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[par][0]));
+      const int ey = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[par][1]));
+      if (ex + ey > E) {
+        const float f = pow2f(E - ex - ey);
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] *= f;
-      E = ex + ey;
+          for (int r = 0; r < 16; ++r) acc[t][r] *= f;
+        E = ex + ey;
+      }
+      sx = pow2f(14 - (E - ey)); sy = pow2f(14 - ey);
+      par ^= 1;
+      if (tid < 2) amax_cell[par][tid] = 0u;
     }
-    const float sx = pow2f(14 - (E - ey)), sy = pow2f(14 - ey);
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
-      f16x4 p0, p1;
+      X4 p[NPL];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { _Float16 u, v; split2(rx[i][e] * sx, u, v); p0[e] = u; p1[e] = v; }
-      *reinterpret_cast<f16x4*>(&Xl[xw + i * 1024]) = p0;
-      *reinterpret_cast<f16x4*>(&Xl[xw + i * 1024 + X_PLANE]) = p1;
+      for (int e = 0; e < 4; ++e) {
+        typename P::T t[NPL];
+        P::split(P::SCALED ? rx[i][e] * sx : rx[i][e], t);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) p[pl][e] = t[pl];
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Xl[xw + i * 1024 + pl * X_PLANE]) = p[pl];
     }
 #pragma unroll
     for (int i = 0; i < NYI; ++i) {
-      f16x4 p0, p1;
+      X4 p[NPL];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { _Float16 u, v; split2(ry[i][e] * sy, u, v); p0[e] = u; p1[e] = v; }
-      *reinterpret_cast<f16x4*>(&Yl[yw + i * 1024]) = p0;
-      *reinterpret_cast<f16x4*>(&Yl[yw + i * 1024 + Y_PLANE]) = p1;
+      for (int e = 0; e < 4; ++e) {
+        typename P::T t[NPL];
+        P::split(P::SCALED ? ry[i][e] * sy : ry[i][e], t);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) p[pl][e] = t[pl];
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Yl[yw + i * 1024 + pl * Y_PLANE]) = p[pl];
     }
-    par ^= 1;
-    if (tid < 2) amax_cell[par][tid] = 0u;
     __syncthreads();
 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       if (ks < nk) {
-        f16x8 fb[2], fa[2][2];
+        X8 fb[NPL], fa[2][NPL];
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) fb[pl] = cat(tr(Yl, yb + ks * 1024 + pl * Y_PLANE), tr(Yl, yb + ks * 1024 + 256 + pl * Y_PLANE));
+        for (int pl = 0; pl < NPL; ++pl) fb[pl] = cat(tr(Yl, yb + ks * 1024 + pl * Y_PLANE), tr(Yl, yb + ks * 1024 + 256 + pl * Y_PLANE));
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) fa[0][pl] = cat(tr(Xl, xb[ks][0] + pl * X_PLANE), tr(Xl, xb[ks][1] + pl * X_PLANE));
+        for (int pl = 0; pl < NPL; ++pl) fa[0][pl] = cat(tr(Xl, xb[ks][0] + pl * X_PLANE), tr(Xl, xb[ks][1] + pl * X_PLANE));
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
           if (tap + 1 < NT) {
             const int r = (tap + 1) / NS, s = (tap + 1) - NS * r;
             const int ro = r * rowoff1 + s * 64;
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
+            for (int pl = 0; pl < NPL; ++pl)
               fa[(tap + 1) & 1][pl] = cat(tr(Xl, xb[ks][0] + ro + pl * X_PLANE), tr(Xl, xb[ks][1] + ro + pl * X_PLANE));
           }
           __builtin_amdgcn_sched_barrier(0);
-          const f16x8(&A)[2] = fa[tap & 1];
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], fb[1], acc[tap], 0, 0, 0);
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], fb[0], acc[tap], 0, 0, 0);
-          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], fb[0], acc[tap], 0, 0, 0);
+          const X8(&A)[NPL] = fa[tap & 1];
+#pragma unroll
+          for (int t = 0; t < P::NTERM; ++t) acc[tap] = P::mfma(A[P::ta(t)], fb[P::tb(t)], acc[tap]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_f16_kernel(WgF16Args 
 
   const int co = co0 + 32 * wn + (lane & 31);
   const int Eo = E - 28;                                   // two factors: the combined exponent can leave the float range
-  const float fo1 = pow2f(Eo / 2), fo2 = pow2f(Eo - Eo / 2);
+  const float fo1 = P::SCALED ? pow2f(Eo / 2) : 1.f, fo2 = P::SCALED ? pow2f(Eo - Eo / 2) : 1.f;
   if (co < a.Cout && p_begin < p_end) {
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
@@ -267,8 +267,8 @@ void choose_wgrad_patch(int H, int W, int NR, int NS, int& Ph, int& Pw) {
 }  // namespace
 
 namespace {
-template <int NR, int NS>
-int launch_class(WgF16Args a, int ntile, hipStream_t stream) {
+template <class P, int NR, int NS>
+int launch_class(WgArgs a, int ntile, hipStream_t stream) {
   choose_wgrad_patch(a.H, a.W, NR, NS, a.Ph, a.Pw);
   a.tiles_y = cdiv(a.H, a.Ph); a.tiles_x = cdiv(a.W, a.Pw);
   a.npatch = a.B * a.tiles_y * a.tiles_x;
@@ -280,13 +280,30 @@ int launch_class(WgF16Args a, int ntile, hipStream_t stream) {
   if (nsplit > a.npatch) nsplit = a.npatch;
   a.patches_per_split = cdiv(a.npatch, nsplit);
   nsplit = cdiv(a.npatch, a.patches_per_split);
-  hipLaunchKernelGGL((conv_wgrad_class_f16_kernel<NR, NS>), dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((conv_wgrad_class_kernel<P, NR, NS>), dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+template <class P>
+int run_classes(WgArgs& a, int ntile, int R, int S, int stride, int pad, hipStream_t stream) {
+  for (int r0 = 0; r0 < stride && r0 < R; ++r0)
+    for (int s0 = 0; s0 < stride && s0 < S; ++s0) {
+      const int nR = (R - r0 + stride - 1) / stride, nS = (S - s0 + stride - 1) / stride;
+      a.cy = r0 - pad; a.cx = s0 - pad; a.rbase = r0; a.rstep = stride; a.sbase = s0; a.sstep = stride;
+      int e = FS_ERR_ARG;
+      if (nR == 3 && nS == 3) e = launch_class<P, 3, 3>(a, ntile, stream);
+      else if (nR == 2 && nS == 2) e = launch_class<P, 2, 2>(a, ntile, stream);
+      else if (nR == 2 && nS == 1) e = launch_class<P, 2, 1>(a, ntile, stream);
+      else if (nR == 1 && nS == 2) e = launch_class<P, 1, 2>(a, ntile, stream);
+      else if (nR == 1 && nS == 1) e = launch_class<P, 1, 1>(a, ntile, stream);
+      if (e != FS_OK) return e;
+    }
   return FS_OK;
 }
 }  // namespace
 
-bool fs_wgrad_f16_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil) {
+bool fs_wgrad_split_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil) {
   (void)pad;
   if (dil != 1 || Cin % 4 || Cout % 4 || Cin < 16 || Cout < 16 || R != S) return false;
   if (R == 3 && stride == 1) return true;                                   // one class of 3 x 3 taps
@@ -294,11 +311,11 @@ bool fs_wgrad_f16_eligible(int Cin, int Cout, int R, int S, int stride, int pad,
   return nr <= 2 && (stride < R ? stride : R) <= 3;                        // classes of 1 or 2 taps per dimension, at most 9 classes
 }
 
-// dW of any conv2d with square filter: one launch per tap class (dw zeroed by the caller or accumulated into)
-int fs_wgrad_f16_general(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S,
-                         int stride, int pad, hipStream_t stream) {
+// dW of any conv2d with square filter: one launch per tap class (dw zeroed by the caller or accumulated into).  mode: 1 = bf16x3, 2 = f16x2
+int fs_wgrad_split(int mode, const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S,
+                   int stride, int pad, hipStream_t stream) {
   if ((size_t)B * H * W * Cin * 4 >= 4294967000UL || (size_t)B * Ho * Wo * Cout * 4 >= 4294967000UL) return FS_ERR_ARG;
-  WgF16Args a;
+  WgArgs a;
   a.x = x; a.dy = dy; a.dw = dw;
   a.B = B; a.H = Ho; a.W = Wo; a.Hx = H; a.Wx = W; a.Cin = Cin; a.Cout = Cout;
   a.sm = stride; a.S = S;
@@ -306,21 +323,5 @@ int fs_wgrad_f16_general(const float* x, const float* dy, float* dw, int B, int 
   a.x_bytes = (unsigned)((size_t)B * H * W * Cin * 4);
   a.dy_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * 4);
   const int ntile = a.tiles_ci * a.tiles_co;
-  for (int r0 = 0; r0 < stride && r0 < R; ++r0)
-    for (int s0 = 0; s0 < stride && s0 < S; ++s0) {
-      const int nR = (R - r0 + stride - 1) / stride, nS = (S - s0 + stride - 1) / stride;
-      a.cy = r0 - pad; a.cx = s0 - pad; a.rbase = r0; a.rstep = stride; a.sbase = s0; a.sstep = stride;
-      int e = FS_ERR_ARG;
-      if (nR == 3 && nS == 3) e = launch_class<3, 3>(a, ntile, stream);
-      else if (nR == 2 && nS == 2) e = launch_class<2, 2>(a, ntile, stream);
-      else if (nR == 2 && nS == 1) e = launch_class<2, 1>(a, ntile, stream);
-      else if (nR == 1 && nS == 2) e = launch_class<1, 2>(a, ntile, stream);
-      else if (nR == 1 && nS == 1) e = launch_class<1, 1>(a, ntile, stream);
-      if (e != FS_OK) return e;
-    }
-  return FS_OK;
-}
-
-int fs_wgrad_f16(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t stream) {
-  return fs_wgrad_f16_general(x, dy, dw, B, H, W, Cin, H, W, Cout, 3, 3, 1, 1, stream);
+  return mode == 2 ? run_classes<PrecF16>(a, ntile, R, S, stride, pad, stream) : run_classes<PrecX3>(a, ntile, R, S, stride, pad, stream);
 }

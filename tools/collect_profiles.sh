@@ -15,7 +15,7 @@ python3 $R/tools/traffic_summary.py $O/fetch $O/write $O/hbm_traffic_serial.json
 cp $(ls $O/stats/*/*kernel_stats.csv | tail -1) $O/bench_serial_kernel_stats.csv
 rm -rf $O/fetch $O/write $O/stats
 cd $R
-for spec in "fwd 0 halo_f16" "fwd 2 halo_f16" "fwd 4 halo_f16" "wgrad 0 wgrad_class_f16" "wgrad 4 wgrad_class_f16"; do
+for spec in "fwd 0 conv3x3_halo_kernel" "fwd 2 conv3x3_halo_kernel" "fwd 4 conv3x3_halo_kernel" "wgrad 0 conv_wgrad_class_kernel" "wgrad 4 conv_wgrad_class_kernel"; do
   set -- $spec
   bash tools/pmc_conv.sh $1 $2 $3 > $O/sq_$3_$1_shape$2.txt 2>&1
 done
