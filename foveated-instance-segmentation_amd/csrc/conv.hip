@@ -17,7 +17,7 @@
 // inside one filter tap; each wave owns 32 x 64 = two 32x32 accumulators; operands are staged global -> registers -> LDS
 // with the next stage's loads in flight under the MFMAs.
 #include "common.h"
-#include "conv_halo.h"
+#include "conv_kernels.h"
 #include <stdlib.h>
 #include <string.h>
 

@@ -21,7 +21,7 @@
 //     into the pack header); the pack kernel writes the planes already scaled.
 // The final result is acc * 2^(E-14) * 2^(Ew-14), applied in the epilogue.
 #include "conv_split.h"
-#include "conv_halo.h"
+#include "conv_kernels.h"
 
 namespace {
 

@@ -1,5 +1,5 @@
-// Internal interface between conv.hip (C-ABI entry points, kernel selection) and conv_halo.hip
-// (halo-tiled split-precision 3x3 kernel + weight pack).  Not part of include/fovealseg.h.
+// Internal interface between conv.hip (C-ABI entry points, kernel selection) and the split-precision kernel families
+// (conv_halo.hip, conv_tapset.hip, conv_wgrad.hip).  Not part of include/fovealseg.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -11,7 +11,7 @@
 // activation exponent of conv_halo.hip is updated at every LDS refill), as 16-byte
 // global loads straight into MFMA B fragments.  Same tiling as conv_halo.hip (128 x 64 tile, wave tile 64 x 32).
 #include "conv_split.h"
-#include "conv_halo.h"
+#include "conv_kernels.h"
 
 namespace {
 

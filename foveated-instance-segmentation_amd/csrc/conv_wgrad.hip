@@ -1,5 +1,5 @@
 // Weight gradient of a convolution on the 16-bit MFMA pipe in split precision (conv_split.h: f16x2 or bf16x3), one launch
-// per tap class (conv_halo.h FsTapClass; 3x3 stride 1 = one class of 9 taps):
+// per tap class (conv_kernels.h FsTapClass; 3x3 stride 1 = one class of 9 taps):
 //     dW[r][s][ci][co] = sum_{b,y,x} X[b][sm*(y+tr)+cy][sm*(x+ts)+cx][ci] * dY[b][y][x][co],   (r, s) = class tap (tr, ts)
 //
 // GEMM view: M = ci, N = co, K = pixels.  A workgroup owns one 64(ci) x 64(co) tile of ALL taps of the class (NR*NS 32x32
@@ -19,7 +19,7 @@
 // (<= 2^(14-ex): never overflows; a patch far below the running magnitude loses low-order bits only relative to what is already
 // accumulated).  The atomics at the end add acc * 2^(E-28).
 #include "conv_split.h"
-#include "conv_halo.h"
+#include "conv_kernels.h"
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -40,7 +40,7 @@ struct WgArgs {
   const float* dy;   // (B,H,W,Cout)
   float* dw;         // [R][S][Cin][Cout], zero-initialised or accumulated into
   int B, H, W, Hx, Wx, Cin, Cout;
-  // tap class (conv_halo.h FsTapClass): X row of (dY row oy, class tap tr) = sm*(oy + tr) + cy, filter row rbase + rstep*tr
+  // tap class (conv_kernels.h FsTapClass): X row of (dY row oy, class tap tr) = sm*(oy + tr) + cy, filter row rbase + rstep*tr
   int sm, cy, cx, rbase, rstep, sbase, sstep, S;
   int Ph, Pw, tiles_y, tiles_x, npatch, patches_per_split;
   int tiles_ci, tiles_co;
