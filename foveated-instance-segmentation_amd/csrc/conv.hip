@@ -10,7 +10,7 @@
 // Which kernel runs (precision mode g_conv_precision: 0 = f32, 1 = bf16x3, 2 = f16x2):
 //   3x3 stride 1 pad 1, aligned channels, modes 1/2, scratch given : conv_halo.hip (fwd, bwd-data), conv_wgrad.hip (bwd-weight)
 //   other multi-tap filters / strided bwd-data sub-problems, modes 1/2 : conv_tapset.hip; bwd-weight per tap class: conv_wgrad.hip
-//   1x1 and single-tap sub-problems, modes 1/2                     : conv_igemm_x3_kernel   (this file, bf16x3)
+//   1x1 and single-tap sub-problems, modes 1/2                     : conv_igemm_split_kernel<P> (this file)
 //   everything in mode 0                                           : conv_igemm_affine_kernel, conv_wgrad_taps_kernel (fp32 MFMA)
 //   channel counts that are not multiples of 4                     : conv_igemm_kernel, conv_wgrad_kernel (generic)
 // The kernels in this file share one tiling: 256 threads = 4 waves, workgroup tile 128 (pixels) x 64 (channels), K-step 32
@@ -18,6 +18,7 @@
 // with the next stage's loads in flight under the MFMAs.
 #include "common.h"
 #include "conv_kernels.h"
+#include "conv_split.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -483,29 +484,28 @@ __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Split-precision variant of the affine kernel ("bf16x3"): every fp32 operand is split on the fly into
-// three bf16 terms x = x1 + x2 + x3 (exact to 24 bits) while it is written to LDS, and each fp32 product
-// is formed by six bf16 MFMAs (x1y3 + x2y2 + x3y1 + x1y2 + x2y1 + x1y1, fp32 accumulation; the dropped
-// terms are <= 2^-24 relative, i.e. at the fp32 rounding level).  v_mfma_f32_32x32x16_bf16 runs at 16x the
-// fp32-MFMA rate, so six of them cost 3/8 of the eight v_mfma_f32_32x32x2_f32 they replace.
-// Same tiling / addressing / epilogue as conv_igemm_affine_kernel; LDS holds 3 bf16 planes per operand,
-// rows padded to 80 B so the ds_read_b128 fragment reads are conflict-free.
+// Split-precision variant of the affine kernel, templated over the operand split of conv_split.h: every fp32 operand is
+// split on the fly into 16-bit planes while it is written to LDS and each fp32 product is the sum of the plane products that
+// matter (fp32 accumulation):
+//   PrecX3  ("bf16x3"): x = x1 + x2 + x3, six bf16 MFMAs (x1y3 + x2y2 + x3y1 + x1y2 + x2y1 + x1y1; the dropped terms are
+//                       <= 2^-24 relative).  v_mfma_f32_32x32x16_bf16 runs at 16x the fp32-MFMA rate, so six of them cost
+//                       3/8 of the eight v_mfma_f32_32x32x2_f32 they replace.
+//   PrecF16 ("f16x2") : x * 2^s = h1 + h2, three fp16 MFMAs; s comes from the maxima of the LDS stage (source tile and weight
+//                       tile separately), the accumulators carry the running exponent.
+// Same tiling / addressing / epilogue as conv_igemm_affine_kernel; LDS holds NPL planes per operand, rows padded to 80 B
+// so the ds_read_b128 fragment reads are conflict-free.
 // ------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int XLD = 40;   // bf16 per LDS row: 32 k + 8 pad (80 bytes)
+constexpr int XLD = 40;   // 16-bit elements per LDS row: 32 k + 8 pad (80 bytes)
 
-__device__ __forceinline__ void split3(float x, __bf16& a, __bf16& b, __bf16& c) {
-  a = (__bf16)x;
-  const float r = x - (float)a;
-  b = (__bf16)r;
-  c = (__bf16)(r - (float)b);
-}
-
-__global__ __launch_bounds__(256) void conv_igemm_x3_kernel(AffArgs a) {
-  constexpr int TM = 128, NR = 4;
-  __shared__ __attribute__((aligned(16))) __bf16 Ap[3][TM * XLD];
-  __shared__ __attribute__((aligned(16))) __bf16 Bp[3][BN * XLD];
+template <class P>
+__global__ __launch_bounds__(256) void conv_igemm_split_kernel(AffArgs a) {
+  constexpr int TM = 128, NR = 4, NPL = P::NPL;
+  typedef typename P::T T;
+  typedef typename P::x8 X8;
+  typedef typename P::x4 X4;
+  __shared__ __attribute__((aligned(16))) T Ap[NPL][TM * XLD];
+  __shared__ __attribute__((aligned(16))) T Bp[NPL][BN * XLD];
+  __shared__ unsigned amax_cell[2][2];      // [stage parity][source, weights]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long M = (long)a.B * a.Hq * a.Wq;
@@ -582,24 +582,32 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(AffArgs a) {
       }
     }
   };
-  auto store_stage = [&]() {
+  auto store_stage = [&](float sa, float sb) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      bf16x4 p0, p1, p2;
+      X4 p[NPL];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { __bf16 x, y, z; split3(ra[i][e], x, y, z); p0[e] = x; p1[e] = y; p2[e] = z; }
+      for (int e = 0; e < 4; ++e) {
+        T t[NPL];
+        P::split(P::SCALED ? ra[i][e] * sa : ra[i][e], t);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) p[pl][e] = t[pl];
+      }
       const int o = (arow + 32 * i) * XLD + 4 * q;
-      *reinterpret_cast<bf16x4*>(&Ap[0][o]) = p0;
-      *reinterpret_cast<bf16x4*>(&Ap[1][o]) = p1;
-      *reinterpret_cast<bf16x4*>(&Ap[2][o]) = p2;
-    }
-    bf16x8 w0, w1, w2;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { __bf16 x, y, z; split3(rb[j], x, y, z); w0[j] = x; w1[j] = y; w2[j] = z; }
+      for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Ap[pl][o]) = p[pl];
+    }
+    X8 w[NPL];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      T t[NPL];
+      P::split(P::SCALED ? rb[j] * sb : rb[j], t);
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) w[pl][j] = t[pl];
+    }
     const int o = bn * XLD + bk0;
-    *reinterpret_cast<bf16x8*>(&Bp[0][o]) = w0;
-    *reinterpret_cast<bf16x8*>(&Bp[1][o]) = w1;
-    *reinterpret_cast<bf16x8*>(&Bp[2][o]) = w2;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X8*>(&Bp[pl][o]) = w[pl];
   };
 
   f32x16 acc0 = {0}, acc1 = {0};
@@ -607,41 +615,68 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(AffArgs a) {
   const int aidx = (wave * 32 + l31) * XLD + 8 * lh;     // + 16*s
   const int bidx = l31 * XLD + 8 * lh;                   // + 32*t*XLD + 16*s
 
+  // Scaled planes (f16x2): every stage's operands are scaled by powers of two taken from the stage's own maxima (ea, eb) and
+  // the accumulators carry the running exponent E >= ea + eb -- the scheme of conv_wgrad.hip, per stage instead of per patch.
+  int E = 2 * fs_split::EMIN - 1, par = 0;
+  if (P::SCALED) {
+    if (tid < 4) amax_cell[tid >> 1][tid & 1] = 0u;
+    __syncthreads();
+  }
   if (nstage > 0) load_stage(0);
   for (int st = 0; st < nstage; ++st) {
+    float sa = 1.f, sb = 1.f;
+    if (P::SCALED) {
+      float ma = 0.f, mb = 0.f;
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ma = fmaxf(ma, fabsf(ra[i][e]));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mb = fmaxf(mb, fabsf(rb[j]));
+      ma = wave_max(ma); mb = wave_max(mb);
+      if (lane == 0) { atomicMax(&amax_cell[par][0], __builtin_bit_cast(unsigned, ma)); atomicMax(&amax_cell[par][1], __builtin_bit_cast(unsigned, mb)); }
+    }
     __syncthreads();
-    store_stage();
+    if (P::SCALED) {
+      const int ea = __builtin_amdgcn_readfirstlane(fs_split::exponent_of_bits(amax_cell[par][0]));
+      const int eb = __builtin_amdgcn_readfirstlane(fs_split::exponent_of_bits(amax_cell[par][1]));
+      if (ea + eb > E) {
+        const float f = fs_split::pow2f(E - ea - eb);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] *= f; acc1[r] *= f; }
+        E = ea + eb;
+      }
+      sa = fs_split::pow2f(14 - (E - eb)); sb = fs_split::pow2f(14 - eb);
+      par ^= 1;
+      if (tid < 2) amax_cell[par][tid] = 0u;
+    }
+    store_stage(sa, sb);
     __syncthreads();
     if (st + 1 < nstage) load_stage(st + 1);
-    bf16x8 fa[2][3], fb[2][2][3];
+    X8 fa[2][NPL], fb[2][2][NPL];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int p3 = 0; p3 < 3; ++p3) {
-        fa[s2][p3] = *reinterpret_cast<const bf16x8*>(&Ap[p3][aidx + 16 * s2]);
-        fb[s2][0][p3] = *reinterpret_cast<const bf16x8*>(&Bp[p3][bidx + 16 * s2]);
-        fb[s2][1][p3] = *reinterpret_cast<const bf16x8*>(&Bp[p3][bidx + 32 * XLD + 16 * s2]);
+      for (int p3 = 0; p3 < NPL; ++p3) {
+        fa[s2][p3] = *reinterpret_cast<const X8*>(&Ap[p3][aidx + 16 * s2]);
+        fb[s2][0][p3] = *reinterpret_cast<const X8*>(&Bp[p3][bidx + 16 * s2]);
+        fb[s2][1][p3] = *reinterpret_cast<const X8*>(&Bp[p3][bidx + 32 * XLD + 16 * s2]);
       }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       // smallest cross terms first
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0], fb[s2][0][2], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0], fb[s2][1][2], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][1], fb[s2][0][1], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][1], fb[s2][1][1], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][2], fb[s2][0][0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][2], fb[s2][1][0], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0], fb[s2][0][1], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0], fb[s2][1][1], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][1], fb[s2][0][0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][1], fb[s2][1][0], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0], fb[s2][0][0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][0], fb[s2][1][0], acc1, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < P::NTERM; ++t) {
+        acc0 = P::mfma(fa[s2][P::ta(t)], fb[s2][0][P::tb(t)], acc0);
+        acc1 = P::mfma(fa[s2][P::ta(t)], fb[s2][1][P::tb(t)], acc1);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  const int Eo = E - 28;                                   // two factors: the combined exponent can leave the float range
+  const float fo1 = P::SCALED ? fs_split::pow2f(Eo / 2) : 1.f, fo2 = P::SCALED ? fs_split::pow2f(Eo - Eo / 2) : 1.f;
   float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -652,7 +687,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x3_kernel(AffArgs a) {
     for (int r = 0; r < 16; ++r) {
       const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m >= M) continue;
-      float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
+      float v = (P::SCALED ? (t == 0 ? acc0[r] : acc1[r]) * fo1 * fo2 : (t == 0 ? acc0[r] : acc1[r])) + bv;
       long e = m * a.Cd + n;
       if (a.os > 1) {
         const int b = (int)(m / ((long)a.Hq * a.Wq));
@@ -911,8 +946,10 @@ int launch_affine_one(AffArgs& a) {
   a.nx = cdiv(M, 128);
   a.ny = cdiv(a.Cd, BN);
   // MT=2 (256-row tiles) needs 84 KB of LDS = one workgroup per CU and measured 20-25 % slower.
-  if (g_conv_precision >= 1)
-    hipLaunchKernelGGL(conv_igemm_x3_kernel, dim3(a.nx * a.ny), dim3(256), 0, a_stream, a);
+  if (g_conv_precision == 2)
+    hipLaunchKernelGGL(conv_igemm_split_kernel<fs_split::PrecF16>, dim3(a.nx * a.ny), dim3(256), 0, a_stream, a);
+  else if (g_conv_precision == 1)
+    hipLaunchKernelGGL(conv_igemm_split_kernel<fs_split::PrecX3>, dim3(a.nx * a.ny), dim3(256), 0, a_stream, a);
   else
     hipLaunchKernelGGL(conv_igemm_affine_kernel<1>, dim3(a.nx * a.ny), dim3(256), 0, a_stream, a);
   FS_LAUNCH_CHECK();
@@ -933,7 +970,7 @@ static const bool g_tapset_1x1 = [] { const char* e = getenv("FS_TAPSET_1X1"); r
 static const bool g_tapset_all = [] { const char* e = getenv("FS_TAPSET_ALL"); return e && e[0] == '1'; }();
 bool tapset_shape_ok(int Cs, int Cd, int R, int S, int stride, int dil) {
   const int cr = stride < R ? stride : R, cs = stride < S ? stride : S;
-  // 1x1 filters have no tap reuse: measured slower than conv_igemm_x3_kernel (43 vs 55 TF on 64->256 @ 80x80), not routed here
+  // 1x1 filters have no tap reuse: measured slower than conv_igemm_split_kernel (43 vs 55 TF on 64->256 @ 80x80), not routed here
   return dil == 1 && (R * S > 1 || g_tapset_1x1) && Cs % 4 == 0 && Cd % 4 == 0 && Cs >= 16 && cr * cs <= 9 &&
          ((R + stride - 1) / stride) * ((S + stride - 1) / stride) <= 64;
 }

@@ -5,7 +5,7 @@
 // (scaled,) split and written to LDS ONCE and all 9 taps read it at shifted slot offsets (18 k16-steps between barriers).
 // The weights are split ahead of time by a pack kernel into the exact order the MFMA B fragments are consumed, so B fragments
 // are 16-byte global loads straight into registers (contiguous 1 KB per wave load) and never touch LDS or the VALU.  The plain
-// kernel (conv_igemm_x3_kernel) re-loaded and re-split its A tile for every tap: 285 VALU instructions per 24 MFMAs.
+// kernel (conv_igemm_split_kernel) re-loaded and re-split its A tile for every tap: 285 VALU instructions per 24 MFMAs.
 //
 //   workgroup = 256 threads = 4 waves as 2 (pixel halves) x 2 (channel halves); wave tile 64 x 32*NW
 //   LDS: NPL planes x 224 halo slots x 80 B (32 k + 16 B pad -> conflict-free ds_read_b128)

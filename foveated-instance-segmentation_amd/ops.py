@@ -64,8 +64,9 @@ def _out_hw(h, w, r, s, stride, pad, dil=1):
 
 
 class KernelTimer:
-    """Optional HIP-event timing of individual conv launches on the current stream (bench.py only).
-    `flops` are algorithmic: 2 * B*Ho*Wo * Cout * R*S*Cin for every variant."""
+    """Optional HIP-event timing of individual launches on the current stream (bench.py only).
+    `flops` is the algorithmic work of the launch: 2 * B*Ho*Wo * Cout * R*S*Cin for every conv variant, bytes for the
+    HBM-bound kinds (bn_fwd, bn_bwd)."""
 
     def __init__(self):
         self.records = {}          # kind -> list of (start_event, stop_event, flops)
@@ -254,8 +255,10 @@ class ConvBnAct(Function):
         z = torch.empty_like(y)
         # activation-derivative bits for the backward passes (1 byte per 4 channels instead of re-reading z)
         amask = torch.empty(M * C // 4, device=y.device, dtype=torch.uint8) if (meta["act"] != 0 and any(ctx.needs_input_grad)) else None
-        hip.call("fs_bn_act_fwd", hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(beta), hip.ptr(res),
-                 hip.ptr(z), hip.ptr(amask), M, C, meta["act"])
+        # timer "work" of the HBM-bound kinds = algorithmic bytes: every operand read once, every result written once
+        _launch("bn_fwd", 4.0 * M * C * (2 + (res is not None)) + (M * C // 4 if amask is not None else 0),
+                "fs_bn_act_fwd", hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(beta), hip.ptr(res),
+                hip.ptr(z), hip.ptr(amask), M, C, meta["act"])
         ctx.meta = dict(stride=meta["stride"], pad=meta["pad"], dil=dil, act=meta["act"], training=training, drop_p=drop_p,
                         drop_key=meta["drop_key"], has_bias=bias is not None, has_res=res is not None)
         ctx.save_for_backward(x, w, gamma, y, z if amask is None else None, mean, invstd, amask)
@@ -277,9 +280,10 @@ class ConvBnAct(Function):
         dgamma = tg if direct_affine else torch.empty(C, device=y.device, dtype=torch.float32)
         dbeta = tb if direct_affine else torch.empty(C, device=y.device, dtype=torch.float32)
         sums = torch.empty(2 * C, device=y.device, dtype=torch.float64)
-        hip.call("fs_bn_act_bwd", hip.ptr(dz), hip.ptr(z), hip.ptr(amask), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), M, C,
-                 m["act"], 1 if m["training"] else 0, float(m["drop_p"]), int(m["drop_key"]), hip.ptr(dy), hip.ptr(dres),
-                 hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums))
+        _launch("bn_bwd", 4.0 * M * C * (3 + m["has_res"]) + (M * C // 4 if amask is not None else 0),
+                "fs_bn_act_bwd", hip.ptr(dz), hip.ptr(z), hip.ptr(amask), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), M, C,
+                m["act"], 1 if m["training"] else 0, float(m["drop_p"]), int(m["drop_key"]), hip.ptr(dy), hip.ptr(dres),
+                hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums))
         dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax) if ctx.needs_input_grad[0] else None
         tgt = _direct_grad_target(w)
         dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"], accumulate=tgt is not None)
