@@ -153,7 +153,30 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; is[j] = invstd[c + j]; }
     const long rb = (long)blockIdx.x * rows_per_block;
     long re = rb + rows_per_block; if (re > M) re = M;
-    for (long r = rb + w.r0; r < re; r += w.rpi) {
+    long r = rb + w.r0;
+    if (act == FS_ACT_NONE || mask != nullptr) {
+      // four rows per trip: all loads of a trip are issued before the first use (a single row per trip keeps only
+      // 32 KB per CU in flight, about half of what the HBM latency needs)
+      const long step = w.rpi;
+      for (; r + 3 * step < re; r += 4 * step) {
+        f32x4 g[4], yy[4];
+        unsigned m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long o = (r + u * step) * ld + c;
+          g[u] = *reinterpret_cast<const f32x4*>(dz + o);
+          yy[u] = *reinterpret_cast<const f32x4*>(y + o);
+          m[u] = act != FS_ACT_NONE ? (unsigned)mask[o >> 2] : 0xFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[u][j] = ((m[u] >> j) & 1u) ? g[u][j] : 0.f;
+          s += g[u]; sx += g[u] * ((yy[u] - mu) * is);
+        }
+      }
+    }
+    for (; r < re; r += w.rpi) {
       f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * ld + c);
       if (act != FS_ACT_NONE) {
         if (mask != nullptr) {

@@ -510,20 +510,53 @@ __global__ void inverse_grid_kernel(const int* __restrict__ owner, float* __rest
 }
 // Nearest-valid fill (models.py:159-286 with rev_deform_interp='nearest'): exact Euclidean nearest claimed pixel, ties to
 // the smallest (row, col).  Pass A: nearest claimed column in the same row; pass B: minimise (y-y')^2 + (x-x'(y'))^2 over rows.
-__global__ void fill_row_nearest_kernel(const int* __restrict__ owner, int* __restrict__ rowx, int Ws) {
+__global__ __launch_bounds__(256) void fill_row_nearest_kernel(const int* __restrict__ owner, int* __restrict__ rowx, int Ws) {
+  extern __shared__ int rowbuf[];                      // [Ws]: claimed flag, then nearest claimed column
+  __shared__ int carryL[256], carryR[256];
+  const int tid = threadIdx.x;
   const long row = blockIdx.x;
   const int* o = owner + row * Ws;
   int* r = rowx + row * Ws;
-  for (int x = threadIdx.x; x < Ws; x += blockDim.x) {
-    int best = -1;
-    for (int d = 0; d < Ws; ++d) {
-      const int xl = x - d, xr = x + d;
-      if (xl >= 0 && o[xl] >= 0) { best = xl; break; }
-      if (xr < Ws && o[xr] >= 0) { best = xr; break; }
-      if (xl < 0 && xr >= Ws) break;
-    }
-    r[x] = best;
+  int any = 0;
+  for (int x = tid; x < Ws; x += 256) { const int c = o[x] >= 0; rowbuf[x] = c; any |= c; }
+  // most rows of a strongly magnified image hold no claimed pixel at all
+  if (!__syncthreads_or(any)) {
+    for (int x = tid; x < Ws; x += 256) r[x] = -1;
+    return;
   }
+  // thread t owns the columns [x0, x1): last / first claimed column of the segment, then a scan over the 256 segments
+  const int seg = (Ws + 255) / 256;
+  const int x0 = tid * seg < Ws ? tid * seg : Ws, x1 = x0 + seg < Ws ? x0 + seg : Ws;
+  int last = -1, first = 0x7fffffff;
+  for (int x = x0; x < x1; ++x)
+    if (rowbuf[x]) { last = x; if (first == 0x7fffffff) first = x; }
+  carryL[tid] = last; carryR[tid] = first;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    int l = carryL[tid], rr = carryR[tid];
+    if (tid >= off) { const int v = carryL[tid - off]; l = v > l ? v : l; }
+    if (tid + off < 256) { const int v = carryR[tid + off]; rr = v < rr ? v : rr; }
+    __syncthreads();
+    carryL[tid] = l; carryR[tid] = rr;
+    __syncthreads();
+  }
+  int left = tid > 0 ? carryL[tid - 1] : -1;
+  int right = tid < 255 ? carryR[tid + 1] : 0x7fffffff;
+  for (int x = x0; x < x1; ++x) {                      // nearest claimed column at or left of x
+    if (rowbuf[x]) left = x;
+    rowbuf[x] = left;
+  }
+  for (int x = x1 - 1; x >= x0; --x) {                 // ... against the nearest at or right of x; a tie goes to the left one
+    const int l = rowbuf[x];
+    if (l == x) right = x;
+    int best;
+    if (l < 0) best = right == 0x7fffffff ? -1 : right;
+    else if (right == 0x7fffffff) best = l;
+    else best = (x - l) <= (right - x) ? l : right;
+    rowbuf[x] = best;
+  }
+  __syncthreads();
+  for (int x = tid; x < Ws; x += 256) r[x] = rowbuf[x];
 }
 __global__ void fill_col_nearest_kernel(const int* __restrict__ rowx, int* __restrict__ src, long n, int Hs, int Ws) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -550,15 +583,21 @@ __global__ void fill_col_nearest_kernel(const int* __restrict__ rowx, int* __res
   src[i] = bsrc;
 }
 __global__ void fill_copy_kernel(float* __restrict__ vals, const int* __restrict__ owner, const int* __restrict__ src, int C, long per,
-                                 long total) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;       // over (b, c, pixel)
-  if (i >= total) return;
-  const long pix = i % per;
-  const long bc = i / per;
-  const long b = bc / C;
-  if (owner[b * per + pix] >= 0) return;               // claimed pixels keep their sampled value
-  const int sp = src[b * per + pix];
-  if (sp >= 0) vals[bc * per + pix] = vals[bc * per + sp];
+                                 long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;       // over (b, pixel): the source index is looked up once for all classes
+  if (i >= n) return;
+  if (owner[i] >= 0) return;                           // claimed pixels keep their sampled value
+  const int sp = src[i];
+  if (sp < 0) return;                                  // image without any claimed pixel
+  const long b = i / per;
+  const long pix = i - b * per;
+  float* v = vals + b * C * per;
+  int c = 0;
+  for (; c + 4 <= C; c += 4) {                          // four independent gathers in flight per trip
+    const float a0 = v[(c + 0) * per + sp], a1 = v[(c + 1) * per + sp], a2 = v[(c + 2) * per + sp], a3 = v[(c + 3) * per + sp];
+    v[(c + 0) * per + pix] = a0; v[(c + 1) * per + pix] = a1; v[(c + 2) * per + pix] = a2; v[(c + 3) * per + pix] = a3;
+  }
+  for (; c < C; ++c) v[c * per + pix] = v[c * per + sp];
 }
 
 }  // namespace
@@ -716,12 +755,12 @@ int fs_fill_nearest(float* vals, const int* owner, int* scratch, int B, int C, i
   const long per = (long)Hs * Ws, n = (long)B * per;
   int* rowx = scratch;          // [B*Hs*Ws]
   int* src = scratch + n;       // [B*Hs*Ws]
-  hipLaunchKernelGGL(fill_row_nearest_kernel, dim3((unsigned)((long)B * Hs)), dim3(256), 0, stream, owner, rowx, Ws);
+  FS_REQUIRE(Ws <= 16384);     // one row of column indices in LDS
+  hipLaunchKernelGGL(fill_row_nearest_kernel, dim3((unsigned)((long)B * Hs)), dim3(256), (size_t)Ws * sizeof(int), stream, owner, rowx, Ws);
   FS_LAUNCH_CHECK();
   hipLaunchKernelGGL(fill_col_nearest_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, rowx, src, n, Hs, Ws);
   FS_LAUNCH_CHECK();
-  const long total = n * C;
-  hipLaunchKernelGGL(fill_copy_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, vals, owner, src, C, per, total);
+  hipLaunchKernelGGL(fill_copy_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, vals, owner, src, C, per, n);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

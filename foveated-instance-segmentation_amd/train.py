@@ -284,13 +284,17 @@ class DeviceMeter:
     def __init__(self, names, device):
         self.names = list(names)
         self.acc = torch.zeros(len(self.names) + 1, device=device, dtype=torch.float64)
+        self._sums, self._count = self.acc[:-1], self.acc[-1:]       # views, made once
 
     def update(self, values, weight=1.0):
         dev = self.acc.device
-        v = torch.stack([(x.detach().to(device=dev, dtype=torch.float64) if torch.is_tensor(x) else torch.tensor(float(x), dtype=torch.float64, device=dev)).reshape(())
-                         for x in values])
-        self.acc[:-1] += v * weight
-        self.acc[-1] += weight
+        if all(torch.is_tensor(x) and x.device == dev and x.dim() == 0 for x in values):
+            v = torch.stack([x.detach() for x in values])          # the step's outputs: one stack + two in-place adds per step
+        else:
+            v = torch.stack([(x.detach().to(device=dev, dtype=torch.float64) if torch.is_tensor(x) else torch.tensor(float(x), dtype=torch.float64, device=dev)).reshape(())
+                             for x in values])
+        self._sums.add_(v, alpha=weight)
+        self._count.add_(weight)
 
     def averages(self, reduce=True):
         tot = self.acc.clone()

@@ -268,3 +268,17 @@ def test_fill_nearest_properties_full_size():
     assert torch.equal(out, out2)                                               # idempotent
     vals = set(out[0, 0][~hole[0]].cpu().tolist())
     assert set(out[0, 0].unique().cpu().tolist()) <= vals                       # holes only ever take claimed values
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Hs,Ws,C", [(37, 300, 6), (50, 513, 3), (8, 1500, 1)])
+def test_unwarp_nearest_ragged_widths(Hs, Ws, C):
+    # widths that are no multiple of the row kernel's 256 segments, class counts around its 4-way unrolled copy
+    g = torch.Generator().manual_seed(Hs * 1000 + Ws)
+    grid = torch.rand(2, 9, 11, 2, generator=g) * 2.2 - 1.1
+    grid = grid.clamp(-1, 1)
+    pred = torch.randn(2, C, 9, 11, generator=g)
+    out, hole = fovealseg.ops.unwarp_nearest(pred.cuda(), grid.cuda(), Hs, Ws)
+    want, whole = O.unwarp_nearest_ref(pred, grid, Hs, Ws)
+    assert torch.equal(hole.cpu(), whole)
+    assert torch.equal(out.cpu(), want)
