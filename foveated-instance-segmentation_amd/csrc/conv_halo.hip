@@ -358,8 +358,18 @@ __global__ __launch_bounds__(256) void weight_amax_segments_kernel(const float* 
   const int p = blockIdx.x;
   const float* w = arena + offsets[p];
   const long n = sizes[p];
+  const long n4 = (((size_t)w & 15) == 0) ? n / 4 : 0;  // 16-byte loads, two in flight per trip
+  if ((long)blockIdx.y * (n4 ? 1024 : 256) >= n) return;   // small parameters need one block (block 0 also takes the tail)
   float m = 0.f;
-  for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < n; i += (long)gridDim.y * 256) m = fmaxf(m, fabsf(w[i]));
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
+  const long stride = (long)gridDim.y * 256;
+  for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < n4; i += 2 * stride) {
+    const long i2 = i + stride < n4 ? i + stride : i;
+    const f32x4 a = w4[i], b = w4[i2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(a[e]), fabsf(b[e])));
+  }
+  for (long i = 4 * n4 + (long)blockIdx.y * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(w[i]));
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&out[p], __builtin_bit_cast(unsigned, m));
 }
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(256) void weight_amax_segments_kernel(const float* 
 int fs_weight_amax_segments_impl(const float* arena, const long* offsets, const long* sizes, int nparams, unsigned* out, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned) * (size_t)nparams, stream);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(weight_amax_segments_kernel, dim3(nparams, 8), dim3(256), 0, stream, arena, offsets, sizes, out);
+  hipLaunchKernelGGL(weight_amax_segments_kernel, dim3(nparams, 32), dim3(256), 0, stream, arena, offsets, sizes, out);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -156,7 +156,20 @@ __global__ __launch_bounds__(1024) void edge_loss_fwd_kernel(const float* __rest
   __shared__ float red[4][16];
   __shared__ double dred[16];
   float mn = INFINITY, mx = -INFINITY, tmn = INFINITY, tmx = -INFINITY;
-  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+  // one workgroup walks the whole batch twice: 16-byte loads, two of each operand in flight per trip
+  const long n4 = ((((size_t)xs | (size_t)t) & 15) == 0) ? n / 4 : 0;
+  const f32x4* xs4 = reinterpret_cast<const f32x4*>(xs);
+  const f32x4* t4 = reinterpret_cast<const f32x4*>(t);
+  for (long i = threadIdx.x; i < n4; i += 2 * blockDim.x) {
+    const long i2 = i + blockDim.x < n4 ? i + blockDim.x : i;
+    const f32x4 a0 = xs4[i], b0 = t4[i], a1 = xs4[i2], b1 = t4[i2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mn = fminf(mn, fminf(a0[e], a1[e])); mx = fmaxf(mx, fmaxf(a0[e], a1[e]));
+      tmn = fminf(tmn, fminf(b0[e], b1[e])); tmx = fmaxf(tmx, fmaxf(b0[e], b1[e]));
+    }
+  }
+  for (long i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
     const float a = xs[i], b = t[i];
     mn = fminf(mn, a); mx = fmaxf(mx, a); tmn = fminf(tmn, b); tmx = fmaxf(tmx, b);
   }
@@ -170,7 +183,18 @@ __global__ __launch_bounds__(1024) void edge_loss_fwd_kernel(const float* __rest
   }
   const float r = mx - mn, tr = tmx - tmn;
   double acc = 0.0, cmin = 0.0, cmax = 0.0;
-  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+  for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+    const f32x4 a4 = xs4[i], b4 = t4[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float u = (a4[e] - mn) / r, v = (b4[e] - tmn) / tr;
+      const float d = u - v;
+      acc += (double)(d * d);
+      cmin += (a4[e] == mn) ? 1.0 : 0.0;
+      cmax += (a4[e] == mx) ? 1.0 : 0.0;
+    }
+  }
+  for (long i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
     const float a = xs[i];
     const float u = (a - mn) / r, v = (t[i] - tmn) / tr;
     const float d = u - v;
@@ -195,7 +219,20 @@ __global__ __launch_bounds__(1024) void edge_loss_bwd_kernel(const float* __rest
   const float r = mx - mn, tr = tmx - tmn;
   const float k = 2.f * coef * gout[0] / (float)n;
   double s_gu1 = 0.0, s_gu = 0.0;    // sum g*(u-1), sum g*u
-  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+  const long n4 = ((((size_t)xs | (size_t)t | (size_t)dxs) & 15) == 0) ? n / 4 : 0;
+  const f32x4* xs4 = reinterpret_cast<const f32x4*>(xs);
+  const f32x4* t4 = reinterpret_cast<const f32x4*>(t);
+  for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+    const f32x4 a4 = xs4[i], b4 = t4[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float u = (a4[e] - mn) / r, v = (b4[e] - tmn) / tr;
+      const float g = k * (u - v);
+      s_gu1 += (double)(g * (u - 1.f));
+      s_gu += (double)(g * u);
+    }
+  }
+  for (long i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
     const float u = (xs[i] - mn) / r, v = (t[i] - tmn) / tr;
     const float g = k * (u - v);
     s_gu1 += (double)(g * (u - 1.f));
@@ -205,7 +242,20 @@ __global__ __launch_bounds__(1024) void edge_loss_bwd_kernel(const float* __rest
   s_gu = block_sum<double>(s_gu, dred);
   const float dmn = (float)(s_gu1 / (double)r) / stats[4];
   const float dmx = (float)(-s_gu / (double)r) / stats[5];
-  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+  for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+    const f32x4 a4 = xs4[i], b4 = t4[i];
+    f32x4 d4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float u = (a4[e] - mn) / r, v = (b4[e] - tmn) / tr;
+      float d = k * (u - v) / r;
+      if (a4[e] == mn) d += dmn;
+      if (a4[e] == mx) d += dmx;
+      d4[e] = d;
+    }
+    reinterpret_cast<f32x4*>(dxs)[i] = d4;
+  }
+  for (long i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
     const float a = xs[i];
     const float u = (a - mn) / r, v = (t[i] - tmn) / tr;
     float d = k * (u - v) / r;
@@ -290,6 +340,8 @@ __global__ __launch_bounds__(1024) void gauss_grid_bwd_kernel(const float* __res
   extern __shared__ float sm[];
   float* A = sm; float* Bf = sm + GMAX; float* Cf = sm + 2 * GMAX; float* D = sm + 3 * GMAX; float* E = sm + 4 * GMAX;
   __shared__ double g[256];
+  constexpr int BT = 128;                              // largest grid side the border tables cover
+  __shared__ double gx_lo[2 * BT], gx_hi[2 * BT], gy_lo[2 * BT], gy_hi[2 * BT];
   const int b = blockIdx.x, n = hs * ws, K = 2 * pad + 1;
   for (int i = threadIdx.x; i < K; i += blockDim.x) g[i] = g1d[i];
   for (int i = threadIdx.x; i < n; i += blockDim.x) A[i] = xs_g[(long)b * n + i];
@@ -309,12 +361,47 @@ __global__ __launch_bounds__(1024) void gauss_grid_bwd_kernel(const float* __res
     const double dp = -(dax * ax + day * ay) / p;
     A[i] = (float)dp; D[i] = (float)dax; E[i] = (float)day;   // A (xs) is dead after the row pass
   }
+  // The two border columns (rows) collect the pad+1 padded positions that replicate them.  Summed tap by tap that is
+  // (pad+1) x K products for 2/ws of the pixels -- the threads that own them run ~pad times longer than the rest -- so the
+  // sums over the padded positions are folded into per-source weights first:
+  //   T0[o] = sum_j g[j-o],  T1[o] = sum_j c(j) g[j-o]   over the border's j range (left/top: [0,pad], right/bottom: [n-1+pad, n+2pad-1])
+  const double invx = 1.0 / (double)(ws - 1), invy = 1.0 / (double)(hs - 1);
+  const bool tables = hs <= BT && ws <= BT;
+  if (tables) {
+    for (int q = threadIdx.x; q < 2 * (ws + hs); q += blockDim.x) {
+      const bool isx = q < 2 * ws;
+      const int qq = isx ? q : q - 2 * ws;
+      const int len = isx ? ws : hs;
+      const bool hi = qq >= len;
+      const int o = hi ? qq - len : qq;
+      const double inv = isx ? invx : invy;
+      const int j_lo = hi ? len - 1 + pad : 0, j_hi = hi ? len + 2 * pad - 1 : pad;
+      double t0 = 0.0, t1 = 0.0;
+      for (int j = j_lo; j <= j_hi; ++j) {
+        const int k = j - o;
+        if (k < 0 || k >= K) continue;
+        t0 += g[k];
+        t1 += (double)(j - pad) * inv * g[k];
+      }
+      double* T = isx ? (hi ? gx_hi : gx_lo) : (hi ? gy_hi : gy_lo);
+      T[2 * o] = t0; T[2 * o + 1] = t1;
+    }
+  }
   __syncthreads();
   // row pass (transposed, folded): for every source row oy and folded column x:
   //   Va[oy][x] = sum_{j -> x} sum_ox g[j-ox] (D0 + cx(j) D1)[oy][ox],   Vb[oy][x] = sum_{j->x} sum_ox g[j-ox] D2[oy][ox]
-  const double invx = 1.0 / (double)(ws - 1), invy = 1.0 / (double)(hs - 1);
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int oy = i / ws, x = i - oy * ws;
+    if (tables && (x == 0 || x == ws - 1)) {
+      const double* T = x == 0 ? gx_lo : gx_hi;
+      double va = 0.0, vb = 0.0;
+      for (int ox = 0; ox < ws; ++ox) {
+        va += T[2 * ox] * (double)A[oy * ws + ox] + T[2 * ox + 1] * (double)D[oy * ws + ox];
+        vb += T[2 * ox] * (double)E[oy * ws + ox];
+      }
+      Bf[i] = (float)va; Cf[i] = (float)vb;
+      continue;
+    }
     const int j_lo = (x == 0) ? 0 : x + pad, j_hi = (x == ws - 1) ? ws + 2 * pad - 1 : x + pad;
     double va = 0.0, vb = 0.0;
     for (int j = j_lo; j <= j_hi; ++j) {
@@ -337,6 +424,13 @@ __global__ __launch_bounds__(1024) void gauss_grid_bwd_kernel(const float* __res
   // column pass (transposed, folded): dxs[y][x] = sum_{i -> y} sum_oy g[i-oy] (Va + cy(i) Vb)[oy][x]
   for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
     const int y = idx / ws, x = idx - y * ws;
+    if (tables && (y == 0 || y == hs - 1)) {
+      const double* T = y == 0 ? gy_lo : gy_hi;
+      double acc = 0.0;
+      for (int oy = 0; oy < hs; ++oy) acc += T[2 * oy] * (double)Bf[oy * ws + x] + T[2 * oy + 1] * (double)Cf[oy * ws + x];
+      dxs[(long)b * n + idx] = (float)acc;
+      continue;
+    }
     const int i_lo = (y == 0) ? 0 : y + pad, i_hi = (y == hs - 1) ? hs + 2 * pad - 1 : y + pad;
     double acc = 0.0;
     for (int i = i_lo; i <= i_hi; ++i) {

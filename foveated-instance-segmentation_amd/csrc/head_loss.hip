@@ -124,18 +124,26 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
   const int bg = K - 1;
   double focal = 0.0;
   float cnt[6] = {0, 0, 0, 0, 0, 0};
-  for (int p = chunk * blockDim.x + threadIdx.x; p < HW; p += blocks_per_img * blockDim.x) {
-    const int t = (int)gt[(long)b * HW + p];
+  // every lane of a wave makes the same number of trips (inactive pixels contribute zeros): the per-class probability sums
+  // are reduced across the wave in registers, so LDS sees one atomic per wave and class instead of one per lane
+  const int lane = threadIdx.x & 63;
+  for (int p0 = chunk * blockDim.x; p0 < HW; p0 += blocks_per_img * blockDim.x) {
+    const int p = p0 + threadIdx.x;
+    const bool live = p < HW;
+    const int pc = live ? p : HW - 1;
+    const int t = (int)gt[(long)b * HW + pc];
     float mx = -INFINITY; int am = 0;
-    for (int k = 0; k < K; ++k) { const float v = pb[(long)k * HW + p]; if (v > mx) { mx = v; am = k; } }
+    for (int k = 0; k < K; ++k) { const float v = pb[(long)k * HW + pc]; if (v > mx) { mx = v; am = k; } }
     float se = 0.f;
-    for (int k = 0; k < K; ++k) se += expf(pb[(long)k * HW + p] - mx);
+    for (int k = 0; k < K; ++k) se += expf(pb[(long)k * HW + pc] - mx);
     const float lse = logf(se);
     for (int k = 0; k < K; ++k) {
-      const float pk = expf(pb[(long)k * HW + p] - mx - lse);
-      atomicAdd(&sp[k], pk);
-      if (k == t) { atomicAdd(&si[k], pk); atomicAdd(&sc[k], 1.f); }
+      const float pk = live ? expf(pb[(long)k * HW + pc] - mx - lse) : 0.f;
+      const float ws = wave_sum(pk);
+      if (lane == 0) atomicAdd(&sp[k], ws);
+      if (live && k == t) { atomicAdd(&si[k], pk); atomicAdd(&sc[k], 1.f); }
     }
+    if (!live) continue;
     const float logpt = pb[(long)t * HW + p] - mx - lse;
     const float pt = expf(logpt);
     focal += (double)(-powf(1.f - pt, gamma) * logpt);

@@ -433,6 +433,84 @@ def test_seg_loss_g10(golden):
     assert np.abs(pred.grad.cpu().numpy() - g["dpred"]).max() <= 1e-6 * max(1.0, np.abs(g["dpred"]).max())
 
 
+@pytest.mark.parametrize("B,K,H,W", [(2, 51, 37, 41), (3, 7, 5, 9)])
+def test_seg_loss_ragged_sizes(B, K, H, W):
+    # pixel counts that are no multiple of the 64-lane waves / 256-thread blocks (partly idle waves in the class sums)
+    gen = torch.Generator().manual_seed(K * H)
+    pred = torch.randn(B, K, H, W, generator=gen) * 2
+    gt = torch.randint(0, K, (B, H, W), generator=gen)
+    gt[0, : H // 2] = K - 1
+    pd = pred.to(DEV).requires_grad_(True)
+    out = ops.SegLoss.apply(pd, gt.to(DEV), 5.0)
+    out[0].backward()
+    pr = pred.clone().requires_grad_(True)
+    fl, dl = O.focal_loss(pr, gt, 5.0), O.dice_loss_multiclass(pr, gt)
+    (fl + dl).backward()
+    o = out.detach().cpu().numpy()
+    assert abs(o[1] - float(fl)) <= 2e-6 and abs(o[2] - float(dl)) <= 2e-6
+    accs = [float(a) for a in O.accuracies(pred, gt, bg=K - 1)]
+    assert np.abs(o[3:7] - np.array(accs)).max() <= 1e-6
+    assert relerr(pd.grad.cpu(), pr.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 9, 11), (2, 1, 13, 7), (3, 1, 80, 80)])
+def test_edge_loss_ragged_sizes(shape):
+    # element counts with a scalar tail behind the 16-byte passes
+    gen = torch.Generator().manual_seed(shape[2])
+    xs = torch.rand(shape, generator=gen)
+    t = torch.rand(shape, generator=gen)
+    xd = xs.to(DEV).requires_grad_(True)
+    el = ops.EdgeLoss.apply(xd, t.to(DEV), 5.0)
+    el.backward()
+    xr = xs.clone().requires_grad_(True)
+    a = (xr - xr.min()) / (xr.max() - xr.min())
+    b = (t - t.min()) / (t.max() - t.min())
+    ref = 5.0 * F.mse_loss(a, b)
+    ref.backward()
+    assert abs(float(el) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    assert relerr(xd.grad.cpu(), xr.grad) <= 1e-5
+
+
+@pytest.mark.parametrize("hs,ws,pad", [(48, 100, 45), (32, 160, 20), (80, 80, 45)])
+def test_gauss_grid_bwd_shapes(hs, ws, pad):
+    # non-square grids: border-weight tables (sides <= 128) and the tap-by-tap border path (wider), against fp64 autograd
+    gen = torch.Generator().manual_seed(hs + ws)
+    xs = torch.softmax(torch.randn(2, hs * ws, generator=gen) * 2, dim=1).view(2, 1, hs, ws)
+    g1d = torch.from_numpy(O.gaussian_1d(2 * pad + 1, pad)).to(DEV)
+    x64 = xs.double().requires_grad_(True)
+    g64 = O.create_grid_f64(x64, pad)
+    safe = ((g64.detach().abs() - 1).abs() > 1e-4).to(torch.float64)
+    cot = torch.randn(2, hs, ws, 2, generator=gen).double() * safe
+    (g64 * cot).sum().backward()
+    xd = xs.to(DEV).requires_grad_(True)
+    grid = ops.GaussGrid.apply(xd, g1d, pad)
+    assert np.abs(grid.detach().cpu().numpy() - g64.detach().numpy()).max() <= 3e-6
+    grid.backward(cot.float().to(DEV))
+    assert relerr(xd.grad.cpu(), x64.grad.float()) <= 1e-4
+
+
+def test_weight_amax_segments_unaligned():
+    # parameters at arbitrary arena offsets: 16-byte body where the segment is aligned, scalar path and tails elsewhere
+    gen = torch.Generator().manual_seed(11)
+    sizes = [1, 3, 64, 255, 1000, 1025, 4099, 70001, 300000]
+    offs, n = [], 5
+    for i, sz in enumerate(sizes):
+        offs.append(n)
+        n += sz + (i % 3)
+    arena = torch.randn(n, generator=gen)
+    arena[offs[5] + 1024] = 77.0          # maximum in a tail element
+    arena[offs[8] + 299999] = -91.0
+    ad = arena.to(DEV)
+    out = torch.empty(len(sizes), device=DEV, dtype=torch.int32)
+    hip = fovealseg.hip
+    offs_d = torch.tensor(offs, dtype=torch.int64, device=DEV)
+    sizes_d = torch.tensor(sizes, dtype=torch.int64, device=DEV)
+    hip.call("fs_weight_amax_segments", hip.ptr(ad), hip.ptr(offs_d), hip.ptr(sizes_d), len(sizes), hip.ptr(out))
+    got = out.cpu().view(torch.float32)
+    want = torch.stack([arena[o:o + s].abs().max() for o, s in zip(offs, sizes)])
+    assert torch.equal(got, want)
+
+
 def _hip_module():
     cfg = fovealseg.lvis50_cfg()
     MB = fovealseg.ModelBuilder
