@@ -5,6 +5,7 @@ reference's logical (Cout,Cin,R,S) shape with RSCK strides, so `w.permute(2,3,1,
 [R][S][Cin][Cout] array the kernels read (DESIGN.md "Data layout").
 """
 import ctypes
+import os
 import zlib
 
 import torch
@@ -99,6 +100,7 @@ class KernelTimer:
         return out
 
 
+WGRAD_FIRST = os.environ.get("FS_WGRAD_FIRST", "1") != "0"      # kernel experiments: order of the two conv backward launches
 TIMER = None      # set to a KernelTimer by bench.py around the timed region
 
 
@@ -284,11 +286,14 @@ class ConvBnAct(Function):
                 "fs_bn_act_bwd", hip.ptr(dz), hip.ptr(z), hip.ptr(amask), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), M, C,
                 m["act"], 1 if m["training"] else 0, float(m["drop_p"]), int(m["drop_key"]), hip.ptr(dy), hip.ptr(dres),
                 hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums))
-        dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax) if ctx.needs_input_grad[0] else None
         tgt = _direct_grad_target(w)
+        if not WGRAD_FIRST:
+            dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax) if ctx.needs_input_grad[0] else None
         dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"], accumulate=tgt is not None)
         if tgt is not None:
             dw = None
+        if WGRAD_FIRST:     # dx is what the next backward node reads: produce it last so it is the freshest tensor in the cache
+            dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax) if ctx.needs_input_grad[0] else None
         dbias = colsum(dy, C) if m["has_bias"] else None
         if direct_affine:
             dgamma = dbeta = None
