@@ -211,21 +211,26 @@ def main():
                 if "conv_wgrad" in summ:
                     line["roofline_wgrad"] = entry(summ["conv_wgrad"], "conv_wgrad_taps_kernel<3|9> + conv_wgrad_kernel (bwd-weight, fp32 MFMA)",
                                                    PEAK_F32_MFMA_TFLOPS, "conv_wgrad_taps_kernel")
-            def hbm_entry(kk, desc):
+            def hbm_entry(kk, desc, knames):
                 ach = kk["flops"] / (kk["total_ms"] * 1e-3) / 1e9
+                parts = [_profiled_traffic(k) for k in knames]
+                traffic = None
+                if all(parts):
+                    traffic = {"hbm_bytes_per_launch": sum(t["hbm_bytes_per_launch"] for t in parts), "source": parts[0]["source"]}
                 return {"kernel": desc, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
                         "launches_per_step": kk["launches"] // args.steps,
                         "avg_launch_us": round(1000.0 * kk["total_ms"] / kk["launches"], 2),
                         "mb_per_launch": round(kk["flops"] / kk["launches"] / 1e6, 2),
                         "share_of_serial_step": round(kk["total_ms"] / (1000.0 * serial_elapsed), 3)}
             if "bn_fwd" in summ:
                 line["roofline_bn_fwd"] = hbm_entry(summ["bn_fwd"], "bn_act_fwd_kernel (normalise + residual + activation + mask bytes; "
-                                                    "algorithmic bytes = conv output read, [residual read,] activation written, 1 mask byte per 4 channels)")
+                                                    "algorithmic bytes = conv output read, [residual read,] activation written, 1 mask byte per 4 channels)", ["bn_act_fwd_kernel"])
             if "bn_bwd" in summ:
                 line["roofline_bn_bwd"] = hbm_entry(summ["bn_bwd"], "bn_bwd_reduce_kernel + bn_bwd_apply_kernel (one C-ABI call; algorithmic bytes = dz, conv "
                                                     "output and mask read once, dy [and the residual gradient] written once -- the two-pass "
-                                                    "reduction reads dz and the conv output twice, so 3/5 of the HBM peak is this pair's ceiling)")
+                                                    "reduction reads dz and the conv output twice, so 3/5 of the HBM peak is this pair's ceiling)",
+                                                    ["bn_bwd_reduce_kernel", "bn_bwd_apply_kernel"])
         # whole step against the planning roofs of SURVEY.md 8(d): 456.9 GFLOP and 3 x 0.671 GB algorithmic per image, fwd+bwd
         per_gpu = line["value"] / world
         line["whole_step"] = {"algorithmic_tflops": round(0.4569 * per_gpu, 1), "fp32_mfma_peak_tflops": PEAK_F32_MFMA_TFLOPS,

@@ -172,7 +172,10 @@ def ddp_setup(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl" and torch.cuda.is_available():      # bind the communicator (and barrier()) to this rank's GPU
+            kw["device_id"] = torch.device("cuda", local_rank % torch.cuda.device_count())
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
     return rank, local_rank, world
