@@ -71,7 +71,8 @@ def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, act, res=None, drop_p=0.
     meta = dict(stride=conv.stride, pad=conv.padding, dil=conv.dilation, act=act, training=training, momentum=bn.momentum,
                 drop_p=drop_p, drop_key=ops.DropoutState.key(layer_id) if (training and drop_p > 0) else 0,
                 running_mean=bn.running_mean, running_var=bn.running_var, num_batches_tracked=_NbtCounter(bn))
-    return ops.ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, res, meta)
+    x, w = ops.pad_in_channels(x, conv.weight)
+    return ops.ConvBnAct.apply(x, w, conv.bias, bn.weight, bn.bias, res, meta)
 
 
 PARALLEL_BRANCHES = True

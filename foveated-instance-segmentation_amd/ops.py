@@ -219,6 +219,46 @@ def colsum(x2d_rows, C):
 
 
 # ----------------------------------------------------------------------------------------------
+# Layers fed by 3 or 5 input channels (HRNet stem, saliency net) as aligned problems: the generic scalar-channel kernels spend
+# 0.4-1.3 ms per launch on them where the aligned ones are bound by the 105-315 MB of activations they move.
+# ----------------------------------------------------------------------------------------------
+PAD_ODD_CHANNELS = os.environ.get("FS_PAD_ODD_CHANNELS", "1") != "0"
+
+
+def padded_in_channels(cin):
+    """Input-channel count the aligned kernels accept for a layer with `cin` channels (bwd-weight wants >= 16, all want x4)."""
+    return 16 if cin < 16 else (cin + 3) // 4 * 4
+
+
+class PadWeightChannels(Function):
+    """(Cout,Cin,R,S) RSCK weight -> (Cout,Cp,R,S) RSCK weight with zero taps for the padding channels; backward slices."""
+
+    @staticmethod
+    def forward(ctx, w, cp):
+        cout, cin, r, s = w.shape
+        wp = new_rsck_weight(cout, cp, r, s, device=w.device)
+        v = rsck(wp)
+        v.zero_()
+        v[:, :, :cin, :].copy_(rsck(w))
+        ctx.cin = cin
+        return wp
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.cin], None
+
+
+def pad_in_channels(x, w):
+    """(x (B,H,W,Cin), w) -> (x padded with zero channels, w padded alike) when Cin is not a multiple of 4 and the split-precision
+    kernels are on; exact: the extra products are 0 * 0."""
+    cin = w.shape[1]
+    if not PAD_ODD_CHANNELS or cin % 4 == 0 or hip.get_conv_precision() == "f32":
+        return x, w
+    cp = padded_in_channels(cin)
+    return torch.nn.functional.pad(x, (0, cp - cin)), PadWeightChannels.apply(w, cp)
+
+
+# ----------------------------------------------------------------------------------------------
 # conv (+bias) (+dropout) + BatchNorm + residual + activation
 # ----------------------------------------------------------------------------------------------
 class ConvBnAct(Function):

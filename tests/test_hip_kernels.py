@@ -511,6 +511,31 @@ def test_weight_amax_segments_unaligned():
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("Ci,Co,k,stride", [(3, 64, 3, 1), (5, 192, 3, 1), (5, 24, 3, 2), (7, 32, 1, 1), (18, 20, 3, 1)])
+def test_odd_input_channels_padded(Ci, Co, k, stride, prec):
+    # layers whose input-channel count is no multiple of 4 run as zero-padded aligned problems (ops.pad_in_channels)
+    gen = torch.Generator().manual_seed(Ci * 100 + Co)
+    B, H, W, pad = 3, 19, 23, k // 2
+    x = torch.randn(B, H, W, Ci, generator=gen)
+    wl = torch.randn(Co, Ci, k, k, generator=gen) * 0.2
+    w = ops.new_rsck_weight(Co, Ci, k, k, device=DEV)
+    w.copy_(wl.to(DEV))
+    w.requires_grad_(True)
+    xd = x.to(DEV).requires_grad_(True)
+    xp, wp = ops.pad_in_channels(xd, w)
+    assert (xp.shape[-1] % 4 == 0 and xp.shape[-1] >= 16) == (prec != "f32") or Ci % 4 == 0
+    y = ops.ConvBias.apply(xp, wp, None, stride, pad)
+    x64 = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    w64 = wl.double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, stride, pad)
+    cot = torch.randn(y64.shape, generator=gen)
+    (y64 * cot.double()).sum().backward()
+    (y * cot.permute(0, 2, 3, 1).to(DEV)).sum().backward()
+    assert relerr(nchw(y.detach()), y64.detach().float()) <= 1e-5
+    assert relerr(nchw(xd.grad), x64.grad.float()) <= 1e-5
+    assert relerr(w.grad.cpu(), w64.grad.float()) <= 1e-5
+
+
 def _hip_module():
     cfg = fovealseg.lvis50_cfg()
     MB = fovealseg.ModelBuilder
