@@ -941,6 +941,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(WgradArgs a) {
   }
 }
 
+// dst pixels (y, x) whose class (y % st, x % st) is in `classes` <- 0, all channels (16-byte stores, nothing read)
+__global__ __launch_bounds__(256) void zero_classes_kernel(float* __restrict__ dst, long n4, int H, int W, int C4, int st, unsigned classes) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long pix = i / C4;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    if ((classes >> ((y % st) * st + (x % st))) & 1u) reinterpret_cast<f32x4*>(dst)[i] = z;
+  }
+}
+
 int launch_affine_one(AffArgs& a) {
   const long M = (long)a.B * a.Hq * a.Wq;
   a.nx = cdiv(M, 128);
@@ -971,6 +981,9 @@ static const bool g_tapset_all = [] { const char* e = getenv("FS_TAPSET_ALL"); r
 bool tapset_shape_ok(int Cs, int Cd, int R, int S, int stride, int dil) {
   const int cr = stride < R ? stride : R, cs = stride < S ? stride : S;
   // 1x1 filters have no tap reuse: measured slower than conv_igemm_split_kernel (43 vs 55 TF on 64->256 @ 80x80), not routed here
+  // stride >= filter size: every tap class is a single tap, nothing is shared between outputs -- same case as 1x1
+  // (960->512 3x3 stride 4 forward: 1.73 ms on conv_igemm_split_kernel, 2.37 ms here)
+  if (stride >= R && stride >= S && R * S > 1 && !g_tapset_1x1) return false;
   return dil == 1 && (R * S > 1 || g_tapset_1x1) && Cs % 4 == 0 && Cd % 4 == 0 && Cs >= 16 && cr * cs <= 9 &&
          ((R + stride - 1) / stride) * ((S + stride - 1) / stride) <= 64;
 }
@@ -1024,6 +1037,10 @@ int launch_affine(const ConvArgs& c, long M) {
   // tap r iff (y + pad - r) % stride == 0, i.e. r = r0 + stride*t with r0 = (oy0 + pad) % stride, and then
   // reads dY row (y + pad - r)/stride = py + (oy0 + pad - r0)/stride - t.
   const int st = c.stride;
+  // classes no tap reaches (stride > filter size: 7 of 16 for 3x3 stride 4, 15 of 16 for 1x1 stride 4) are zero-filled by one
+  // store-only launch instead of one conv launch each (1x1 stride 4, 1.57 GB of dX: 1.13 -> 0.55 ms)
+  const bool fill_ok = st * st <= 32 && c.Cd % 4 == 0 && c.bias == nullptr;
+  unsigned empty_classes = 0u;
   for (int oy0 = 0; oy0 < st; ++oy0)
     for (int ox0 = 0; ox0 < st; ++ox0) {
       AffArgs b = a;
@@ -1032,9 +1049,10 @@ int launch_affine(const ConvArgs& c, long M) {
       b.r0 = (oy0 + c.pad) % st; b.s0 = (ox0 + c.pad) % st;
       b.nR = b.r0 < c.R ? (c.R - b.r0 + st - 1) / st : 0;
       b.nS = b.s0 < c.S ? (c.S - b.s0 + st - 1) / st : 0;
-      if (b.nR == 0 || b.nS == 0) { b.nR = 0; b.nS = 0; }       // no tap reaches this class: writes zeros
+      if (b.nR == 0 || b.nS == 0) { b.nR = 0; b.nS = 0; }       // no tap reaches this class: zeros
       b.cy = (oy0 + c.pad - b.r0) / st; b.cx = (ox0 + c.pad - b.s0) / st;
       if (b.Hq <= 0 || b.Wq <= 0) continue;
+      if (b.nR == 0 && fill_ok) { empty_classes |= 1u << (oy0 * st + ox0); continue; }
       if ((b.nR * b.nS > 1 || (g_tapset_1x1 && b.nR * b.nS == 1)) && use_tapset(c)) {       // single-tap sub-problems: no reuse, the plain kernel is faster
         // dY row of tap t is py + cy - t: in increasing source order tr = nR-1-t, filter row r0 + st*(nR-1-tr)
         FsTapsetProblem p = tapset_base(c);
@@ -1048,6 +1066,13 @@ int launch_affine(const ConvArgs& c, long M) {
       int e = launch_affine_one(b);
       if (e != FS_OK) return e;
     }
+  if (empty_classes != 0u) {
+    const long n4 = (long)c.B * c.Hd * c.Wd * (c.Cd / 4);
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(zero_classes_kernel, dim3((unsigned)blocks), dim3(256), 0, c.stream_, c.dst, n4, c.Hd, c.Wd, c.Cd / 4, st, empty_classes);
+    FS_LAUNCH_CHECK();
+  }
   return FS_OK;
 }
 

@@ -252,8 +252,8 @@ def pad_in_channels(x, w):
     """(x (B,H,W,Cin), w) -> (x padded with zero channels, w padded alike) when Cin is not a multiple of 4 and the split-precision
     kernels are on; exact: the extra products are 0 * 0."""
     cin = w.shape[1]
-    if not PAD_ODD_CHANNELS or cin % 4 == 0 or hip.get_conv_precision() == "f32":
-        return x, w
+    if not PAD_ODD_CHANNELS or cin % 4 == 0 or w.shape[2] * w.shape[3] > 32 or hip.get_conv_precision() == "f32":
+        return x, w          # aligned already, or a filter beyond the aligned kernels' 32 taps (7x7 ResNet stem): generic kernels
     cp = padded_in_channels(cin)
     return torch.nn.functional.pad(x, (0, cp - cin)), PadWeightChannels.apply(w, cp)
 

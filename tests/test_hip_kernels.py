@@ -79,6 +79,9 @@ CONV_CASES = [
     (1, 12, 12, 960, 240, 3, 1, False),    # C1 cbr
     (2, 20, 20, 96, 512, 3, 4, True),      # cls_net stride 4 + bias
     (2, 20, 20, 96, 64, 1, 4, True),       # 1x1 stride 4 downsample
+    (2, 19, 22, 32, 48, 3, 4, False),      # stride > filter reach, ragged size: empty bwd-data classes are zero-filled
+    (2, 17, 17, 32, 32, 3, 3, False),      # stride = filter size
+    (1, 13, 9, 16, 32, 1, 3, False),
     (5, 1, 1, 512, 51, 1, 1, True),        # FC as 1x1 conv, scalar path
     (1, 10, 10, 512, 512, 3, 1, False),
     (2, 10, 10, 64, 64, 3, 1, False, 2),    # dilation 2 (DeepLab layer3)

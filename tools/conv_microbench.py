@@ -20,6 +20,9 @@ SHAPES = [  # B, H, W, Cin, Cout, k, stride
     (64, 80, 80, 256, 64, 1, 1),
     (64, 80, 80, 64, 128, 3, 2),
     (64, 80, 80, 192, 192, 3, 1),
+    (64, 80, 80, 960, 512, 3, 4),     # C1 classification head: stride > filter reach, every tap class is a single tap
+    (64, 80, 80, 960, 512, 1, 4),
+    (64, 20, 20, 512, 512, 3, 2),
 ]
 
 
