@@ -66,9 +66,9 @@ class _NbtCounter:
         self.bn._pending_batches += n
 
 
-def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, act, res=None, drop_p=0.0, layer_id=0):
+def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, act, res=None, drop_p=0.0, layer_id=0, stride=None):
     training = bn.training
-    meta = dict(stride=conv.stride, pad=conv.padding, dil=conv.dilation, act=act, training=training, momentum=bn.momentum,
+    meta = dict(stride=conv.stride if stride is None else stride, pad=conv.padding, dil=conv.dilation, act=act, training=training, momentum=bn.momentum,
                 drop_p=drop_p, drop_key=ops.DropoutState.key(layer_id) if (training and drop_p > 0) else 0,
                 running_mean=bn.running_mean, running_var=bn.running_var, num_batches_tracked=_NbtCounter(bn))
     x, w = ops.pad_in_channels(x, conv.weight)
@@ -177,9 +177,9 @@ class _ConvBn(nn.Sequential):
         super().__init__(*mods)
         self.relu = relu
 
-    def forward(self, x, res=None, act=None):
+    def forward(self, x, res=None, act=None, stride=None):
         a = (ACT_RELU if self.relu else ACT_NONE) if act is None else act
-        return conv_bn_act(x, self[0], self[1], a, res=res)
+        return conv_bn_act(x, self[0], self[1], a, res=res, stride=stride)
 
 
 class _Chain(nn.Sequential):
@@ -316,7 +316,14 @@ class ResidualBlock(nn.Module):
         self.downsample[0].padding = 0
 
     def forward(self, x):
-        r = self.downsample(x)
+        ds = self.downsample[0]
+        if ops.FANOUT_SUBSAMPLE and ds.k == 1 and ds.stride > 1 and ds.padding == 0:
+            # a strided 1x1 conv reads every stride-th pixel: run it densely on the subsampled input, and let the backward add
+            # its gradient into conv1's dX at those pixels instead of materialising a full-size, 15/16-zero tensor for autograd to sum
+            x, xs = ops.FanOutSubsample.apply(x, ds.stride)
+            r = self.downsample(xs, stride=1)
+        else:
+            r = self.downsample(x)
         o = self.conv1(x)
         return self.conv2(o, res=r, act=ACT_RELU)
 

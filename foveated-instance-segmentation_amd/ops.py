@@ -258,6 +258,31 @@ def pad_in_channels(x, w):
     return torch.nn.functional.pad(x, (0, cp - cin)), PadWeightChannels.apply(w, cp)
 
 
+FANOUT_SUBSAMPLE = os.environ.get("FS_FANOUT_SUBSAMPLE", "1") != "0"
+
+
+class FanOutSubsample(Function):
+    """x (B,H,W,C) -> (x, x[:, ::s, ::s, :] contiguous).  Backward: the subsampled branch's gradient is added in place into the
+    full-resolution branch's gradient at the sampled pixels (that tensor is the fresh dX of the branch's first consumer)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        ctx.shape = x.shape
+        return x.view_as(x), x[:, ::s, ::s, :].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_full, g_sub):
+        s = ctx.s
+        if g_full is None:
+            g_full = torch.zeros(ctx.shape, device=g_sub.device, dtype=g_sub.dtype)
+        elif not g_full.is_contiguous():
+            g_full = g_full.contiguous()
+        if g_sub is not None:
+            g_full[:, ::s, ::s, :].add_(g_sub)
+        return g_full, None
+
+
 # ----------------------------------------------------------------------------------------------
 # conv (+bias) (+dropout) + BatchNorm + residual + activation
 # ----------------------------------------------------------------------------------------------
