@@ -135,6 +135,26 @@ def main():
     # kernel lifetimes overlap and a per-launch duration is not separable; the same K steps are
     # therefore repeated with the branch streams serialised and every conv launch bracketed by HIP
     # events on the launch stream (this pass is NOT part of `value`).
+    # forward-only (inference) rate of the same path, SURVEY.md 8(d): eval mode (running statistics, no dropout), no autograd
+    fwd_only = None
+    if world == 1:
+        try:
+            module.eval()
+            T.eval_step(module, batch)
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            for i in range(args.steps):
+                T.eval_step(module, batch)
+            torch.cuda.synchronize()
+            tf = time.perf_counter() - tf0
+            fwd_only = {"img_per_s": round(args.batch * args.steps / tf, 1), "ms_per_batch": round(1000.0 * tf / args.steps, 2),
+                        "algorithmic_tflops": round(0.15229 * args.batch * args.steps / tf, 1),
+                        "what": "DeformSegmentationModule forward, is_inference=True, eval mode, no_grad; 152.29 GFLOP per image"}
+        except Exception as exc:
+            fwd_only = {"error": repr(exc)}
+        finally:
+            module.train()
+
     timer, timer_error = None, None
     if not args.no_kernel_timer and world == 1:      # single-GPU only: the step contains collectives
         saved = Mods.PARALLEL_BRANCHES
@@ -231,6 +251,8 @@ def main():
                                                     "output and mask read once, dy [and the residual gradient] written once -- the two-pass "
                                                     "reduction reads dz and the conv output twice, so 3/5 of the HBM peak is this pair's ceiling)",
                                                     ["bn_bwd_reduce_kernel", "bn_bwd_apply_kernel"])
+        if fwd_only is not None:
+            line["forward_only"] = fwd_only
         # whole step against the planning roofs of SURVEY.md 8(d): 456.9 GFLOP and 3 x 0.671 GB algorithmic per image, fwd+bwd
         per_gpu = line["value"] / world
         line["whole_step"] = {"algorithmic_tflops": round(0.4569 * per_gpu, 1), "fp32_mfma_peak_tflops": PEAK_F32_MFMA_TFLOPS,
