@@ -10,7 +10,7 @@
 // Which kernel runs (precision mode g_conv_precision: 0 = f32, 1 = bf16x3, 2 = f16x2):
 //   3x3 stride 1 pad 1, aligned channels, modes 1/2, scratch given : conv_halo.hip (fwd, bwd-data), conv_wgrad.hip (bwd-weight)
 //   other multi-tap filters / strided bwd-data sub-problems, modes 1/2 : conv_tapset.hip; bwd-weight per tap class: conv_wgrad.hip
-//   1x1 and single-tap sub-problems, modes 1/2                     : conv_igemm_split_kernel<P> (this file)
+//   1x1, stride >= filter size, single-tap sub-problems, modes 1/2 : conv_igemm_split_kernel<P> (this file)
 //   everything in mode 0                                           : conv_igemm_affine_kernel, conv_wgrad_taps_kernel (fp32 MFMA)
 //   channel counts that are not multiples of 4                     : conv_igemm_kernel, conv_wgrad_kernel (generic)
 // The kernels in this file share one tiling: 256 threads = 4 waves, workgroup tile 128 (pixels) x 64 (channels), K-step 32

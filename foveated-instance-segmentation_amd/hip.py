@@ -108,8 +108,8 @@ def load():
 
 def set_conv_precision(mode: str) -> None:
     """'f32' (fp32 MFMA), 'bf16x3' (three bf16 terms per operand, six bf16 MFMAs per product) or 'f16x2' (two scaled
-    fp16 terms, three fp16 MFMAs per product, used by the 3x3 stride-1 kernels; other shapes run bf16x3).  All three
-    accumulate in fp32 and stay within the rounding error of an fp32 accumulation chain."""
+    fp16 terms, three fp16 MFMAs per product).  All three accumulate in fp32 and stay within the rounding error of an fp32
+    accumulation chain; layers whose channel counts are no multiple of 4 run on the fp32-MFMA kernels in every mode."""
     code = {"f32": 0, "bf16x3": 1, "f16x2": 2}[mode]
     if load().fs_set_conv_precision(code) != 0:
         raise HipLibraryError("fs_set_conv_precision rejected the mode")
