@@ -131,3 +131,37 @@ def test_dropout_hash_statistics():
     assert abs(keep.mean() - 0.7) < 2e-3
     assert O.layer_key(3, 77) == ops.layer_key(3, 77)
     assert not np.array_equal(keep, O.dropout_keep_mask_nhwc(1 << 20, ops.layer_key(3, 78), 0.3))
+
+
+def test_pad_weight_channels_and_fanout_subsample_autograd():
+    """Host-side autograd glue added for the odd-channel and strided-shortcut layers (pure tensor logic, no kernel)."""
+    import torch
+    from fovealseg import ops
+    g = torch.Generator().manual_seed(3)
+    # PadWeightChannels: zero taps for the padding channels, gradient sliced back to the parameter's shape
+    w = ops.new_rsck_weight(6, 5, 3, 3)
+    w.copy_(torch.randn(6, 5, 3, 3, generator=g))
+    w.requires_grad_(True)
+    wp = ops.PadWeightChannels.apply(w, 16)
+    assert wp.shape == (6, 16, 3, 3) and ops.rsck(wp).is_contiguous()
+    assert torch.equal(wp[:, :5].detach(), w.detach()) and float(wp[:, 5:].detach().abs().max()) == 0.0
+    cot = torch.randn(6, 16, 3, 3, generator=g)
+    (wp * cot).sum().backward()
+    assert torch.equal(w.grad, cot[:, :5])
+    assert ops.padded_in_channels(3) == 16 and ops.padded_in_channels(5) == 16 and ops.padded_in_channels(18) == 20
+    # FanOutSubsample: forward = (x, x[:, ::s, ::s]); backward adds the subsampled gradient at the sampled pixels
+    x = torch.randn(2, 9, 10, 4, generator=g, requires_grad=True)
+    xf, xs = ops.FanOutSubsample.apply(x, 4)
+    assert torch.equal(xf, x) and torch.equal(xs, x[:, ::4, ::4, :])
+    gf, gs = torch.randn(xf.shape, generator=g), torch.randn(xs.shape, generator=g)
+    ((xf * 1.0 * gf).sum() + (xs * gs).sum()).backward()
+    want = gf.clone()
+    want[:, ::4, ::4, :] += gs
+    assert torch.allclose(x.grad, want)
+    # only the subsampled branch used
+    x2 = torch.randn(1, 5, 5, 2, generator=g, requires_grad=True)
+    _, xs2 = ops.FanOutSubsample.apply(x2, 2)
+    xs2.sum().backward()
+    want2 = torch.zeros_like(x2)
+    want2[:, ::2, ::2, :] = 1.0
+    assert torch.equal(x2.grad, want2)
