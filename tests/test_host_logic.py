@@ -2,6 +2,7 @@
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -165,3 +166,23 @@ def test_pad_weight_channels_and_fanout_subsample_autograd():
     want2 = torch.zeros_like(x2)
     want2[:, ::2, ::2, :] = 1.0
     assert torch.equal(x2.grad, want2)
+
+
+def test_driver_contract_surface():
+    """bench.py takes the driver's flags and __graft_entry__ exposes build() / smoke(); nothing here touches a GPU."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    for flag in ("--gpus", "--steps", "--warmup", "--conv-precision"):
+        assert flag in out.stdout
+    src = open(os.path.join(root, "bench.py")).read()
+    for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"', '"vs_baseline"', '"dtype"',
+                '"data"', '"config"', '"roofline"', '"cpu_baseline"'):
+        assert key in src, key
+    assert "/root/reference" not in src                      # nothing on the GPU box may read the reference
+    sys.path.insert(0, root)
+    import __graft_entry__ as g
+    assert callable(g.build) and callable(g.smoke)
+    entry = open(os.path.join(root, "__graft_entry__.py")).read()
+    assert "gfx950" in entry or "build.py" in entry
