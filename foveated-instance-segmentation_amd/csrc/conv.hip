@@ -240,7 +240,7 @@ struct AffArgs {
   int R, S, stride, pad, dil;
   int transposed;
   float drop_scale; uint32_t drop_thresh, drop_key;
-  unsigned src_bytes, w_bytes;
+  unsigned src_bytes, w_bytes, dst_bytes;   // dst_bytes = 0: Y / dX is 4 GB or more, 64-bit stores
   // output sub-grid (stride>1 bwd-data is run as stride^2 dense sub-problems, one per output parity
   // class, each with its own tap subset): loop grid Hq x Wq, dst pixel = (py*os+oy0, px*os+ox0),
   // taps r = r0 + tstep*tr' (nR of them), s likewise; source row of tap' (0,0) = py + cy.
@@ -678,25 +678,37 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(AffArgs a) {
   const int Eo = E - 28;                                   // two factors: the combined exponent can leave the float range
   const float fo1 = P::SCALED ? fs_split::pow2f(Eo / 2) : 1.f, fo2 = P::SCALED ? fs_split::pow2f(Eo - Eo / 2) : 1.f;
   float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+  // Epilogue with the row arithmetic hoisted out of the column loop and 32-bit buffer stores when dX / Y is below 4 GB: at
+  // K = 64 (the 1x1 bottleneck convs) the epilogue's VALU work, not the MFMAs, was the larger share of the kernel.
+  float bv[2];
+  bool nok[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int n = n0 + 32 * t + l31;
-    if (n >= a.Cd) continue;
-    const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
+    nok[t] = n < a.Cd;
+    bv[t] = (a.bias != nullptr && nok[t]) ? a.bias[n] : 0.f;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
+  const long HWq = (long)a.Hq * a.Wq;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= M) continue;
-      float v = (P::SCALED ? (t == 0 ? acc0[r] : acc1[r]) * fo1 * fo2 : (t == 0 ? acc0[r] : acc1[r])) + bv;
-      long e = m * a.Cd + n;
-      if (a.os > 1) {
-        const int b = (int)(m / ((long)a.Hq * a.Wq));
-        const int rem = (int)(m - (long)b * a.Hq * a.Wq);
-        const int py = rem / a.Wq, px = rem - py * a.Wq;
-        e = (((long)b * a.Hd + py * a.os + a.oy0) * a.Wd + px * a.os + a.ox0) * a.Cd + n;
-      }
+  for (int r = 0; r < 16; ++r) {
+    const long m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (m >= M) continue;
+    long erow = m * a.Cd;
+    if (a.os > 1) {
+      const int b = (int)(m / HWq);
+      const int rem = (int)(m - (long)b * HWq);
+      const int py = rem / a.Wq, px = rem - py * a.Wq;
+      erow = (((long)b * a.Hd + py * a.os + a.oy0) * a.Wd + px * a.os + a.ox0) * a.Cd;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (!nok[t]) continue;
+      float v = (P::SCALED ? (t == 0 ? acc0[r] : acc1[r]) * fo1 * fo2 : (t == 0 ? acc0[r] : acc1[r])) + bv[t];
+      const long e = erow + n0 + 32 * t + l31;
       if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-      a.dst[e] = v;
+      if (a.dst_bytes != 0u) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc_d, (int)((unsigned)e * 4u), 0, 0);
+      else a.dst[e] = v;
       csum[t] += v; csq[t] += v * v;
     }
   }
@@ -1017,6 +1029,7 @@ int launch_affine(const ConvArgs& c, long M) {
   AffArgs a{c.src, c.w, c.bias, c.dst, c.B, c.Hs, c.Ws, c.Cs, c.Hd, c.Wd, c.Cd, c.R, c.S, c.stride, c.pad, c.dil, c.transposed,
             c.drop_scale, c.drop_thresh, c.drop_key,
             (unsigned)((size_t)c.B * c.Hs * c.Ws * c.Cs * 4), (unsigned)((size_t)c.R * c.S * c.Cs * c.Cd * 4),
+            (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL ? (unsigned)((size_t)c.B * c.Hd * c.Wd * c.Cd * 4) : 0u,
             c.Hd, c.Wd, 1, 0, 0, 0, 0, 1, c.R, c.S, c.pad, c.pad, 0, 0, c.stats_};
   a_stream = c.stream_;
   (void)M;
