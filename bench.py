@@ -5,55 +5,76 @@ metric  : images/sec, forward + backward + optimiser step, 1024x1024 -> 80x80 fo
           batch 64 per GPU (BASELINE.json configs[1]), train mode (BN batch statistics, Dropout 0.3).
 step    : one full optimisation step (train_deform_semantic.py:74-129) on a synthetic batch that is
           already resident in HBM.
-Usage   : python bench.py --gpus N --steps K --warmup W        (N>1 under torch.distributed.run)
+modes   : the conv engine has three arithmetic modes, all fp32 tensors + fp32 accumulation.
+          All three are timed in ONE run.  `value` is the `--headline` mode, by default `bf16x3`: operands
+          split into three bf16 terms = 24 significand bits, the reference's fp32 operand width.  `f16x2`
+          (22-23 bit operands) and `f32` (fp32 MFMA) are reported next to it under `modes`.
+Usage   : python bench.py --gpus N --steps K --warmup W
+          N>1: under torch.distributed.run (one rank per GPU, RCCL); started WITHOUT a launcher it
+          spawns that launcher itself before touching the GPU.
 Output  : ONE JSON line on rank 0 (see README/DESIGN.md "Measurement").
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, dense bf16 MFMA; the bf16x3 conv issues 6 bf16 MFMAs per fp32 product
-PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16 MFMA (same rate as bf16); the f16x2 conv issues 3 fp16 MFMAs per fp32 product
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # same guide, dense bf16 / fp16 MFMA
 PEAK_HBM_GBS = 8000.0
+
+MODES = {
+    # name: (kernel template tag, MFMAs per fp32 product, operand significand bits, description)
+    "bf16x3": ("PrecX3", 6, 24, "f32 storage + f32 accumulate; each operand = 3 bf16 terms (24 significand bits), 6 x v_mfma_f32_32x32x16_bf16 per product"),
+    "f16x2": ("PrecF16", 3, 22, "f32 storage + f32 accumulate; each operand scaled and split into 2 fp16 terms (22-23 significand bits), 3 x v_mfma_f32_32x32x16_f16 per product"),
+    "f32": (None, 1, 24, "f32 storage, v_mfma_f32_32x32x2_f32 products, f32 accumulate"),
+}
+
+
+def mode_peak(mode):
+    return PEAK_F32_MFMA_TFLOPS if mode == "f32" else PEAK_16BIT_MFMA_TFLOPS / MODES[mode][1]
 
 
 def _profiled_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this same command
-    (profiles/r01/hbm_traffic_serial.json; FETCH_SIZE doubled per the gfx950 correction).  PMC counters
+    (profiles/rNN/hbm_traffic_serial*.json; FETCH_SIZE doubled per the gfx950 correction).  PMC counters
     cannot be read from inside the benchmark process, so this is the offline measurement, or None."""
-    path = os.path.join(ROOT, "profiles", "r01", "hbm_traffic_serial.json")
-    try:
-        with open(path) as f:
-            table = json.load(f)
-        hits = [v for k, v in table.items() if k == kernel or k.startswith(kernel + "<")]      # template instances of one kernel
-        n = sum(v["launches"] for v in hits)
-        avg = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n
-        return {"hbm_bytes_per_launch": int(avg), "source": "profiles/r01/hbm_traffic_serial.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
-    except Exception:
-        return None
+    for rel in ("profiles/r02/hbm_traffic_serial.json", "profiles/r01/hbm_traffic_serial.json"):
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                table = json.load(f)
+            hits = [v for k, v in table.items() if k == kernel or k.startswith(kernel + "<")]      # template instances of one kernel
+            n = sum(v["launches"] for v in hits)
+            avg = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n
+            return {"hbm_bytes_per_launch": int(avg), "source": rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+        except Exception:
+            continue
+    return None
 
 
-def cpu_baseline(batch=4, H=1024, threads=None, reps=5):
+def _threads():
+    try:          # the GPU box exposes 128 logical CPUs but grants a 16-core share
+        return min(16, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return min(16, os.cpu_count() or 1)
+
+
+def cpu_baseline(batch=4, H=1024, threads=None, reps=5, fwd_batch=64):
     """The CPU oracle (port of the reference algorithm) timed on this host: BASELINE.json configs[0] (B=4, 1024^2), one
-    warm-up and five timed train-mode forward+backward passes, median reported (about 15 s of CPU work)."""
+    warm-up and five timed train-mode forward+backward passes, median reported, plus one B=64 forward-only pass
+    (about 30 s of CPU work in all)."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fovealseg_oracle as O
     from fovealseg.weights import apply_name_keyed_init
     from fovealseg.train import synthetic_batch
-    if threads is None:          # the GPU box exposes 128 logical CPUs but grants a 16-core share
-        try:
-            threads = min(16, len(os.sched_getaffinity(0)))
-        except AttributeError:
-            threads = min(16, os.cpu_count() or 1)
+    threads = threads or _threads()
     torch.set_num_threads(threads)
     o = O.OracleDeformSeg()
     apply_name_keyed_init(o)
@@ -69,12 +90,40 @@ def cpu_baseline(batch=4, H=1024, threads=None, reps=5):
         times.append(time.perf_counter() - t0)
     timed = sorted(times[1:])
     t = timed[len(timed) // 2]
-    return {"value": round(batch / t, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/fovealseg_oracle.py OracleDeformSeg, B={batch}, {H}x{H}->80x80, train mode, 1 warm-up + {reps} timed fwd+bwd "
-                      f"(no optimiser step), median {t:.2f} s, {sum(times):.1f} s of CPU work in all"}
+    out = {"value": round(batch / t, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"oracle/fovealseg_oracle.py OracleDeformSeg, B={batch}, {H}x{H}->80x80, train mode, 1 warm-up + {reps} timed fwd+bwd "
+                     f"(no optimiser step), median {t:.2f} s, {sum(times):.1f} s of CPU work in all"}
+    if fwd_batch:
+        o.eval()
+        X, Fp, Y, cls = synthetic_batch(fwd_batch, H, H, seed=1, device="cpu")
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            o({"img_data": X, "seg_label": Y, "focus_point": Fp, "cls_label": cls}, is_inference=True)
+            tf = time.perf_counter() - t0
+        out["forward_only"] = {"value": round(fwd_batch / tf, 3), "unit": "img/s", "sample": f"one eval-mode forward, B={fwd_batch}, {tf:.1f} s"}
+    return out
 
 
-def main():
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`bench.py --gpus N` (N>1) started without a launcher: become the launcher.  Nothing in this process has touched the
+    GPU yet (torch is not even imported), so the N ranks are plain children: `python -m torch.distributed.run ... bench.py`
+    -- the command the driver itself uses (train_deform_semantic.py:687-689 uses mp.spawn for the same purpose)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -83,23 +132,41 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-forward-only", action="store_true")
     ap.add_argument("--serial-streams", action="store_true", help="run the HRNet branches on one stream (profiling)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
-    ap.add_argument("--conv-precision", default="f16x2", choices=["f16x2", "bf16x3", "f32"],
-                    help="arithmetic of the conv kernels (fp32 tensors and fp32 accumulation in every mode): f16x2 = operands "
-                         "scaled and split into 2 fp16 terms, 3 fp16 MFMAs per product; "
-                         "bf16x3 = 3 bf16 terms, 6 bf16 MFMAs per product; f32 = fp32 MFMA.  All three are at the fp32 error level "
-                         "(tools/conv_accuracy.py)")
-    args = ap.parse_args()
+    ap.add_argument("--headline", default="bf16x3", choices=list(MODES),
+                    help="the mode whose throughput is `value` (default bf16x3: 24-bit operands like the reference's fp32)")
+    ap.add_argument("--modes", default="bf16x3,f16x2,f32", help="comma list of conv arithmetic modes to time in this run")
+    ap.add_argument("--conv-precision", default=None, choices=list(MODES), help="shorthand: time ONLY this mode and make it the headline")
+    return ap.parse_args()
 
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import torch
+    import torch.distributed as dist
     import fovealseg
     from fovealseg import train as T
     from fovealseg import ops
+    from fovealseg import modules as Mods
+
+    if args.conv_precision:
+        args.headline, args.modes = args.conv_precision, args.conv_precision
+    modes = [m for m in args.modes.split(",") if m]
+    if args.headline not in modes:
+        modes.insert(0, args.headline)
+    modes.sort(key=lambda m: m != args.headline)          # headline first
 
     fovealseg.hip.load()       # fail loudly if the HIP library is missing
-    fovealseg.hip.set_conv_precision(args.conv_precision)
     rank, local_rank, world = T.ddp_setup(backend=args.backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if world > 1:
+        assert dist.is_initialized() and dist.get_world_size() == world
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
@@ -110,155 +177,113 @@ def main():
     T.broadcast_parameters(optimizers, module)
     batch = T.synthetic_batch(args.batch, args.size, args.size, seed=1 + rank, device=dev)
     ops.DropoutState.seed = 1234 + rank
+    if args.serial_streams:
+        Mods.PARALLEL_BRANCHES = False
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    from fovealseg import modules as Mods
-    if args.serial_streams:
-        Mods.PARALLEL_BRANCHES = False
-    out = None
-    for i in range(args.warmup):
-        out = T.train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = T.train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    loss_val = float(out[0].detach())
-    assert loss_val == loss_val, "loss is NaN"
+    it = [0]
 
-    # Per-kernel roofline pass.  In the timed region the HRNet branches run on 4 HIP streams, so
-    # kernel lifetimes overlap and a per-launch duration is not separable; the same K steps are
-    # therefore repeated with the branch streams serialised and every conv launch bracketed by HIP
-    # events on the launch stream (this pass is NOT part of `value`).
+    def steps(n):
+        out = None
+        for _ in range(n):
+            out = T.train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=it[0])
+            it[0] += 1
+        return out
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+
+    results = {}
+    for mode in modes:
+        fovealseg.hip.set_conv_precision(mode)
+        for opt in optimizers:
+            opt.flat.refresh_amax()
+        steps(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        out = steps(args.steps)
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        loss_val = float(out[0].detach())
+        assert loss_val == loss_val, f"loss is NaN in mode {mode}"
+        res = {"value": round(args.batch * world * args.steps / elapsed, 3), "unit": "img/s", "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
+               "operand_significand_bits": MODES[mode][2], "arithmetic": MODES[mode][3], "loss": round(loss_val, 5)}
+
+        # Per-kernel roofline pass.  In the timed region the HRNet branches run on 4 HIP streams, so kernel lifetimes overlap and
+        # a per-launch duration is not separable; the same K steps are therefore repeated with the branch streams serialised and
+        # every conv / BatchNorm / front-end launch bracketed by HIP events on the launch stream (NOT part of `value`).
+        if not args.no_kernel_timer and world == 1:
+            saved = Mods.PARALLEL_BRANCHES
+            Mods.PARALLEL_BRANCHES = False
+            timer = ops.KernelTimer()
+            ops.TIMER = timer
+            try:
+                torch.cuda.synchronize()
+                tr0 = time.perf_counter()
+                steps(args.steps)
+                torch.cuda.synchronize()
+                serial_elapsed = time.perf_counter() - tr0
+                res.update(roofline_entries(mode, timer.summary(), args.steps, serial_elapsed))
+            except Exception as exc:                       # the throughput line must survive a failure of the diagnostic pass
+                res["roofline"] = None
+                res["roofline_error"] = repr(exc)
+            finally:
+                ops.TIMER = None
+                Mods.PARALLEL_BRANCHES = saved
+        per_gpu = res["value"] / world
+        res["whole_step"] = {"algorithmic_tflops": round(0.4569 * per_gpu, 1), "frac_of_mode_mfma_peak": round(0.4569 * per_gpu / mode_peak(mode), 4),
+                             "mode_mfma_peak_tflops": round(mode_peak(mode), 1), "algorithmic_hbm_gbs": round(3 * 0.671 * per_gpu, 1)}
+        results[mode] = res
+        if world > 1:
+            dist.barrier()
+
     # forward-only (inference) rate of the same path, SURVEY.md 8(d): eval mode (running statistics, no dropout), no autograd
     fwd_only = None
-    if world == 1:
-        try:
-            module.eval()
-            T.eval_step(module, batch)
-            torch.cuda.synchronize()
-            tf0 = time.perf_counter()
-            for i in range(args.steps):
+    if world == 1 and not args.no_forward_only:
+        fwd_only = {}
+        for mode in modes:
+            fovealseg.hip.set_conv_precision(mode)
+            try:
+                module.eval()
                 T.eval_step(module, batch)
-            torch.cuda.synchronize()
-            tf = time.perf_counter() - tf0
-            fwd_only = {"img_per_s": round(args.batch * args.steps / tf, 1), "ms_per_batch": round(1000.0 * tf / args.steps, 2),
-                        "algorithmic_tflops": round(0.15229 * args.batch * args.steps / tf, 1),
-                        "what": "DeformSegmentationModule forward, is_inference=True, eval mode, no_grad; 152.29 GFLOP per image"}
-        except Exception as exc:
-            fwd_only = {"error": repr(exc)}
-        finally:
-            module.train()
+                torch.cuda.synchronize()
+                tf0 = time.perf_counter()
+                for _ in range(args.steps):
+                    T.eval_step(module, batch)
+                torch.cuda.synchronize()
+                tf = time.perf_counter() - tf0
+                fwd_only[mode] = {"img_per_s": round(args.batch * args.steps / tf, 1), "ms_per_batch": round(1000.0 * tf / args.steps, 2),
+                                  "algorithmic_tflops": round(0.15229 * args.batch * args.steps / tf, 1)}
+            except Exception as exc:
+                fwd_only[mode] = {"error": repr(exc)}
+            finally:
+                module.train()
+        fwd_only["what"] = "DeformSegmentationModule forward, is_inference=True, eval mode, no_grad; 152.29 GFLOP per image"
 
-    timer, timer_error = None, None
-    if not args.no_kernel_timer and world == 1:      # single-GPU only: the step contains collectives
-        saved = Mods.PARALLEL_BRANCHES
-        Mods.PARALLEL_BRANCHES = False
-        timer = ops.KernelTimer()
-        ops.TIMER = timer
-        try:
-            torch.cuda.synchronize()
-            tr0 = time.perf_counter()
-            for i in range(args.steps):
-                T.train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=args.warmup + args.steps + i)
-            torch.cuda.synchronize()
-            serial_elapsed = time.perf_counter() - tr0
-        except Exception as exc:                       # the throughput line must survive a failure of the diagnostic pass
-            timer, timer_error = None, repr(exc)
-        finally:
-            ops.TIMER = None
-            Mods.PARALLEL_BRANCHES = saved
-    if world > 1:
-        dist.barrier()
-
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t)
-    imgs = args.batch * world * args.steps
+    head = results[args.headline]
     line = {
         "metric": "images/sec fwd+bwd, 1024->80 foveated HRNetV2, batch 64",
-        "value": round(imgs / elapsed, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "conv_precision": args.conv_precision,
+        "value": head["value"], "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": f"f32 ({args.headline}: {MODES[args.headline][3]})", "data": "synthetic", "conv_precision": args.headline,
         "config": {"workload": f"BASELINE configs[1]: HRNetV2-nodownsp + C1, {args.size}x{args.size}->80x80, gaussian_radius 45, "
                                f"batch {args.batch}/GPU, train mode (BN batch stats, Dropout 0.3), fwd+bwd+Adam x4",
-                   "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": round(loss_val, 5)},
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": head["loss"]},
     }
     if rank == 0:
-        if timer_error is not None:
-            line["roofline"] = None
-            line["roofline_error"] = timer_error
-        if timer is not None:
-            summ = timer.summary()
-            def entry(kk, desc, peak, kname):
-                ach = kk["flops"] / (kk["total_ms"] * 1e-3) / 1e12
-                return {"kernel": desc, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": _profiled_traffic(kname),
-                        "launches_per_step": kk["launches"] // args.steps,
-                        "avg_launch_us": round(1000.0 * kk["total_ms"] / kk["launches"], 2),
-                        "gflop_per_launch": round(kk["flops"] / kk["launches"] / 1e9, 3),
-                        "share_of_serial_step": round(kk["total_ms"] / (1000.0 * serial_elapsed), 3)}
-            split = {"f16x2": ("PrecF16", PEAK_F16_MFMA_TFLOPS / 3.0, "two scaled fp16 terms per operand, 3 x v_mfma_f32_32x32x16_f16 per product"),
-                     "bf16x3": ("PrecX3", PEAK_BF16_MFMA_TFLOPS / 6.0, "three bf16 terms per operand, 6 x v_mfma_f32_32x32x16_bf16 per product")}
-            if args.conv_precision in split and "conv3x3" in summ:
-                tag, peak, how = split[args.conv_precision]
-                line["roofline"] = entry(
-                    summ["conv3x3"],
-                    f"conv3x3_halo_kernel<{tag}> (3x3 stride-1 forward + bwd-data, halo-tiled implicit GEMM; {how}, fp32 accumulate; "
-                    "achieved = algorithmic fp32 FLOP/s over the C-ABI call incl. its weight pack pre-kernels, peak = dense MFMA peak / "
-                    "MFMAs per product)", peak, "conv3x3_halo_kernel")
-                line["roofline"]["serial_ms_per_step"] = round(1000.0 * serial_elapsed / args.steps, 2)
-                line["roofline"]["measured"] = "second pass of the same K steps with branch streams serialised, HIP events per launch"
-                if "wgrad3x3" in summ:
-                    line["roofline_wgrad"] = entry(
-                        summ["wgrad3x3"], f"conv_wgrad_class_kernel<{tag},3,3> (3x3 stride-1 bwd-weight, 9 taps per workgroup, split-K atomics; {how})",
-                        peak, f"conv_wgrad_class_kernel<fs_split::{tag}, 3, 3>")
-                if "conv_affine" in summ:
-                    line["roofline_other_convs"] = entry(
-                        summ["conv_affine"], f"conv_tapset_kernel<{tag}> (strided 3x3 forward + bwd-data sub-problems) + conv_igemm_split_kernel<{tag}> (1x1 convs "
-                                             "and single-tap sub-problems, HBM-bound at these channel counts)",
-                        peak, f"conv_igemm_split_kernel<fs_split::{tag}>")
-            elif "conv_affine" in summ:
-                line["roofline"] = entry(summ["conv_affine"], "conv_igemm_affine_kernel<1> (fwd + bwd-data implicit GEMM, fp32 MFMA 32x32x2)",
-                                         PEAK_F32_MFMA_TFLOPS, "conv_igemm_affine_kernel<1>")
-                line["roofline"]["serial_ms_per_step"] = round(1000.0 * serial_elapsed / args.steps, 2)
-                if "conv_wgrad" in summ:
-                    line["roofline_wgrad"] = entry(summ["conv_wgrad"], "conv_wgrad_taps_kernel<3|9> + conv_wgrad_kernel (bwd-weight, fp32 MFMA)",
-                                                   PEAK_F32_MFMA_TFLOPS, "conv_wgrad_taps_kernel")
-            def hbm_entry(kk, desc, knames):
-                ach = kk["flops"] / (kk["total_ms"] * 1e-3) / 1e9
-                parts = [_profiled_traffic(k) for k in knames]
-                traffic = None
-                if all(parts):
-                    traffic = {"hbm_bytes_per_launch": sum(t["hbm_bytes_per_launch"] for t in parts), "source": parts[0]["source"]}
-                return {"kernel": desc, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
-                        "launches_per_step": kk["launches"] // args.steps,
-                        "avg_launch_us": round(1000.0 * kk["total_ms"] / kk["launches"], 2),
-                        "mb_per_launch": round(kk["flops"] / kk["launches"] / 1e6, 2),
-                        "share_of_serial_step": round(kk["total_ms"] / (1000.0 * serial_elapsed), 3)}
-            if "bn_fwd" in summ:
-                line["roofline_bn_fwd"] = hbm_entry(summ["bn_fwd"], "bn_act_fwd_kernel (normalise + residual + activation + mask bytes; "
-                                                    "algorithmic bytes = conv output read, [residual read,] activation written, 1 mask byte per 4 channels)", ["bn_act_fwd_kernel"])
-            if "bn_bwd" in summ:
-                line["roofline_bn_bwd"] = hbm_entry(summ["bn_bwd"], "bn_bwd_reduce_kernel + bn_bwd_apply_kernel (one C-ABI call; algorithmic bytes = dz, conv "
-                                                    "output and mask read once, dy [and the residual gradient] written once -- the two-pass "
-                                                    "reduction reads dz and the conv output twice, so 3/5 of the HBM peak is this pair's ceiling)",
-                                                    ["bn_bwd_reduce_kernel", "bn_bwd_apply_kernel"])
+        for k in ("roofline", "roofline_wgrad", "roofline_other_convs", "roofline_bn_fwd", "roofline_bn_bwd", "roofline_error", "frontend", "whole_step"):
+            if k in head:
+                line[k] = head[k]
+        line["modes"] = results
         if fwd_only is not None:
             line["forward_only"] = fwd_only
-        # whole step against the planning roofs of SURVEY.md 8(d): 456.9 GFLOP and 3 x 0.671 GB algorithmic per image, fwd+bwd
-        per_gpu = line["value"] / world
-        line["whole_step"] = {"algorithmic_tflops": round(0.4569 * per_gpu, 1), "fp32_mfma_peak_tflops": PEAK_F32_MFMA_TFLOPS,
-                              "frac_of_fp32_mfma_peak": round(0.4569 * per_gpu / PEAK_F32_MFMA_TFLOPS, 3),
-                              "algorithmic_hbm_gbs": round(3 * 0.671 * per_gpu, 1),
-                              "note": "per GPU; the split-precision modes run the products on the 16-bit MFMA pipes, so the fp32-MFMA roof (340 img/s) is not their ceiling"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()
@@ -269,6 +294,87 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# Front-end / loss / optimiser kernels (HBM or gather-latency bound): timer kind -> description
+FRONTEND_KINDS = {
+    "fe_gaze_lowres": "gaze_lowres_kernel (K1: bilinear 1024^2 -> 80^2 taps + gaze map)",
+    "fe_area_pool": "area_pool_kernel (K3: label 1024^2 -> 80^2 area pooling, the only full-resolution pass)",
+    "fe_gauss_grid_fwd": "gauss_grid_fwd_kernel (K4: separable Gaussian saliency accumulation -> grid)",
+    "fe_gauss_grid_bwd": "gauss_grid_bwd_kernel",
+    "fe_grid_sample_fwd": "grid_sample_fwd_kernel (K5: foveated bilinear gather of the image)",
+    "fe_grid_sample_label": "grid_sample_label_kernel (K5: label gather + truncation)",
+    "fe_grid_sample_bwd_grid": "grid_sample_bwd_grid_kernel (K6: d loss / d grid)",
+    "fe_seg_loss_fwd": "seg_loss_fwd_kernel (K10/K11: Focal + Dice + accuracies over pred)",
+    "fe_seg_loss_bwd": "seg_loss_bwd_kernel",
+    "fe_adam": "adam_kernel (one launch per arena; 16 B read + 12 B written per parameter)",
+}
+
+
+def roofline_entries(mode, summ, nsteps, serial_elapsed):
+    tag, n_mfma, _bits, how = MODES[mode]
+    peak = mode_peak(mode)
+    out = {}
+
+    def entry(kk, desc, kname):
+        ach = kk["flops"] / (kk["total_ms"] * 1e-3) / 1e12
+        return {"kernel": desc, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": _profiled_traffic(kname),
+                "launches_per_step": kk["launches"] // nsteps,
+                "avg_launch_us": round(1000.0 * kk["total_ms"] / kk["launches"], 2),
+                "gflop_per_launch": round(kk["flops"] / kk["launches"] / 1e9, 3),
+                "share_of_serial_step": round(kk["total_ms"] / (1000.0 * serial_elapsed), 3)}
+
+    def hbm_entry(kk, desc, knames):
+        ach = kk["flops"] / (kk["total_ms"] * 1e-3) / 1e9
+        parts = [_profiled_traffic(k) for k in knames]
+        traffic = None
+        if all(parts):
+            traffic = {"hbm_bytes_per_launch": sum(t["hbm_bytes_per_launch"] for t in parts), "source": parts[0]["source"]}
+        return {"kernel": desc, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                "launches_per_step": kk["launches"] // nsteps,
+                "avg_launch_us": round(1000.0 * kk["total_ms"] / kk["launches"], 2),
+                "mb_per_launch": round(kk["flops"] / kk["launches"] / 1e6, 2),
+                "share_of_serial_step": round(kk["total_ms"] / (1000.0 * serial_elapsed), 3)}
+
+    if tag is not None and "conv3x3" in summ:
+        out["roofline"] = entry(
+            summ["conv3x3"],
+            f"conv3x3_halo_kernel<{tag}> (3x3 stride-1 forward + bwd-data, halo-tiled implicit GEMM; {how}; achieved = algorithmic fp32 FLOP/s "
+            "over the C-ABI call incl. its weight pack pre-kernel, peak = dense 16-bit MFMA peak / MFMAs per product)", "conv3x3_halo_kernel")
+        if "wgrad3x3" in summ:
+            out["roofline_wgrad"] = entry(summ["wgrad3x3"], f"conv_wgrad_class_kernel<{tag},3,3> (3x3 stride-1 bwd-weight, 9 taps per workgroup)",
+                                          f"conv_wgrad_class_kernel<fs_split::{tag}, 3, 3>")
+        if "conv_affine" in summ:
+            out["roofline_other_convs"] = entry(
+                summ["conv_affine"], f"conv_tapset_kernel<{tag}> (strided 3x3 forward + bwd-data sub-problems) + conv_igemm_split_kernel<{tag}> (1x1 convs "
+                                     "and single-tap sub-problems, HBM-bound at these channel counts)", f"conv_igemm_split_kernel<fs_split::{tag}>")
+    elif "conv_affine" in summ:
+        out["roofline"] = entry(summ["conv_affine"], "conv_igemm_affine_kernel<1> (fwd + bwd-data implicit GEMM, fp32 MFMA 32x32x2)", "conv_igemm_affine_kernel<1>")
+        if "conv_wgrad" in summ:
+            out["roofline_wgrad"] = entry(summ["conv_wgrad"], "conv_wgrad_taps_kernel<3|9> + conv_wgrad_kernel (bwd-weight, fp32 MFMA)", "conv_wgrad_taps_kernel")
+    if "roofline" in out:
+        out["roofline"]["serial_ms_per_step"] = round(1000.0 * serial_elapsed / nsteps, 2)
+        out["roofline"]["measured"] = "second pass of the same K steps with branch streams serialised, HIP events per launch on the launch stream"
+    if "bn_fwd" in summ:
+        out["roofline_bn_fwd"] = hbm_entry(summ["bn_fwd"], "BatchNorm apply + residual + activation forward (algorithmic bytes = conv output read, [residual read,] "
+                                           "activation written, 1 mask byte per 4 channels)", ["bn_act_fwd_kernel"])
+    if "bn_bwd" in summ:
+        out["roofline_bn_bwd"] = hbm_entry(summ["bn_bwd"], "BatchNorm + activation backward (one C-ABI call; algorithmic bytes = dz, conv output and mask read once, "
+                                           "dy [and the residual gradient] written once)", ["bn_bwd_reduce_kernel", "bn_bwd_apply_kernel"])
+    fe = {}
+    for kind, desc in FRONTEND_KINDS.items():
+        if kind in summ:
+            kk = summ[kind]
+            gbs = kk["flops"] / (kk["total_ms"] * 1e-3) / 1e9
+            fe[kind[3:]] = {"kernel": desc, "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4),
+                            "avg_launch_us": round(1000.0 * kk["total_ms"] / kk["launches"], 2), "mb_per_launch": round(kk["flops"] / kk["launches"] / 1e6, 3),
+                            "launches_per_step": kk["launches"] // nsteps}
+    if fe:
+        fe["note"] = "algorithmic bytes (SURVEY.md 8(d)): every operand element the kernel needs read once, every result written once; the gather kernels touch 4 taps per output"
+        out["frontend"] = fe
+    return out
 
 
 if __name__ == "__main__":

@@ -60,7 +60,7 @@ def lvis50_cfg() -> CfgNode:
         opt_deform_LabelEdge_softmax=False, edge_loss_scale=100.0, fixed_edge_loss_scale=-1.0,
         stage_adjust_edge_loss=1.0, deform_zero_bound=True, deform_zero_bound_factor=1,
         deform_pretrain_bol=True, deform_pretrain=100,
-        smooth_deform_2nd_start=2000, smooth_deform_2nd_end=2001,
+        smooth_deform_2nd_start=2001, smooth_deform_2nd_end=2001,
         fix_seg_start_epoch=2000, fix_seg_end_epoch=2001,
         fix_deform_aft_pretrain=False, fix_deform_start_epoch=2000, fix_deform_end_epoch=2001,
         def_saliency_pad_mode="replication", global_epoch=1,

@@ -984,7 +984,8 @@ long halo_pack_bytes(int Cs, int Cd) { return fs_halo_pack_bytes(g_conv_precisio
 bool use_halo(const ConvArgs& c) {
   return g_conv_precision >= 1 && c.ws_ != nullptr && fs_halo_eligible(c.Hd, c.Wd, c.Cs, c.Cd, c.R, c.S, c.stride, c.pad, c.dil) &&
          c.Hs == c.Hd && c.Ws == c.Wd && c.ws_bytes_ >= halo_pack_bytes(c.Cs, c.Cd) &&
-         (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL;      // 32-bit store offsets in the epilogue
+         (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL &&      // 32-bit store offsets in the epilogue
+         (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;        // 32-bit buffer offsets of the source (fs_halo_conv3x3 rejects larger)
 }
 
 // Everything else that is channel-aligned, undilated and has scratch goes to the tap-class kernel (conv_tapset.hip).
@@ -1002,7 +1003,15 @@ bool tapset_shape_ok(int Cs, int Cd, int R, int S, int stride, int dil) {
 long tapset_pack_bytes(int Cs, int Cd, int taps) { return fs_tapset_pack_bytes(g_conv_precision, Cs, Cd, taps); }
 bool use_tapset(const ConvArgs& c) {
   return g_conv_precision >= 1 && c.ws_ != nullptr && tapset_shape_ok(c.Cs, c.Cd, c.R, c.S, c.stride, c.dil) &&
-         c.ws_bytes_ >= tapset_pack_bytes(c.Cs, c.Cd, c.R * c.S) && (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL;
+         c.ws_bytes_ >= tapset_pack_bytes(c.Cs, c.Cd, c.R * c.S) && (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL &&
+         (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;        // the tap-class kernel addresses the source with 32-bit byte offsets too
+}
+
+// The channel-aligned kernels (plain / halo / tap-class) address the SOURCE tensor with 32-bit BYTE offsets into a raw buffer
+// resource (AffArgs::src_bytes), so the source must stay below 4 GB -- 2^30 elements, not 2^31; larger problems take the
+// 64-bit-indexed conv_igemm_kernel.
+bool aligned_ok(const ConvArgs& c) {
+  return c.Cs % 4 == 0 && c.Cd % 4 == 0 && c.R * c.S <= 32 && (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;
 }
 int run_tapset(const FsTapsetProblem& p, hipStream_t stream) { return fs_tapset_conv(g_conv_precision, p, stream); }
 FsTapsetProblem tapset_base(const ConvArgs& c) {
@@ -1121,6 +1130,23 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
   return need;
 }
 
+// include/fovealseg.h: fs_conv2d_kernel_choice -- which kernel family the conv entry points select for this problem under the current
+// precision mode and `ws_bytes` of scratch (host-side predicate, no launch; the dispatch below uses the same functions).
+// 0 = generic 64-bit-indexed kernel, 1 = plain aligned implicit GEMM, 2 = halo-tiled 3x3, 3 = tap-class kernel.
+int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                            int transposed, long ws_bytes) {
+  ConvArgs c{nullptr, nullptr, nullptr, nullptr, B, transposed ? Ho : H, transposed ? Wo : W, transposed ? Cout : Cin,
+             transposed ? H : Ho, transposed ? W : Wo, transposed ? Cin : Cout, R, S, stride, pad, dil, transposed, 1.f, 0u, 0u};
+  c.ws_ = ws_bytes > 0 ? (void*)&c : nullptr;
+  c.ws_bytes_ = ws_bytes;
+  if (!aligned_ok(c)) return 0;
+  if (!transposed && use_tapset(c) && (g_tapset_all || !use_halo(c))) return 3;
+  if (transposed && stride == 1 && use_tapset(c) && (g_tapset_all || !use_halo(c))) return 3;
+  if (use_halo(c)) return 2;
+  if (transposed && stride > 1 && use_tapset(c)) return 3;     // the multi-tap parity sub-problems
+  return 1;
+}
+
 // include/fovealseg.h: fs_conv2d_stats_slabs -- number of [Cout][2] partial-sum slabs fs_conv2d_fwd_stats writes for
 // this shape when called with ws_bytes of scratch (depends on which kernel it selects).
 int fs_conv2d_stats_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
@@ -1151,8 +1177,7 @@ int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, i
   }
   const long M = (long)B * Ho * Wo;
   FS_REQUIRE(M * Cout < 4294967296L);
-  if ((Cin % 4 == 0) && (Cout % 4 == 0) && R * S <= 32 && (long)B * H * W * Cin < 2147483647L)
-    return launch_affine(a, M);
+  if (aligned_ok(a)) return launch_affine(a, M);
   dim3 grid(cdiv(M, BM), cdiv(Cout, BN));
   if ((Cin % 4 == 0) && (Cout % 4 == 0))
     hipLaunchKernelGGL(conv_igemm_kernel<true>, grid, dim3(256), 0, stream, a);
@@ -1170,8 +1195,8 @@ int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float
   FS_REQUIRE(x && w && y && stats && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
   FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
   FS_REQUIRE(drop_p >= 0.f && drop_p < 1.f);
-  FS_REQUIRE((Cin % 4 == 0) && (Cout % 4 == 0) && R * S <= 32 && (long)B * H * W * Cin < 2147483647L);
   ConvArgs a{x, w, bias, y, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0, 1.f, 0u, drop_key};
+  FS_REQUIRE(aligned_ok(a));
   a.stream_ = stream;
   a.stats_ = stats;
   a.ws_ = ws; a.ws_bytes_ = ws_bytes; a.w_amax_ = w_amax;
@@ -1194,8 +1219,7 @@ int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H,
   const long M = (long)B * H * W;
   a.stream_ = stream;
   a.ws_ = ws; a.ws_bytes_ = ws_bytes; a.w_amax_ = w_amax;
-  if ((Cin % 4 == 0) && (Cout % 4 == 0) && R * S <= 32 && (long)B * Ho * Wo * Cout < 2147483647L)
-    return launch_affine(a, M);
+  if (aligned_ok(a)) return launch_affine(a, M);
   dim3 grid(cdiv(M, BM), cdiv(Cin, BN));
   if ((Cin % 4 == 0) && (Cout % 4 == 0))
     hipLaunchKernelGGL(conv_igemm_kernel<true>, grid, dim3(256), 0, stream, a);

@@ -73,7 +73,7 @@ _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 
 _lib = None
 # declared in the header, host-side only (no stream argument)
-HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs")
+HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice")
 
 
 class HipLibraryError(RuntimeError):
@@ -102,6 +102,8 @@ def load():
     lib.fs_conv2d_workspace_bytes.argtypes = [_I] * 12
     lib.fs_conv2d_stats_slabs.restype = _I
     lib.fs_conv2d_stats_slabs.argtypes = [_I] * 12 + [_L]
+    lib.fs_conv2d_kernel_choice.restype = _I
+    lib.fs_conv2d_kernel_choice.argtypes = [_I] * 13 + [_L]
     _lib = lib
     return lib
 

@@ -72,7 +72,10 @@ def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, act, res=None, drop_p=0.
                 drop_p=drop_p, drop_key=ops.DropoutState.key(layer_id) if (training and drop_p > 0) else 0,
                 running_mean=bn.running_mean, running_var=bn.running_var, num_batches_tracked=_NbtCounter(bn))
     x, w = ops.pad_in_channels(x, conv.weight)
-    return ops.ConvBnAct.apply(x, w, conv.bias, bn.weight, bn.bias, res, meta)
+    z = ops.ConvBnAct.apply(x, w, conv.bias, bn.weight, bn.bias, res, meta)
+    if ops.ACT_TRACE is not None and act != ACT_NONE:
+        ops.ACT_TRACE.append((bn, act, z))
+    return z
 
 
 PARALLEL_BRANCHES = True
@@ -261,6 +264,8 @@ class HighResolutionModule(nn.Module):
         for i in range(n):
             terms = [xs[j] if j == i else self.fuse_layers[i][j](xs[j]) for j in range(n)]
             outs.append(ops.HrFuse.apply(xs[i].shape[1], xs[i].shape[2], *terms))
+            if ops.ACT_TRACE is not None:
+                ops.ACT_TRACE.append(((self, i), ACT_RELU, outs[-1]))
         return outs
 
 

@@ -102,6 +102,9 @@ class KernelTimer:
 
 WGRAD_FIRST = os.environ.get("FS_WGRAD_FIRST", "1") != "0"      # kernel experiments: order of the two conv backward launches
 TIMER = None      # set to a KernelTimer by bench.py around the timed region
+# Parity-test instrument: when a list, every activation site appends (BatchNorm module | (HighResolutionModule, i), act kind,
+# activated output), so a test can replay the branch each activation took in the CPU oracle (oracle ACT_REPLAY).
+ACT_TRACE = None
 
 
 def _launch(kind, flops, name, *args):
@@ -602,8 +605,8 @@ class SegLoss(Function):
         accum = torch.empty(3 * K + 1 + 6 * B, device=pred.device, dtype=torch.float64)
         out = torch.empty(7, device=pred.device, dtype=torch.float32)
         coef = torch.empty(2 * K, device=pred.device, dtype=torch.float32)
-        hip.call("fs_seg_loss_fwd", hip.ptr(pred), hip.ptr(gt), B, K, H * W, float(gamma), 1e-7, hip.ptr(accum), hip.ptr(out),
-                 hip.ptr(coef))
+        _launch("fe_seg_loss_fwd", 4.0 * B * H * W * (K + 2), "fs_seg_loss_fwd", hip.ptr(pred), hip.ptr(gt), B, K, H * W, float(gamma), 1e-7, hip.ptr(accum), hip.ptr(out),
+                hip.ptr(coef))
         ctx.save_for_backward(pred, gt, coef)
         ctx.gamma = float(gamma)
         return out
@@ -614,7 +617,7 @@ class SegLoss(Function):
         B, K, H, W = pred.shape
         g0 = gout[0:1].contiguous()
         dpred = torch.empty_like(pred)
-        hip.call("fs_seg_loss_bwd", hip.ptr(pred), hip.ptr(gt), hip.ptr(coef), hip.ptr(g0), hip.ptr(dpred), B, K, H * W, ctx.gamma)
+        _launch("fe_seg_loss_bwd", 4.0 * B * H * W * (2 * K + 2), "fs_seg_loss_bwd", hip.ptr(pred), hip.ptr(gt), hip.ptr(coef), hip.ptr(g0), hip.ptr(dpred), B, K, H * W, ctx.gamma)
         return dpred, None, None
 
 
@@ -625,7 +628,7 @@ def gaze_lowres(x, focus, hs, ws):
     B, C, H, W = x.shape
     assert C == 3
     out = torch.empty(B, hs, ws, 5, device=x.device, dtype=torch.float32)
-    hip.call("fs_gaze_lowres_fwd", hip.ptr(x), hip.ptr(focus), hip.ptr(out), B, H, W, hs, ws)
+    _launch("fe_gaze_lowres", 4.0 * B * hs * ws * (4 * 3 + 5), "fs_gaze_lowres_fwd", hip.ptr(x), hip.ptr(focus), hip.ptr(out), B, H, W, hs, ws)
     return out
 
 
@@ -656,7 +659,7 @@ def area_pool(y, hs, ws):
     B, C, H, W = y.shape
     assert C == 1
     out = torch.empty(B, 1, hs, ws, device=y.device, dtype=torch.float32)
-    hip.call("fs_area_pool_fwd", hip.ptr(y), hip.ptr(out), B, H, W, hs, ws)
+    _launch("fe_area_pool", 4.0 * B * (H * W + hs * ws), "fs_area_pool_fwd", hip.ptr(y), hip.ptr(out), B, H, W, hs, ws)
     return out
 
 
@@ -686,7 +689,7 @@ class GaussGrid(Function):
     def forward(ctx, xs, g1d, pad):
         B, _, hs, ws = xs.shape
         grid = torch.empty(B, hs, ws, 2, device=xs.device, dtype=torch.float32)
-        hip.call("fs_gauss_grid_fwd", hip.ptr(xs), hip.ptr(g1d), hip.ptr(grid), B, hs, ws, pad)
+        _launch("fe_gauss_grid_fwd", 4.0 * B * hs * ws * 3, "fs_gauss_grid_fwd", hip.ptr(xs), hip.ptr(g1d), hip.ptr(grid), B, hs, ws, pad)
         ctx.save_for_backward(xs, g1d)
         ctx.pad = pad
         return grid
@@ -696,7 +699,7 @@ class GaussGrid(Function):
         xs, g1d = ctx.saved_tensors
         B, _, hs, ws = xs.shape
         dxs = torch.empty_like(xs)
-        hip.call("fs_gauss_grid_bwd", hip.ptr(xs), hip.ptr(g1d), hip.ptr(dgrid.contiguous()), hip.ptr(dxs), B, hs, ws, ctx.pad)
+        _launch("fe_gauss_grid_bwd", 4.0 * B * hs * ws * 4, "fs_gauss_grid_bwd", hip.ptr(xs), hip.ptr(g1d), hip.ptr(dgrid.contiguous()), hip.ptr(dxs), B, hs, ws, ctx.pad)
         return dxs, None, None
 
 
@@ -709,7 +712,7 @@ class GridSample(Function):
         B, C, H, W = x.shape
         _, h, w, _ = grid.shape
         out = torch.empty(B, h, w, C, device=x.device, dtype=torch.float32)
-        hip.call("fs_grid_sample_fwd", hip.ptr(x), hip.ptr(grid), hip.ptr(out), B, C, H, W, h, w, 1)
+        _launch("fe_grid_sample_fwd", 4.0 * B * h * w * (4 * C + 2 + C), "fs_grid_sample_fwd", hip.ptr(x), hip.ptr(grid), hip.ptr(out), B, C, H, W, h, w, 1)
         ctx.save_for_backward(x, grid)
         return out
 
@@ -722,7 +725,7 @@ class GridSample(Function):
         dx = dgrid = None
         if ctx.needs_input_grad[1]:
             dgrid = torch.empty_like(grid)
-            hip.call("fs_grid_sample_bwd_grid", hip.ptr(gout), hip.ptr(x), hip.ptr(grid), hip.ptr(dgrid), B, C, H, W, h, w, 1)
+            _launch("fe_grid_sample_bwd_grid", 4.0 * B * h * w * (4 * C + C + 2 + 2), "fs_grid_sample_bwd_grid", hip.ptr(gout), hip.ptr(x), hip.ptr(grid), hip.ptr(dgrid), B, C, H, W, h, w, 1)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             hip.call("fs_grid_sample_bwd_input", hip.ptr(gout), hip.ptr(grid), hip.ptr(dx), B, C, H, W, h, w, 1)
@@ -735,7 +738,7 @@ def grid_sample_label(y, grid, return_float=False):
     _, h, w, _ = grid.shape
     label = torch.empty(B, h, w, device=y.device, dtype=torch.int64)
     ys = torch.empty(B, h, w, device=y.device, dtype=torch.float32) if return_float else None
-    hip.call("fs_grid_sample_label", hip.ptr(y), hip.ptr(grid), hip.ptr(label), hip.ptr(ys), B, H, W, h, w)
+    _launch("fe_grid_sample_label", 4.0 * B * h * w * (4 + 2 + 2), "fs_grid_sample_label", hip.ptr(y), hip.ptr(grid), hip.ptr(label), hip.ptr(ys), B, H, W, h, w)
     return (label, ys) if return_float else label
 
 

@@ -84,6 +84,17 @@ class FlatParams:
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad.as_strided(tuple(p.shape), tuple(p.stride()), o)
 
+    def adopt_grads(self):
+        """Copy gradients that live outside the arena (a caller followed the reference loop's `module.zero_grad()`, so autograd
+        allocated fresh `.grad` tensors) into the arena and re-point `.grad` at the views."""
+        for p, o in zip(self.params, self.offsets):
+            view = self.grad.as_strided(tuple(p.shape), tuple(p.stride()), o)
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                view.copy_(p.grad)
+            p.grad = view
+
 
 class FlatAdam:
     """torch.optim.Adam(weight_decay) semantics over a FlatParams arena, one fused HIP launch."""
@@ -101,12 +112,24 @@ class FlatAdam:
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
 
+    def check_grads_in_arena(self):
+        """Every parameter's .grad must BE its slice of the gradient arena: the fused Adam kernel reads the arena only.  A caller
+        that dropped the views (module.zero_grad() sets .grad = None, autograd then allocates fresh tensors) would otherwise
+        step with zero gradients and weight decay alone, silently."""
+        base = self.flat.grad.data_ptr()
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            if p.grad is None or p.grad.data_ptr() != base + 4 * o:
+                raise RuntimeError("FlatAdam: a parameter's .grad is not its gradient-arena view (use optimizer.zero_grad(), not "
+                                   "module.zero_grad(); or call flat.adopt_grads() to copy stray gradients in)")
+
     def step(self):
         g = self.param_groups[0]
+        self.check_grads_in_arena()
         self.t += 1
-        hip.call("fs_adam_step", hip.ptr(self.flat.data), hip.ptr(self.flat.grad), hip.ptr(self.m), hip.ptr(self.v),
-                 self.flat.numel, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                 float(g["weight_decay"]), self.t, float(self.grad_scale))
+        from .ops import _launch
+        _launch("fe_adam", 28.0 * self.flat.numel, "fs_adam_step", hip.ptr(self.flat.data), hip.ptr(self.flat.grad), hip.ptr(self.m), hip.ptr(self.v),
+                self.flat.numel, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                float(g["weight_decay"]), self.t, float(self.grad_scale))
         self.flat.refresh_amax()
 
     def state_dict(self):
@@ -232,7 +255,15 @@ def train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=0):
     loss = out[0]
     loss.mean().backward()
     allreduce_gradients(optimizers)
-    for opt in optimizers:
+    T = cfg.TRAIN
+    for opt in optimizers:          # train_deform_semantic.py:112-120: which optimisers step in this epoch
+        zoom = opt.param_groups[0]["zoom"]
+        if T.fix_deform_aft_pretrain and T.fix_deform_start_epoch <= epoch <= T.fix_deform_end_epoch:
+            if zoom:                # deformation module frozen: its Adam state (t, m, v) must not advance either
+                continue
+        elif T.opt_deform_LabelEdge and T.fix_seg_start_epoch <= epoch <= T.fix_seg_end_epoch:
+            if not zoom:            # segmentation module frozen
+                continue
         opt.step()
     return out
 
@@ -345,7 +376,7 @@ def load_checkpoint(dirpath, epoch, nets, optimizers=None, strict=True):
             for o in optimizers:
                 o.flat.refresh_amax()
         return None
-    state = torch.load(path, map_location="cpu", weights_only=False)
+    state = torch.load(path, map_location="cpu", weights_only=True)      # plain tensors / numbers / strings only (see save_checkpoint)
     DropoutState.seed, DropoutState.step = state["dropout"]["seed"], state["dropout"]["step"]
     torch.set_rng_state(state["rng"])
     if optimizers is not None:

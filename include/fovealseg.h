@@ -74,10 +74,16 @@ int fs_fill_nearest(float* vals, const int* owner, int* scratch, int B, int C, i
 int fs_inverse_index_maps(const float* grid, long long* u, long long* v, long n, int H, int W, fs_stream_t stream);
 
 /* ---- convolution engine (implicit GEMM on the matrix cores) ------------------------------------ */
-/* Arithmetic of the aligned-channel forward / bwd-data kernel: 0 = fp32 MFMA (exact fp32 fma chain),
- * 1 = split precision "bf16x3": each fp32 operand is split into three bf16 terms (exact to 24 bits) and each
- * product is six bf16 MFMAs with fp32 accumulation (error at the fp32 rounding level, 2.7x fewer MFMA cycles).
- * Default 1 (or FS_CONV_PRECISION=f32|bf16x3 in the environment).  Host-side switch, not a launch. */
+/* Arithmetic of the channel-aligned conv kernels (fp32 tensors and fp32 accumulation in every mode):
+ *   0 "f32"    fp32 MFMA (v_mfma_f32_32x32x2_f32), one MFMA per product;
+ *   1 "bf16x3" each fp32 operand split into three bf16 terms (exact to 24 significand bits), six bf16 MFMAs per product;
+ *   2 "f16x2"  each operand scaled by a power of two and split into two fp16 terms (22-23 significand bits), three fp16
+ *              MFMAs per product.
+ * Default 2, or FS_CONV_PRECISION=f32|bf16x3|f16x2 in the environment at load time.
+ * This is the library's ONE piece of process-global mutable state (like a BLAS math-mode switch): a host-side word read by the
+ * conv entry points when they choose a kernel.  It is not a launch and is not ordered with streams; set it while no other
+ * thread is inside a conv entry point (the Python layer sets it once at start-up, the tests between cases).  Everything
+ * else the entry points need comes in through their arguments. */
 int fs_set_conv_precision(int mode);
 int fs_get_conv_precision(void);
 /* Scratch the forward (transposed=0) / bwd-data (transposed=1) entry points can use for this shape, in bytes
@@ -86,6 +92,12 @@ int fs_get_conv_precision(void);
  * scratch (ws = NULL) they fall back to the kernel that splits weights in flight.  Host-side query, no launch. */
 long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                                int transposed);
+/* Which kernel family fs_conv2d_fwd (transposed=0) / fs_conv2d_bwd_data (transposed=1) select for this problem under the
+ * current precision mode with ws_bytes of scratch: 0 = generic 64-bit-indexed implicit GEMM (any channel count, sources of
+ * 4 GB and more), 1 = plain channel-aligned implicit GEMM, 2 = halo-tiled 3x3 stride-1 kernel, 3 = tap-class kernel.  The
+ * aligned kernels address the source with 32-bit byte offsets, so they are chosen only below 4 GB.  Host-side predicate. */
+int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                            int transposed, long ws_bytes);
 /* Number of [Cout][2] partial-sum slabs fs_conv2d_fwd_stats writes for this shape given ws_bytes of scratch. */
 int fs_conv2d_stats_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                           long ws_bytes);

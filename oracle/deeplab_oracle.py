@@ -12,6 +12,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from fovealseg_oracle import ORelu, _relu, _site      # activation-replay test instrument (see fovealseg_oracle.ACT_REPLAY)
+
 
 class _Bottle(nn.Module):
     def __init__(self, inplanes, planes, stride, dilation, down):
@@ -25,10 +27,10 @@ class _Bottle(nn.Module):
         self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4)) if down else None
 
     def forward(self, x):
-        o = F.relu(self.bn1(self.conv1(x)))
-        o = F.relu(self.bn2(self.conv2(o)))
+        o = _relu(_site(self, "bn1"), self.bn1(self.conv1(x)))
+        o = _relu(_site(self, "bn2"), self.bn2(self.conv2(o)))
         o = self.bn3(self.conv3(o))
-        return F.relu(o + (x if self.downsample is None else self.downsample(x)))
+        return _relu(_site(self, "bn3"), o + (x if self.downsample is None else self.downsample(x)))
 
 
 class _Backbone(nn.Module):
@@ -54,18 +56,18 @@ class _Backbone(nn.Module):
         return nn.Sequential(*mods)
 
     def forward(self, x):
-        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, 2, 1)
+        x = F.max_pool2d(_relu(_site(self, "bn1"), self.bn1(self.conv1(x))), 3, 2, 1)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 
 class _ASPP(nn.Module):
     def __init__(self, cin, rates=(12, 24, 36), cout=256):
         super().__init__()
-        mods = [nn.Sequential(nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU())]
-        mods += [nn.Sequential(nn.Conv2d(cin, cout, 3, padding=r, dilation=r, bias=False), nn.BatchNorm2d(cout), nn.ReLU()) for r in rates]
-        mods.append(nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU()))
+        mods = [nn.Sequential(nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout), ORelu())]
+        mods += [nn.Sequential(nn.Conv2d(cin, cout, 3, padding=r, dilation=r, bias=False), nn.BatchNorm2d(cout), ORelu()) for r in rates]
+        mods.append(nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout), ORelu()))
         self.convs = nn.ModuleList(mods)
-        self.project = nn.Sequential(nn.Conv2d(len(mods) * cout, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(), nn.Dropout(0.5))
+        self.project = nn.Sequential(nn.Conv2d(len(mods) * cout, cout, 1, bias=False), nn.BatchNorm2d(cout), ORelu(), nn.Dropout(0.5))
 
     def forward(self, x, drop_fn=None):
         outs = [m(x) for m in self.convs[:-1]]
@@ -80,7 +82,7 @@ class _Net(nn.Module):
     def __init__(self, nc):
         super().__init__()
         self.backbone = _Backbone()
-        self.classifier = nn.Sequential(_ASPP(2048), nn.Conv2d(256, 512, 1), nn.BatchNorm2d(512), nn.ReLU(), nn.Conv2d(512, nc, 1))
+        self.classifier = nn.Sequential(_ASPP(2048), nn.Conv2d(256, 512, 1), nn.BatchNorm2d(512), ORelu(), nn.Conv2d(512, nc, 1))
 
 
 class OracleDeepLab(nn.Module):

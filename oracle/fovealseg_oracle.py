@@ -27,6 +27,49 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-5
 
+# --------------------------------------------------------------------------------------------
+# activation replay (test instrument): a ReLU's derivative is discontinuous at 0, so two correct fp32
+# evaluations of the same graph can disagree on the branch an activation within rounding of 0 takes,
+# and that one element moves its whole receptive field of gradients by O(1).  With ACT_REPLAY set to
+# {site name: bool tensor (NCHW) "the unit under test took the active branch"}, every activation site
+# below multiplies by that recorded mask instead of re-deciding the branch: the backward comparison is
+# then between two smooth functions (the same way Dropout masks are replayed through _Ctx.drop_fn).
+# Site names are module paths relative to the root given to assign_paths(): the BatchNorm that feeds
+# the activation ("...bn1", "conv1.1", "cbr.1"), or "<HRModule path>.fuse<i>" for the fuse sums.
+# --------------------------------------------------------------------------------------------
+ACT_REPLAY: Optional[Dict[str, torch.Tensor]] = None
+ACT_REPLAY_HI: Optional[Dict[str, torch.Tensor]] = None      # ReLU6 only: "saturated at 6" masks
+
+
+def assign_paths(root: nn.Module, prefix: str = "") -> None:
+    for name, m in root.named_modules():
+        m._opath = (prefix + "." + name).strip(".") if name else prefix
+
+
+def _site(mod: nn.Module, leaf: str) -> str:
+    base = getattr(mod, "_opath", "")
+    return (base + "." + leaf).strip(".")
+
+
+def _relu(name: str, t: torch.Tensor, six: bool = False) -> torch.Tensor:
+    if ACT_REPLAY is None or name not in ACT_REPLAY:
+        return F.relu6(t) if six else F.relu(t)
+    m = ACT_REPLAY[name].to(t.dtype)
+    if six:
+        hi = ACT_REPLAY_HI[name].to(t.dtype)
+        return t * m + 6.0 * hi
+    return t * m
+
+
+class ORelu(nn.Module):
+    """nn.ReLU as child i of a Sequential(..., bn, relu, ...): the site is named after child i-1, the BatchNorm in front of it."""
+
+    def forward(self, t):
+        base = getattr(self, "_opath", "")
+        head, _, leaf = base.rpartition(".")
+        name = (head + "." + str(int(leaf) - 1)).strip(".") if leaf.isdigit() else ""
+        return _relu(name, t)
+
 
 # --------------------------------------------------------------------------------------------
 # constants of DeformSegmentationModule.__init__
@@ -109,8 +152,8 @@ class OracleFovSim(nn.Module):
         self.norm3 = RefSyncBN(cout, momentum=0.1)
 
     def forward(self, x):
-        a = F.relu6(self.norm1(self.fov_expand_1(x)))
-        b = F.relu6(self.norm2(self.fov_expand_2(a)))
+        a = _relu(_site(self, "norm1"), self.norm1(self.fov_expand_1(x)), six=True)
+        b = _relu(_site(self, "norm2"), self.norm2(self.fov_expand_2(a)), six=True)
         return self.norm3(self.fov_squeeze_1(b))
 
 
@@ -158,9 +201,9 @@ class OBasic(nn.Module):
             if ctx.drop_fn is not None:
                 return ctx.drop_fn(path + "." + name, t)
             return F.dropout(t, 0.3, ctx.training)
-        o = F.relu(self.bn1(drop("conv1", self.conv1(x))))
+        o = _relu(_site(self, "bn1"), self.bn1(drop("conv1", self.conv1(x))))
         o = self.bn2(drop("conv2", self.conv2(o)))
-        return F.relu(o + x)
+        return _relu(_site(self, "bn2"), o + x)
 
 
 class OBottle(nn.Module):
@@ -177,11 +220,11 @@ class OBottle(nn.Module):
         self.downsample = nn.Sequential(_conv(cin, planes * 4, 1), RefSyncBN(planes * 4, 0.1)) if down else None
 
     def forward(self, x):
-        o = F.relu(self.bn1(self.conv1(x)))
-        o = F.relu(self.bn2(self.conv2(o)))
+        o = _relu(_site(self, "bn1"), self.bn1(self.conv1(x)))
+        o = _relu(_site(self, "bn2"), self.bn2(self.conv2(o)))
         o = self.bn3(self.conv3(o))
         r = x if self.downsample is None else self.downsample(x)
-        return F.relu(o + r)
+        return _relu(_site(self, "bn3"), o + r)
 
 
 class _Seq(nn.Sequential):
@@ -191,7 +234,7 @@ class _Seq(nn.Sequential):
 def _cb(cin, cout, k, s, relu):
     mods = [_conv(cin, cout, k, s), RefSyncBN(cout, 0.1)]
     if relu:
-        mods.append(nn.ReLU())
+        mods.append(ORelu())
     return nn.Sequential(*mods)
 
 
@@ -239,7 +282,7 @@ class OHRModule(nn.Module):
                                           mode="bilinear", align_corners=False)
                 else:
                     y = y + self.fuse_layers[i][j](xs[j])
-            out.append(F.relu(y))
+            out.append(_relu(_site(self, f"fuse{i}"), y))
         return out
 
 
@@ -266,8 +309,8 @@ class OracleHRNet(nn.Module):
 
     def forward(self, x, return_feature_maps=False, drop_fn: Optional[DropFn] = None):
         ctx = _Ctx(self.training, drop_fn)
-        x = F.relu(self.bn1(self.conv1(x)))
-        x = F.relu(self.bn2(self.conv2(x)))
+        x = _relu(_site(self, "bn1"), self.bn1(self.conv1(x)))
+        x = _relu(_site(self, "bn2"), self.bn2(self.conv2(x)))
         x = self.layer1(x)
         ys = [self.transition1[0](x), self.transition1[1](x)]
         for m, mod in enumerate(self.stage2):
@@ -291,12 +334,12 @@ class OResBlock(nn.Module):
 
     def __init__(self, cin, cout, stride):
         super().__init__()
-        self.conv1 = nn.Sequential(nn.Conv2d(cin, cout, 3, stride, 1), nn.BatchNorm2d(cout), nn.ReLU())
+        self.conv1 = nn.Sequential(nn.Conv2d(cin, cout, 3, stride, 1), nn.BatchNorm2d(cout), ORelu())
         self.conv2 = nn.Sequential(nn.Conv2d(cout, cout, 3, 1, 1), nn.BatchNorm2d(cout))
         self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride), nn.BatchNorm2d(cout))
 
     def forward(self, x):
-        return F.relu(self.conv2(self.conv1(x)) + self.downsample(x))
+        return _relu(_site(self, "conv2.1"), self.conv2(self.conv1(x)) + self.downsample(x))
 
 
 class OClsNet(nn.Module):
@@ -319,7 +362,7 @@ class OracleC1(nn.Module):
 
     def __init__(self, num_class=51, fc_dim=960):
         super().__init__()
-        self.cbr = nn.Sequential(_conv(fc_dim, fc_dim // 4, 3), RefSyncBN(fc_dim // 4, 0.001), nn.ReLU())
+        self.cbr = nn.Sequential(_conv(fc_dim, fc_dim // 4, 3), RefSyncBN(fc_dim // 4, 0.001), ORelu())
         self.conv_last = nn.Conv2d(fc_dim // 4, 1, 1)
         self.cls_net = OClsNet(fc_dim, num_class)
 

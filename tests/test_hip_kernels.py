@@ -34,28 +34,56 @@ def rsck_param(w):    # logical (Co,Ci,R,S) cpu -> device tensor with RSCK stora
     return p
 
 
-SPLIT = ("bf16x3", "f16x2")
-
-
-def relerr(a, b, prec=None):
-    """max |a-b| / max |b|.  In the split-precision modes (prec == 'bf16x3' / 'f16x2') the largest 3 % of the element
-    errors are ignored: the split-precision convs are as accurate as the fp32-MFMA one (tools/conv_accuracy.py: rms
-    2.7e-7..1.0e-6 vs 4.3e-7..1.6e-6 against fp64) but not bit-identical to it, so in blocks with ReLU an activation within ~1e-6 of
-    zero can take the other branch; that single element then changes its 3x3 neighbourhood of input gradients by
-    O(1), which a max-norm over a 2x20x20 test tensor would report as a failure of the whole tensor."""
+def relerr(a, b):
+    """max |a-b| / max |b| over ALL elements (no quantile, no per-mode allowance: the comparisons below are made
+    well-conditioned instead -- the branch every activation took on the device is replayed in the CPU oracle, the way
+    Dropout masks are, so both sides differentiate the same smooth function; see `replay`)."""
     a, b = a.double(), b.double()
-    d = (a - b).abs().flatten()
-    if prec in SPLIT and d.numel() >= 100:
-        d = d.kthvalue(max(1, int(0.97 * d.numel()))).values
-    else:
-        d = d.max()
-    return float(d / b.abs().max().clamp_min(1e-12))
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
-def wtol(prec, tol):
-    """Tolerance for quantities REDUCED over the pixels of a tiny test tensor (weight / affine gradients): one
-    ReLU-boundary flip (see relerr) moves every element of such a sum by ~1/sqrt(M) of its value."""
-    return 0.1 if prec in SPLIT else tol
+def rmsrel(a, b):
+    """||a-b||_2 / ||b||_2 (whole-tensor relative error of a gradient tensor)."""
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+class replay:
+    """with replay(root, trace): the oracle's activation sites take the branches recorded in `trace` (an ops.ACT_TRACE
+    list filled by a forward of the HIP module tree `root`; names are module paths relative to `root`)."""
+
+    def __init__(self, root, trace, prefix=""):
+        names = {id(m): n for n, m in root.named_modules()}
+        self.lo, self.hi = {}, {}
+        for key, act, z in trace:
+            if isinstance(key, tuple):
+                name = (names[id(key[0])] + f".fuse{key[1]}").strip(".")
+            else:
+                name = names[id(key)]
+            name = (prefix + "." + name).strip(".")
+            zc = nchw(z)
+            if act == 2:
+                self.lo[name], self.hi[name] = (zc > 0) & (zc < 6), zc >= 6
+            else:
+                self.lo[name] = zc > 0
+
+    def __enter__(self):
+        O.ACT_REPLAY, O.ACT_REPLAY_HI = self.lo, self.hi
+        return self
+
+    def __exit__(self, *exc):
+        O.ACT_REPLAY = O.ACT_REPLAY_HI = None
+
+
+class traced:
+    """with traced() as tr: HIP forwards append their activation outputs to tr."""
+
+    def __enter__(self):
+        ops.ACT_TRACE = []
+        return ops.ACT_TRACE
+
+    def __exit__(self, *exc):
+        ops.ACT_TRACE = None
 
 
 @pytest.fixture(params=["f32", "bf16x3", "f16x2"])
@@ -216,7 +244,26 @@ def test_conv_bn_act(training, act, use_res, drop, prec):
     res = torch.randn(B, C, H, W, generator=g) if use_res else None
     key = ops.layer_key(123, 456)
 
-    # ---- oracle side (torch CPU) ----
+    # ---- HIP side ----
+    xd = nhwc(x).requires_grad_(True)
+    wd = rsck_param(w).requires_grad_(True)
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    rd = nhwc(res).requires_grad_(True) if use_res else None
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    cot = torch.randn(B, C, H, W, generator=g)
+
+    class Cnt:
+        n = 0
+
+        def add_(self, k):
+            self.n += k
+    meta = dict(stride=1, pad=1, act=act, training=training, momentum=0.1, drop_p=drop, drop_key=key,
+                running_mean=rmd, running_var=rvd, num_batches_tracked=Cnt())
+    zd = ops.ConvBnAct.apply(xd, wd, None, gd, bd, rd, meta)
+    zd.backward(nhwc(cot))
+    zh = nchw(zd)
+
+    # ---- oracle side (torch CPU); the activation takes the branch the device took (see `replay`) ----
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     rr = res.clone().requires_grad_(True) if use_res else None
@@ -229,33 +276,19 @@ def test_conv_bn_act(training, act, use_res, drop, prec):
     z = F.batch_norm(y, rm_ref, rv_ref, gr, br, training, 0.1, 1e-5)
     if use_res:
         z = z + rr
-    z = F.relu(z) if act == 1 else (F.relu6(z) if act == 2 else z)
-    cot = torch.randn(z.shape, generator=g)
+    if act == 1:
+        z = z * (zh > 0).float()
+    elif act == 2:
+        z = z * ((zh > 0) & (zh < 6)).float() + 6.0 * (zh >= 6).float()
     z.backward(cot)
 
-    # ---- HIP side ----
-    xd = nhwc(x).requires_grad_(True)
-    wd = rsck_param(w).requires_grad_(True)
-    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
-    rd = nhwc(res).requires_grad_(True) if use_res else None
-    rmd, rvd = rm.to(DEV), rv.to(DEV)
-
-    class Cnt:
-        n = 0
-
-        def add_(self, k):
-            self.n += k
-    meta = dict(stride=1, pad=1, act=act, training=training, momentum=0.1, drop_p=drop, drop_key=key,
-                running_mean=rmd, running_var=rvd, num_batches_tracked=Cnt())
-    zd = ops.ConvBnAct.apply(xd, wd, None, gd, bd, rd, meta)
-    zd.backward(nhwc(cot))
-    assert relerr(nchw(zd), z.detach()) <= 2e-5
-    assert relerr(nchw(xd.grad), xr.grad, prec) <= 1e-4
-    assert relerr(wd.grad.cpu(), wr.grad) <= wtol(prec, 1e-4)
-    assert relerr(gd.grad.cpu(), gr.grad) <= wtol(prec, 1e-4)
-    assert relerr(bd.grad.cpu(), br.grad) <= wtol(prec, 1e-4)
+    assert relerr(zh, z.detach()) <= 2e-5
+    assert relerr(nchw(xd.grad), xr.grad) <= 1e-4
+    assert relerr(wd.grad.cpu(), wr.grad) <= 1e-4
+    assert relerr(gd.grad.cpu(), gr.grad) <= 1e-4
+    assert relerr(bd.grad.cpu(), br.grad) <= 1e-4
     if use_res:
-        assert relerr(nchw(rd.grad), rr.grad, prec) <= 1e-5
+        assert relerr(nchw(rd.grad), rr.grad) <= 1e-5
     if training:
         assert relerr(rmd.cpu(), rm_ref) <= 1e-5 and relerr(rvd.cpu(), rv_ref) <= 1e-5
         assert meta["num_batches_tracked"].n == 1
@@ -565,38 +598,69 @@ def _set_drop(m, p):
             d.drop_p = p
 
 
+@pytest.fixture(scope="module")
+def oracle():
+    o = O.OracleDeformSeg()
+    fovealseg.weights.apply_name_keyed_init(o)
+    O.assign_paths(o)
+    return o
+
+
+def _run_oracle_block(oblk, name, rel, ins, train):
+    ctx = O._Ctx(train, (lambda n, t: t) if train else None)       # Dropout(0.3) at p=0 in the goldens
+    if name == "basic":
+        return [oblk(ins[0], ctx, rel)]
+    if name == "bottleneck":
+        return [oblk(ins[0])]
+    return oblk(ins, ctx, rel)
+
+
+# One tolerance table for all three precision modes: with the activation branches replayed the backward is a
+# smooth function on both sides, so f16x2 / bf16x3 meet the same bounds as the fp32-MFMA mode.
+TOL_BLOCK_OUT, TOL_BLOCK_DIN, TOL_BLOCK_DW = 2e-5, 2e-4, 5e-4
+TOL_E2E_GRAD = 2e-3          # rms-relative, per parameter tensor, through the full depth of the network (fwd ~100 layers + bwd)
+
+
 @pytest.mark.parametrize("name", ["basic", "bottleneck", "hrmodule4"])
 @pytest.mark.parametrize("mode", ["eval", "train_p0"])
-def test_g7_blocks(golden, hipmod, name, mode, prec):
+def test_g7_blocks(golden, hipmod, oracle, name, mode, prec):
     g = golden(f"g7_{name}_{mode}")
+    prefix = str(g["prefix"])
     fovealseg.weights.apply_name_keyed_init(hipmod)
-    blk = _sub(hipmod, str(g["prefix"]))
+    fovealseg.weights.apply_name_keyed_init(oracle)
+    blk, oblk = _sub(hipmod, prefix), _sub(oracle, prefix)
     blk.train(mode != "eval")
+    oblk.train(mode != "eval")
     _set_drop(blk, 0.0)
     n_in = sum(1 for k in g.files if k.startswith("in"))
     ins = [nhwc(T(g[f"in{i}"])).requires_grad_(True) for i in range(n_in)]
-    outs = blk(ins[0]) if n_in == 1 else blk(ins)
+    with traced() as tr:
+        outs = blk(ins[0]) if n_in == 1 else blk(ins)
     outs = [outs] if isinstance(outs, torch.Tensor) else list(outs)
     blk.zero_grad()
     torch.autograd.backward(outs, [nhwc(T(g[f"cot{i}"])) for i in range(len(outs))])
-    for i, o in enumerate(outs):
+    for i, o in enumerate(outs):                          # forward: against the reference's own output
         ref = g[f"out{i}"]
-        assert np.abs(nchw(o).numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
-    # train mode + bf16x3: a boundary flip also shifts the batch means mean(g), mean(g*xhat) that BatchNorm's backward
-    # subtracts from EVERY element of that channel, so the whole tensor moves by ~1/M of the flipped value
-    tol_din = 1e-2 if (prec in SPLIT and mode != "eval") else 2e-4
+        assert np.abs(nchw(o).numpy() - ref).max() <= TOL_BLOCK_OUT * max(1.0, np.abs(ref).max())
+    # backward: against the oracle with the device's activation branches replayed (oracle pinned to these goldens on CPU)
+    oins = [T(g[f"in{i}"]).clone().requires_grad_(True) for i in range(n_in)]
+    with replay(hipmod, tr):
+        oouts = _run_oracle_block(oblk, name, prefix.split(".", 1)[1], oins, mode != "eval")
+        oblk.zero_grad()
+        sum((o * T(g[f"cot{i}"])).sum() for i, o in enumerate(oouts)).backward()
+    for i, o in enumerate(oouts):                         # the replay leaves the forward where the reference has it
+        ref = g[f"out{i}"]
+        assert np.abs(o.detach().numpy() - ref).max() <= TOL_BLOCK_OUT * max(1.0, np.abs(ref).max())
     for i, t in enumerate(ins):
-        assert relerr(nchw(t.grad), T(g[f"din{i}"]), prec) <= tol_din
-    params = dict(blk.named_parameters())
-    for k in g.files:
-        if k.startswith("dw:") or k.startswith("dgamma:"):
-            gr = params[k.split(":", 1)[1]].grad.cpu()
-            ref = g[k]
-            if gr.shape != ref.shape:
-                gr = gr[:16, :16]
-            assert np.abs(gr.numpy() - ref).max() <= wtol(prec, 5e-4) * max(1e-3, np.abs(ref).max()), k
+        assert relerr(nchw(t.grad), oins[i].grad) <= TOL_BLOCK_DIN, i
+        # and the replayed oracle stays close to the reference's own gradient (differs only where a branch flipped)
+        assert rmsrel(oins[i].grad, T(g[f"din{i}"])) <= 2e-2, i
+    params, oparams = dict(blk.named_parameters()), dict(oblk.named_parameters())
+    for k, p in params.items():                           # EVERY parameter gradient of the block
+        assert relerr(p.grad.cpu(), oparams[k].grad) <= TOL_BLOCK_DW, k
     _set_drop(blk, 0.3)
     fovealseg.weights.apply_name_keyed_init(hipmod)
+    fovealseg.weights.apply_name_keyed_init(oracle)
 
 
 def test_g8_hrnet_eval(golden, hipmod, prec):
@@ -613,28 +677,36 @@ def test_g8_hrnet_eval(golden, hipmod, prec):
 
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
-def test_g9_c1(golden, hipmod, mode, prec):
+def test_g9_c1(golden, hipmod, oracle, mode, prec):
     g = golden(f"g9_c1_{mode}")
     fovealseg.weights.apply_name_keyed_init(hipmod)
+    fovealseg.weights.apply_name_keyed_init(oracle)
     hipmod.decoder.train(mode == "train")
+    oracle.decoder.train(mode == "train")
     gg = torch.Generator().manual_seed(int(g["seed"]))
     f9 = torch.randn(2, 960, 80, 80, generator=gg) * 0.5
     fd = f9.to(DEV).requires_grad_(True)
-    pred = hipmod.decoder([fd])
+    with traced() as tr:
+        pred = hipmod.decoder([fd])
     cot = torch.randn(pred.shape, generator=gg) * 0.01
     hipmod.decoder.zero_grad()
     pred.backward(cot.to(DEV))
     p = pred.detach().cpu()
-    assert np.abs(p[:, :50, 0, 0].numpy() - g["pred_ch0"]).max() <= 2e-5
+    assert np.abs(p[:, :50, 0, 0].numpy() - g["pred_ch0"]).max() <= 2e-5          # the reference's own outputs
     assert np.abs(p[:, 50].numpy() - g["pred_last"]).max() <= 2e-5
-    assert relerr(fd.grad.cpu()[:, ::60, 20:36, 20:36], T(g["dfeat_crop"]), prec) <= 2e-4
-    ref = g["dfc"]
-    assert np.abs(hipmod.decoder.cls_net.fc.weight.grad.cpu().numpy() - ref).max() <= wtol(prec, 2e-4) * np.abs(ref).max()
-    ref = g["dw_conv_last"]
-    assert np.abs(hipmod.decoder.conv_last.weight.grad.cpu().numpy() - ref).max() <= wtol(prec, 2e-4) * np.abs(ref).max()
-    ref = g["dcbr_crop"]
-    assert np.abs(hipmod.decoder.cbr[0].weight.grad.cpu()[:8, :8].numpy() - ref).max() <= wtol(prec, 5e-4) * np.abs(ref).max()
+    fr = f9.clone().requires_grad_(True)
+    with replay(hipmod, tr):
+        opred = oracle.decoder([fr])
+        oracle.decoder.zero_grad()
+        (opred * cot).sum().backward()
+    assert np.abs(opred[:, :50, 0, 0].detach().numpy() - g["pred_ch0"]).max() <= 2e-5
+    assert relerr(fd.grad.cpu(), fr.grad) <= 2e-4
+    assert rmsrel(fr.grad[:, ::60, 20:36, 20:36], T(g["dfeat_crop"])) <= 2e-2     # replayed oracle vs the reference's gradient
+    po = dict(oracle.decoder.named_parameters())
+    for k, q in hipmod.decoder.named_parameters():        # every decoder parameter
+        assert relerr(q.grad.cpu(), po[k].grad) <= 5e-4, k
     fovealseg.weights.apply_name_keyed_init(hipmod)
+    fovealseg.weights.apply_name_keyed_init(oracle)
 
 
 class _InjectValue(torch.autograd.Function):
@@ -654,7 +726,7 @@ def _feed(g):
             "cls_label": T(g["cls"]).to(DEV)}
 
 
-def test_g11_end_to_end(golden, hipmod, prec):
+def test_g11_end_to_end(golden, hipmod, oracle, prec):
     """End to end against the reference run.  The reference's own fp32 grid is 1.75e-5 from the fp64
     value of its formula; a 1.5e-5 perturbation of the grid flips 0.2 % of the truncated
     labels and moves the reference's OWN gradient norms by up to 21 % (measured with the oracle), so
@@ -688,46 +760,70 @@ def test_g11_end_to_end(golden, hipmod, prec):
         assert abs(float(edge) - float(g["outs"][2])) <= 1e-5
         grid_free = hipmod.create_grid(hipmod.saliency(feed["img_data"], feed["focus_point"])[0]).detach().cpu().numpy()
         assert np.abs(grid_free - g["grid"]).max() <= 3e-5
-        # (b) reference grid injected
+        # (b) reference grid injected on both sides; the oracle replays the device's activation branches
         fovealseg.weights.apply_name_keyed_init(hipmod)
+        fovealseg.weights.apply_name_keyed_init(oracle)
         hipmod.train()
+        oracle.train()
         ref_grid = T(g["grid"]).to(DEV)
         orig = hipmod.create_grid
         hipmod.create_grid = lambda xs: _InjectValue.apply(orig(xs), ref_grid)
         try:
             feed = _feed(g)
             hipmod.zero_grad()
-            loss, acc, edge = hipmod(feed)
+            with traced() as tr:
+                loss, acc, edge = hipmod(feed)
             loss.mean().backward()
         finally:
             del hipmod.create_grid
         assert np.array_equal(feed["seg_label"].cpu().numpy(), g["label"])          # bit-exact label map
         got = np.array([float(loss), float(acc), float(edge)])
         assert np.abs(got - g["outs"]).max() <= 1e-4, (got, g["outs"])
-        params = dict(hipmod.named_parameters())
+        oorig = oracle.grid_from_saliency
+        oracle.grid_from_saliency = lambda xs: _InjectValue.apply(oorig(xs), T(g["grid"]))
+        try:
+            ofeed = {"img_data": T(g["x"]), "seg_label": T(g["y"]).clone(), "focus_point": T(g["focus"]), "cls_label": T(g["cls"])}
+            oracle.zero_grad()
+            with replay(hipmod, tr):
+                oloss, oacc, oedge = oracle(ofeed, drop_fn=lambda n, t: t)
+                oloss.backward()
+        finally:
+            del oracle.grid_from_saliency
+        assert abs(float(oloss) - float(g["outs"][0])) <= 1e-4
+        params, oparams = dict(hipmod.named_parameters()), dict(oracle.named_parameters())
+        worst = {}
+        for n, q in params.items():
+            if q.grad is None or n not in oparams or oparams[n].grad is None:
+                continue
+            e = rmsrel(q.grad.cpu(), oparams[n].grad)
+            grp = n.split(".")[0]
+            if e > worst.get(grp, ("", 0.0))[1]:
+                worst[grp] = (n, e)
+        print("g11 worst rms-relative gradient error per net", prec, worst)
+        # encoder + decoder: EVERY parameter-gradient tensor, one bound for all three modes.  The saliency side passes through
+        # the clamp mask of create_grid (ill-conditioned, see g4) and keeps the norm bound of round 1.
+        for grp in ("encoder", "decoder"):
+            assert worst[grp][1] <= TOL_E2E_GRAD, (prec, worst[grp])
         for n, ref in zip(g["gn_names"], g["gn"]):
-            gn = float(params[str(n)].grad.norm())
-            # saliency-side gradients pass through the clamp mask of create_grid (ill-conditioned, see g4).
-            # Backbone norms: the reference's own fp32 run is 4.0e-3 (encoder.conv1.weight) and 2.6e-3 (a stage-3
-            # BN weight) away from an fp64 evaluation of the same graph (measured with the oracle; the other
-            # listed tensors <= 4e-4), so the budget is 2e-3 for the fp32-MFMA path, which tracks the CPU's
-            # rounding closely, and 1.2e-2 for bf16x3, whose (equally small) rounding errors are independent.
-            tol = 5e-2 if (str(n).startswith("localization") or str(n).startswith("net_compress")) else \
-                (2e-3 if prec == "f32" else 1.2e-2)
-            assert abs(gn - float(ref)) <= tol * max(abs(float(ref)), 1e-6), (n, gn, ref)
+            if str(n).startswith("localization") or str(n).startswith("net_compress"):
+                gn = float(params[str(n)].grad.norm())
+                assert abs(gn - float(ref)) <= 5e-2 * max(abs(float(ref)), 1e-6), (n, gn, ref)
+            else:                                                                  # replayed oracle vs the reference's own norms
+                gn = float(oparams[str(n)].grad.norm())
+                assert abs(gn - float(ref)) <= 2e-2 * max(abs(float(ref)), 1e-6), (n, gn, ref)
     finally:
         _set_drop(hipmod, 0.3)
         fovealseg.weights.apply_name_keyed_init(hipmod)
+        fovealseg.weights.apply_name_keyed_init(oracle)
 
 
-def test_dropout_replay_basic_block(hipmod, prec):
-    """Train-mode BasicBlock with Dropout(0.3): the kernel's hash mask replayed in the oracle."""
+def test_dropout_replay_basic_block(hipmod, oracle, prec):
+    """Train-mode BasicBlock with Dropout(0.3): the kernel's hash mask AND its activation branches replayed in the oracle."""
     fovealseg.weights.apply_name_keyed_init(hipmod)
-    o = O.OracleDeformSeg()
-    fovealseg.weights.apply_name_keyed_init(o)
+    fovealseg.weights.apply_name_keyed_init(oracle)
     path = "stage3.1.branches.1.2"
     blk = _sub(hipmod.encoder, path).train()
-    oblk = _sub(o.encoder, path).train()
+    oblk = _sub(oracle.encoder, path).train()
     ops.DropoutState.seed, ops.DropoutState.step = 5, 17
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 128, 10, 10, generator=g)
@@ -737,17 +833,92 @@ def test_dropout_replay_basic_block(hipmod, prec):
         key = ops.DropoutState.key(ops.layer_id_from_name(name))
         keep = O.dropout_keep_mask_nhwc(t.numel(), key, 0.3).reshape(B, H, W, C)
         return t * torch.from_numpy(keep).permute(0, 3, 1, 2).float() * np.float32(1.0 / 0.7)
-    xr = x.clone().requires_grad_(True)
-    ref = oblk(xr, O._Ctx(True, drop_fn), path)
-    cot = torch.randn(ref.shape, generator=g)
-    ref.backward(cot)
     xd = nhwc(x).requires_grad_(True)
-    out = blk(xd)
+    with traced() as tr:
+        out = blk(xd)
+    cot = torch.randn(2, 128, 10, 10, generator=g)
+    blk.zero_grad()
     out.backward(nhwc(cot))
-    assert relerr(nchw(out), ref.detach()) <= 2e-5
-    assert relerr(nchw(xd.grad), xr.grad, prec) <= 2e-4
+    xr = x.clone().requires_grad_(True)
+    with replay(hipmod, tr):
+        ref = oblk(xr, O._Ctx(True, drop_fn), path)
+        oblk.zero_grad()
+        ref.backward(cot)
+    assert relerr(nchw(out), ref.detach()) <= TOL_BLOCK_OUT
+    assert relerr(nchw(xd.grad), xr.grad) <= TOL_BLOCK_DIN
+    po = dict(oblk.named_parameters())
+    for k, q in blk.named_parameters():
+        assert relerr(q.grad.cpu(), po[k].grad) <= TOL_BLOCK_DW, k
     frac = float((nchw(out) == 0).float().mean())
     assert 0.0 < frac < 1.0
+
+
+# ------------------------------------------------------------------------------------------------
+# full depth at the bench shape: HRNetV2 + C1 + Dice/Focal, train mode, B = 64 at 80x80, every precision mode
+# ------------------------------------------------------------------------------------------------
+FULL_DEPTH_LOGIT_TOL = 1e-4       # north_star: "fp32 logits within 1e-4"
+FULL_DEPTH_GRAD_TOL = 2e-3        # rms-relative per parameter-gradient tensor, the same for f32 / bf16x3 / f16x2
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
+def test_full_depth_b64_modes(hipmod, oracle, mode):
+    """VERDICT r1 "next" #1: the claim that the split-precision conv modes sit at the fp32 error level, as a test at FULL DEPTH
+    and at the BENCH batch: encoder (HRNetV2-nodownsp, ~300 conv+BN layers) -> C1 -> Dice+Focal, train mode (batch
+    statistics; Dropout at p = 0), B = 64, 80x80, forward and backward, against the CPU oracle with the device's activation
+    branches replayed: logits <= 1e-4, and EVERY parameter-gradient tensor of encoder and decoder within one rms-relative
+    bound that does not depend on the mode."""
+    B = 64
+    gen = torch.Generator().manual_seed(64)
+    x = torch.rand(B, 3, 80, 80, generator=gen)
+    cls = torch.randint(0, 50, (B, 1, 1), generator=gen)
+    ii = torch.arange(80, dtype=torch.float32)
+    c = torch.rand(B, 2, generator=gen) * 60 + 10
+    disc = ((ii[None, :, None] - c[:, 0, None, None]) ** 2 + (ii[None, None, :] - c[:, 1, None, None]) ** 2) <= 15.0 ** 2
+    gt = torch.where(disc, cls.expand(B, 80, 80), torch.full((B, 80, 80), 50))
+    fovealseg.hip.set_conv_precision(mode)
+    try:
+        fovealseg.weights.apply_name_keyed_init(hipmod)
+        fovealseg.weights.apply_name_keyed_init(oracle)
+        hipmod.train()
+        oracle.train()
+        _set_drop(hipmod, 0.0)
+        hipmod.zero_grad()
+        with traced() as tr:
+            feat = hipmod.encoder.forward_nhwc(nhwc(x))
+            pred = hipmod.decoder.forward_nhwc(feat)
+        loss = ops.SegLoss.apply(pred, gt.to(DEV), 5.0)[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        rp = replay(hipmod, tr)
+        del tr, feat
+        oracle.zero_grad()
+        with rp:
+            opred = oracle.decoder(oracle.encoder(x, return_feature_maps=True, drop_fn=lambda n, t: t))
+            oloss = O.dice_loss_multiclass(opred, gt) + O.focal_loss(opred, gt)
+            oloss.backward()
+        pd = pred.detach().cpu()
+        err_logit = float((pd - opred.detach()).abs().max() / max(1.0, float(opred.detach().abs().max())))
+        assert abs(float(loss) - float(oloss)) <= 1e-5 * max(1.0, abs(float(oloss)))
+        po = dict(oracle.named_parameters())
+        errs = {}
+        for n, q in hipmod.named_parameters():
+            if n.startswith("encoder.") or n.startswith("decoder."):
+                if ".cls_net.layer" in n and n.endswith(".0.bias"):
+                    # a conv bias in front of a batch-statistics BatchNorm: analytically zero gradient, both sides hold rounding noise
+                    assert float(q.grad.norm()) <= 1e-4 * float(dict(hipmod.named_parameters())[n[:-4] + "weight"].grad.norm()), n
+                    continue
+                errs[n] = rmsrel(q.grad.cpu(), po[n].grad)
+        worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+        med = float(np.median(list(errs.values())))
+        print(f"full depth B=64 {mode}: logits {err_logit:.2e}; {len(errs)} gradient tensors, rms-rel median {med:.2e}, worst {worst}")
+        assert err_logit <= FULL_DEPTH_LOGIT_TOL, err_logit
+        assert worst[0][1] <= FULL_DEPTH_GRAD_TOL, worst
+    finally:
+        fovealseg.hip.set_conv_precision("f16x2")
+        _set_drop(hipmod, 0.3)
+        hipmod.zero_grad(set_to_none=True)
+        fovealseg.weights.apply_name_keyed_init(hipmod)
+        fovealseg.weights.apply_name_keyed_init(oracle)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -875,32 +1046,38 @@ def test_deeplab_encoder_vs_oracle(mode, prec):
         key = ops.DropoutState.key(ops.layer_id_from_name("deeplab.classifier.0.project.3"))
         keep = O.dropout_keep_mask_nhwc(t.numel(), key, 0.5).reshape(B, H, W, C)
         return t * torch.from_numpy(keep).permute(0, 3, 1, 2).float() * 2.0
-    xr = x.clone().requires_grad_(True)
-    ref = o(xr, drop_fn=drop_fn)[0]
-    cot = torch.randn(ref.shape, generator=g) * 0.01
-    o.zero_grad()
-    ref.backward(cot)
+    O.assign_paths(o)
     xd = x.to(DEV).requires_grad_(True)
-    out = m(xd)[0]
+    with traced() as tr:
+        out = m(xd)[0]
     assert out.shape == (4, 960, 80, 80)
+    cot = torch.randn(out.shape, generator=g) * 0.01
     m.zero_grad()
     out.backward(cot.to(DEV))
+    xr = x.clone().requires_grad_(True)
+    with replay(m, tr):                   # the oracle takes the activation branches the device took
+        ref = o(xr, drop_fn=drop_fn)[0]
+        o.zero_grad()
+        ref.backward(cot)
     # train mode at B=4 normalises the ASPP image-pooling branch over FOUR samples (and 10x10 maps over 400):
-    # batch statistics of so few values amplify rounding differences, hence the looser train tolerances; the
-    # pooling-branch conv gradient (BatchNorm over 4 values, analytically near-cancelling) is checked in eval only
-    # (measured: the oracle's own fp32 and fp64 runs differ by 7e-4 in the output and 5-13 % in these gradients
-    #  in train mode -- ~100 stacked batch-stat BNs over 400 samples are chaotic; tight train-mode checks are
-    #  done per block in test_deeplab_blocks_train)
-    tol_out, tol_grad = (1e-4, 2e-3) if mode == "eval" else (2e-3, 0.25)
+    # batch statistics of so few values amplify rounding differences (the oracle's own fp32 and fp64 runs differ by 7e-4 in
+    # the output in train mode), hence the looser train tolerances; the pooling-branch conv gradient (BatchNorm over 4
+    # values, analytically near-cancelling) is checked in eval only; tight train-mode checks per block: test_deeplab_blocks_train
+    tol_out, tol_grad = (1e-4, 2e-3) if mode == "eval" else (2e-3, DEEPLAB_TRAIN_GRAD_TOL)
     assert relerr(out.detach().cpu(), ref.detach()) <= tol_out
-    assert relerr(xd.grad.cpu(), xr.grad, prec) <= tol_grad
+    print("deeplab", mode, prec, "dx", relerr(xd.grad.cpu(), xr.grad))
+    assert relerr(xd.grad.cpu(), xr.grad) <= tol_grad
     po, pm = dict(o.named_parameters()), dict(m.named_parameters())
     for k in ("deeplab.backbone.conv1.weight", "deeplab.backbone.layer3.7.conv2.weight", "deeplab.classifier.0.convs.2.0.weight",
               "deeplab.classifier.0.convs.4.1.weight", "deeplab.classifier.4.bias", "deeplab.classifier.1.weight",
               "deeplab.backbone.layer4.2.bn3.weight"):
         if mode == "train" and "convs.4" in k:
             continue
-        assert relerr(pm[k].grad.cpu(), po[k].grad, prec) <= max(tol_grad, wtol(prec, tol_grad) if mode == "eval" else tol_grad), k
+        print("deeplab", mode, prec, k, relerr(pm[k].grad.cpu(), po[k].grad))
+        assert relerr(pm[k].grad.cpu(), po[k].grad) <= tol_grad, k
+
+
+DEEPLAB_TRAIN_GRAD_TOL = 0.25
 
 
 def test_deeplab_blocks_train(prec):
@@ -917,20 +1094,25 @@ def test_deeplab_blocks_train(prec):
     m.train()
     g = torch.Generator().manual_seed(29)
     # dilated bottleneck (layer3[7]: dilation 2)
+    O.assign_paths(o)
     x = torch.randn(2, 1024, 10, 10, generator=g)
-    xr = x.clone().requires_grad_(True)
     ob, mb = o.deeplab.backbone.layer3[7], m.deeplab.backbone.layer3[7]
-    ref = ob(xr)
-    cot = torch.randn(ref.shape, generator=g)
-    ob.zero_grad()
-    ref.backward(cot)
     xd = nhwc(x).requires_grad_(True)
-    out = mb(xd)
+    with traced() as tr:
+        out = mb(xd)
+    cot = torch.randn(2, 1024, 10, 10, generator=g)
     mb.zero_grad()
     out.backward(nhwc(cot))
+    xr = x.clone().requires_grad_(True)
+    with replay(m, tr):
+        ref = ob(xr)
+        ob.zero_grad()
+        ref.backward(cot)
     assert relerr(nchw(out), ref.detach()) <= 2e-5
-    assert relerr(nchw(xd.grad), xr.grad, prec) <= 2e-4
-    assert relerr(mb.conv2.weight.grad.cpu(), ob.conv2.weight.grad) <= wtol(prec, 5e-4)
+    assert relerr(nchw(xd.grad), xr.grad) <= 2e-4
+    pob = dict(ob.named_parameters())
+    for k, q in mb.named_parameters():
+        assert relerr(q.grad.cpu(), pob[k].grad) <= 5e-4, k
     # ASPP head; the image-pooling BN normalises over B values only -> kept in eval mode on both sides
     oh, mh = o.deeplab.classifier, m.deeplab.classifier
     oh[0].convs[4][2].eval()
@@ -944,14 +1126,16 @@ def test_deeplab_blocks_train(prec):
         key = ops.DropoutState.key(ops.layer_id_from_name("deeplab.classifier.0.project.3"))
         keep = O.dropout_keep_mask_nhwc(t.numel(), key, 0.5).reshape(B, H, W, C)
         return t * torch.from_numpy(keep).permute(0, 3, 1, 2).float() * 2.0
-    ref = oh[4](oh[3](oh[2](oh[1](oh[0](fr, drop_fn)))))
-    cot = torch.randn(ref.shape, generator=g) * 0.1
-    oh.zero_grad()
-    ref.backward(cot)
     fd = nhwc(f).requires_grad_(True)
-    out = mh(fd)
+    with traced() as tr:
+        out = mh(fd)
+    cot = torch.randn(4, out.shape[3], 10, 10, generator=g) * 0.1
     mh.zero_grad()
     out.backward(nhwc(cot))
+    with replay(m, tr):
+        ref = oh[4](oh[3](oh[2](oh[1](oh[0](fr, drop_fn)))))
+        oh.zero_grad()
+        ref.backward(cot)
     assert relerr(nchw(out), ref.detach()) <= 5e-5
     assert relerr(nchw(fd.grad), fr.grad) <= 1e-3
     # ("1.bias" is omitted: a conv bias in front of a batch-stat BN has an analytically zero gradient)
