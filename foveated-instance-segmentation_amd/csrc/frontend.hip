@@ -712,6 +712,67 @@ __global__ __launch_bounds__(256) void ingest_sample_kernel(const unsigned char*
   if (Y != nullptr) Y[idx] = in ? (float)mask[(long)sy * W + sx] : 0.f;
 }
 
+// ---- grid up-sampling: nn.Upsample(size=task_input_size, mode='bilinear') of the (B,2,hs,ws) deformation grid when the task
+// network runs at a higher resolution than the saliency map (models/models.py:621-631; BASELINE configs[3]: 80x80 -> 160x160).
+// grid (B,h,w,2) -> out (B,H,W,2), ATen upsample_bilinear2d, align_corners=False.
+struct GLerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ GLerp glerp(int d, int in, int out) {
+  GLerp L;
+  if (in == out) { L.i0 = d; L.i1 = d; L.l0 = 1.f; L.l1 = 0.f; return L; }
+  const float scale = (float)in / (float)out;
+  float s = scale * ((float)d + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  L.i0 = (int)s;
+  L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
+  L.l1 = s - (float)L.i0;
+  L.l0 = 1.f - L.l1;
+  return L;
+}
+__global__ __launch_bounds__(256) void grid_upsample_fwd_kernel(const float2* __restrict__ grid, float2* __restrict__ out, int B, int h, int w,
+                                                                int H, int W) {
+  const long total = (long)B * H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ox = (int)(i % W), oy = (int)((i / W) % H), b = (int)(i / ((long)W * H));
+    const GLerp Ly = glerp(oy, h, H), Lx = glerp(ox, w, W);
+    const float2* base = grid + (long)b * h * w;
+    const float2 v00 = base[(long)Ly.i0 * w + Lx.i0], v01 = base[(long)Ly.i0 * w + Lx.i1];
+    const float2 v10 = base[(long)Ly.i1 * w + Lx.i0], v11 = base[(long)Ly.i1 * w + Lx.i1];
+    float2 r;
+    r.x = Ly.l0 * (Lx.l0 * v00.x + Lx.l1 * v01.x) + Ly.l1 * (Lx.l0 * v10.x + Lx.l1 * v11.x);
+    r.y = Ly.l0 * (Lx.l0 * v00.y + Lx.l1 * v01.y) + Ly.l1 * (Lx.l0 * v10.y + Lx.l1 * v11.y);
+    out[i] = r;
+  }
+}
+// transpose as a gather (integer factors): every source point sums the output pixels whose 2x2 footprint touches it
+__global__ __launch_bounds__(256) void grid_upsample_bwd_kernel(const float2* __restrict__ g, float2* __restrict__ dgrid, int B, int h, int w,
+                                                                int H, int W) {
+  const long total = (long)B * h * w;
+  const int fy = H / h, fx = W / w;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int qx = (int)(i % w), qy = (int)((i / w) % h), b = (int)(i / ((long)w * h));
+    int y_lo = fy * qy - fy / 2, y_hi = fy * qy + (3 * fy) / 2 - 1;
+    int x_lo = fx * qx - fx / 2, x_hi = fx * qx + (3 * fx) / 2 - 1;
+    if (y_lo < 0) y_lo = 0;
+    if (x_lo < 0) x_lo = 0;
+    if (y_hi > H - 1 || qy == h - 1) y_hi = H - 1;
+    if (x_hi > W - 1 || qx == w - 1) x_hi = W - 1;
+    float2 acc = {0.f, 0.f};
+    for (int oy = y_lo; oy <= y_hi; ++oy) {
+      const GLerp Ly = glerp(oy, h, H);
+      const float wy = (Ly.i0 == qy ? Ly.l0 : 0.f) + (Ly.i1 == qy ? Ly.l1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = x_lo; ox <= x_hi; ++ox) {
+        const GLerp Lx = glerp(ox, w, W);
+        const float wx = (Lx.i0 == qx ? Lx.l0 : 0.f) + (Lx.i1 == qx ? Lx.l1 : 0.f);
+        if (wx == 0.f) continue;
+        const float2 v = g[((long)b * H + oy) * W + ox];
+        acc.x += wy * wx * v.x; acc.y += wy * wx * v.y;
+      }
+    }
+    dgrid[i] = acc;
+  }
+}
+
 extern "C" {
 
 int fs_ingest_sample(const unsigned char* img, const unsigned char* mask, float* X, float* Y, int b, int H, int W, int Ci, int Cx,
@@ -794,6 +855,22 @@ int fs_gauss_grid_bwd(const float* xs, const double* g1d, const float* dgrid, fl
     attr_set = true;
   }
   hipLaunchKernelGGL(gauss_grid_bwd_kernel, dim3(B), dim3(1024), 5 * GMAX * sizeof(float), stream, xs, g1d, dgrid, dxs, hs, ws, pad);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// include/fovealseg.h: fs_grid_upsample_fwd / _bwd
+int fs_grid_upsample_fwd(const float* grid, float* out, int B, int h, int w, int H, int W, hipStream_t stream) {
+  FS_REQUIRE(grid && out && B > 0 && h > 0 && w > 0 && H >= h && W >= w);
+  hipLaunchKernelGGL(grid_upsample_fwd_kernel, dim3(cdiv((long)B * H * W, 256)), dim3(256), 0, stream, reinterpret_cast<const float2*>(grid),
+                     reinterpret_cast<float2*>(out), B, h, w, H, W);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+int fs_grid_upsample_bwd(const float* g, float* dgrid, int B, int h, int w, int H, int W, hipStream_t stream) {
+  FS_REQUIRE(g && dgrid && B > 0 && h > 0 && w > 0 && H >= h && W >= w && H % h == 0 && W % w == 0);      // integer factors
+  hipLaunchKernelGGL(grid_upsample_bwd_kernel, dim3(cdiv((long)B * h * w, 256)), dim3(256), 0, stream, reinterpret_cast<const float2*>(g),
+                     reinterpret_cast<float2*>(dgrid), B, h, w, H, W);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -195,146 +195,360 @@ __global__ __launch_bounds__(256) void residual_droppath_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------
-// Attention with a short key/value sequence (Nk <= 128 tokens after sequence reduction), head_dim 64.
-// One thread per query row; K and V of the (batch, head) live in LDS and are read as broadcasts.
-//   S = q.K^T * scale; P = softmax(S); P~ = dropout(P); O = P~ V;  lse saved for the backward.
-// q (B,N,heads*64), k/v (B,Nk,heads*64), o (B,N,heads*64)
+// Attention on the matrix cores, exact fp32: S = (q*scale) K^T, P = softmax(S), P~ = dropout(P), O = P~ V per (batch, head),
+// head_dim 64, any key count (the sequence-reduced keys of SegFormer: 100 at 80x80, 400 at 160x160), keys streamed through
+// LDS in chunks of 64 with an online softmax.  Products run on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: bit-for-bit
+// an fmaf chain), so the result sits at the same error level as the fp32 oracle.
+//
+// Operand maps of v_mfma_f32_32x32x2_f32 (cdna_hip_programming.md): lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]; result element (row = (reg&3) + 8*(reg>>2) + 4*(l>>5), col = l&31) in register reg.
+//   * "row-major operand" (Q, K, dO, V as the contraction-over-head-dim operand, P as the contraction-over-keys operand):
+//     lane (r, h) reads the float2 at [r][4j + 2h] -> the two MFMAs of step j contract k = 4j + 2h and 4j + 2h + 1.  Both
+//     operands of a product use the same map, so the permuted k order is harmless.  LDS rows are 66 floats: the 32 lanes of
+//     a ds_read_b64 group hit 32 distinct even banks.
+//   * "k-major operand" (V in P~V, K in dS K, dO / Q in the dK / dV products): lane (r, h) reads [k][32*dt + r], consecutive
+//     across the group.
+//   * dV = P~^T dO and dK = dS^T Q contract over the ROW index of the P~ / dS tiles, which is the register index of the
+//     accumulator layout: register i of lane (r, h) IS A[key r][query (i&3) + 8*(i>>2) + 4h], no transpose, no LDS.
+// q (B,N,heads*64), k/v (B,Nk,heads*64), o (B,N,heads*64); lse = B*heads*N floats.
 // ------------------------------------------------------------------------------------------
-constexpr int HD = 64, NKMAX = 128;
+constexpr int HD = 64, ALD = 66, KC = 64, QW = 32;
 
-__global__ __launch_bounds__(128) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                       const float* __restrict__ v, float* __restrict__ o, float* __restrict__ lse,
-                                                       int N, int Nk, int heads, float scale, float drop_scale, uint32_t thresh,
-                                                       uint32_t key) {
-  __shared__ float Ks[NKMAX * HD], Vs[NKMAX * HD];
-  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+__device__ __forceinline__ float half_max(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// LDS written by one lane of a wave and read by another lane of the SAME wave: order the accesses, no workgroup barrier
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// nrows x 64 floats (global rows `stride` floats apart, rows >= nvalid read as zero) -> LDS rows of ALD floats, times mul
+__device__ __forceinline__ void stage_rows(const float* __restrict__ src, long stride, int nvalid, float* lds, int nrows, int t, int nt, float mul) {
+  for (int i = t; i < nrows * 16; i += nt) {
+    const int rr = i >> 4, c4 = (i & 15) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (rr < nvalid) v = *reinterpret_cast<const f32x4*>(src + (long)rr * stride + c4) * mul;
+    float2* d = reinterpret_cast<float2*>(&lds[rr * ALD + c4]);
+    d[0] = float2{v.x, v.y};
+    d[1] = float2{v.z, v.w};
+  }
+}
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+__global__ __launch_bounds__(256, 2) void attn_mfma_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, float* __restrict__ o, float* __restrict__ lse,
+                                                            int N, int Nk, int heads, float scale, float drop_scale, uint32_t thresh,
+                                                            uint32_t key) {
+  __shared__ __attribute__((aligned(16))) float Ks[KC * ALD], Vs[KC * ALD], Ps[4][QW * ALD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
   const int C = heads * HD;
-  for (int i = threadIdx.x; i < Nk * (HD / 4); i += blockDim.x) {
-    const int j = i / (HD / 4), d = 4 * (i % (HD / 4));
-    *reinterpret_cast<f32x4*>(&Ks[j * HD + d]) = *reinterpret_cast<const f32x4*>(k + ((long)b * Nk + j) * C + h * HD + d);
-    *reinterpret_cast<f32x4*>(&Vs[j * HD + d]) = *reinterpret_cast<const f32x4*>(v + ((long)b * Nk + j) * C + h * HD + d);
+  const int q0 = blockIdx.x * 128 + wave * QW;
+  const float* qb = q + (long)b * N * C + hd * HD;
+  const float* kb = k + (long)b * Nk * C + hd * HD;
+  const float* vb = v + (long)b * Nk * C + hd * HD;
+  float* Pw = Ps[wave];
+  stage_rows(qb + (long)q0 * C, C, N - q0, Pw, QW, lane, 64, scale);
+  wave_sync();
+  float2 qa[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) qa[j] = *reinterpret_cast<const float2*>(&Pw[r * ALD + 4 * j + 2 * h]);
+  f32x16 O[2];
+  float m[16], l[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { O[0][i] = 0.f; O[1][i] = 0.f; m[i] = -INFINITY; l[i] = 0.f; }
+  const int nchunk = (Nk + KC - 1) / KC;
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();                           // every wave is done with the previous chunk (and with its Q staging)
+    stage_rows(kb + (long)c * KC * C, C, Nk - c * KC, Ks, KC, tid, 256, 1.f);
+    stage_rows(vb + (long)c * KC * C, C, Nk - c * KC, Vs, KC, tid, 256, 1.f);
+    __syncthreads();
+    f32x16 S[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float2 kf = *reinterpret_cast<const float2*>(&Ks[(32 * t + r) * ALD + 4 * j + 2 * h]);
+        S[t] = mfma32(qa[j].x, kf.x, S[t]);
+        S[t] = mfma32(qa[j].y, kf.y, S[t]);
+      }
+    }
+    const int key0 = c * KC + r, key1 = key0 + 32;
+    const bool ok0 = key0 < Nk, ok1 = key1 < Nk;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float s0 = ok0 ? S[0][i] : -INFINITY, s1 = ok1 ? S[1][i] : -INFINITY;
+      const float mn = fmaxf(m[i], half_max(fmaxf(s0, s1)));
+      const float alpha = expf(m[i] - mn);
+      float p0 = expf(s0 - mn), p1 = expf(s1 - mn);
+      l[i] = l[i] * alpha + half_sum(p0 + p1);
+      m[i] = mn;
+      O[0][i] *= alpha; O[1][i] *= alpha;
+      const int rl = acc_row(i, h);
+      if (thresh != 0u) {
+        const uint32_t e = (uint32_t)(((long)bh * N + q0 + rl) * Nk);
+        p0 = fs_dropout_keep(e + (uint32_t)key0, key, thresh) ? p0 * drop_scale : 0.f;
+        p1 = fs_dropout_keep(e + (uint32_t)key1, key, thresh) ? p1 * drop_scale : 0.f;
+      }
+      Pw[rl * ALD + r] = p0;
+      Pw[rl * ALD + 32 + r] = p1;
+    }
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float2 pa = *reinterpret_cast<const float2*>(&Pw[r * ALD + 4 * j + 2 * h]);
+      const int kk = 4 * j + 2 * h;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        O[dt] = mfma32(pa.x, Vs[kk * ALD + 32 * dt + r], O[dt]);
+        O[dt] = mfma32(pa.y, Vs[(kk + 1) * ALD + 32 * dt + r], O[dt]);
+      }
+    }
+    wave_sync();
   }
-  __syncthreads();
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= N) return;
-  float qr[HD];
 #pragma unroll
-  for (int d = 0; d < HD; d += 4) {
-    const f32x4 t = *reinterpret_cast<const f32x4*>(q + ((long)b * N + row) * C + h * HD + d);
-    qr[d] = t.x * scale; qr[d + 1] = t.y * scale; qr[d + 2] = t.z * scale; qr[d + 3] = t.w * scale;
+  for (int i = 0; i < 16; ++i) {
+    const int row = q0 + acc_row(i, h);
+    if (row >= N) continue;
+    const float inv = 1.f / l[i];
+    float* orow = o + ((long)b * N + row) * C + hd * HD;
+    orow[r] = O[0][i] * inv;
+    orow[32 + r] = O[1][i] * inv;
+    if (r == 0) lse[(long)bh * N + row] = m[i] + logf(l[i]);
   }
-  // pass 1: max and sum of exp (online), pass 2: probabilities -> output
-  float m = -INFINITY, l = 0.f;
-  for (int j = 0; j < Nk; ++j) {
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < HD; ++d) s += qr[d] * Ks[j * HD + d];
-    const float mn = fmaxf(m, s);
-    l = l * expf(m - mn) + expf(s - mn);
-    m = mn;
-  }
-  const float L = m + logf(l);
-  float acc[HD];
-#pragma unroll
-  for (int d = 0; d < HD; ++d) acc[d] = 0.f;
-  const uint32_t ebase = (uint32_t)(((long)bh * N + row) * Nk);
-  for (int j = 0; j < Nk; ++j) {
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < HD; ++d) s += qr[d] * Ks[j * HD + d];
-    float p = expf(s - L);
-    if (thresh != 0u) p = fs_dropout_keep(ebase + j, key, thresh) ? p * drop_scale : 0.f;
-#pragma unroll
-    for (int d = 0; d < HD; ++d) acc[d] += p * Vs[j * HD + d];
-  }
-  lse[(long)bh * N + row] = L;
-#pragma unroll
-  for (int d = 0; d < HD; d += 4)
-    *reinterpret_cast<f32x4*>(o + ((long)b * N + row) * C + h * HD + d) = f32x4{acc[d], acc[d + 1], acc[d + 2], acc[d + 3]};
 }
 
-// backward: per row recompute P; dQ per row; dK/dV accumulated per block in LDS, then fp32 atomics.
-__global__ __launch_bounds__(128) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                       const float* __restrict__ v, const float* __restrict__ go,
-                                                       const float* __restrict__ lse, float* __restrict__ dq,
-                                                       float* __restrict__ dk, float* __restrict__ dv, int N, int Nk, int heads,
-                                                       float scale, float drop_scale, uint32_t thresh, uint32_t key) {
-  extern __shared__ float sm[];
-  float* Ks = sm;                       // [Nk][64]
-  float* Vs = Ks + NKMAX * HD;          // [Nk][64]
-  float* dKs = Vs + NKMAX * HD;         // [Nk][64] block accumulators
-  float* dVs = dKs + NKMAX * HD;
-  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+// D[bh][row] = sum_d dO[row][d] * O[row][d]  (= sum_j P~_j dP~_j): 16 lanes per row
+__global__ __launch_bounds__(256) void attn_rowdot_kernel(const float* __restrict__ go, const float* __restrict__ o, float* __restrict__ D,
+                                                          int B, int N, int heads) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long rowid = t >> 4;                       // (b*heads + hd)*N + row
+  const int c4 = (int)(t & 15) * 4;
+  const long total = (long)B * heads * N;
+  float s = 0.f;
+  if (rowid < total) {
+    const int bh = (int)(rowid / N), row = (int)(rowid - (long)bh * N);
+    const int b = bh / heads, hd = bh - b * heads;
+    const long off = ((long)b * N + row) * heads * HD + hd * HD + c4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(go + off), c = *reinterpret_cast<const f32x4*>(o + off);
+    s = a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+  }
+#pragma unroll
+  for (int w = 8; w > 0; w >>= 1) s += __shfl_xor(s, w, 64);
+  if (rowid < total && (t & 15) == 0) D[rowid] = s;
+}
+
+// dQ = dS K with dS = P * (mask * dP~ - D) * scale: a workgroup owns 128 query rows and streams the keys (no atomics)
+__global__ __launch_bounds__(256) void attn_mfma_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, const float* __restrict__ go,
+                                                               const float* __restrict__ lse, const float* __restrict__ D,
+                                                               float* __restrict__ dq, int N, int Nk, int heads, float scale,
+                                                               float drop_scale, uint32_t thresh, uint32_t key) {
+  __shared__ __attribute__((aligned(16))) float Ks[KC * ALD], Vs[KC * ALD], Ps[4][QW * ALD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
   const int C = heads * HD;
-  for (int i = threadIdx.x; i < Nk * (HD / 4); i += blockDim.x) {
-    const int j = i / (HD / 4), d = 4 * (i % (HD / 4));
-    *reinterpret_cast<f32x4*>(&Ks[j * HD + d]) = *reinterpret_cast<const f32x4*>(k + ((long)b * Nk + j) * C + h * HD + d);
-    *reinterpret_cast<f32x4*>(&Vs[j * HD + d]) = *reinterpret_cast<const f32x4*>(v + ((long)b * Nk + j) * C + h * HD + d);
-    *reinterpret_cast<f32x4*>(&dKs[j * HD + d]) = f32x4{0, 0, 0, 0};
-    *reinterpret_cast<f32x4*>(&dVs[j * HD + d]) = f32x4{0, 0, 0, 0};
+  const int q0 = blockIdx.x * 128 + wave * QW;
+  const float* qb = q + (long)b * N * C + hd * HD;
+  const float* gb = go + (long)b * N * C + hd * HD;
+  const float* kb = k + (long)b * Nk * C + hd * HD;
+  const float* vb = v + (long)b * Nk * C + hd * HD;
+  float* Pw = Ps[wave];
+  float2 qa[16], ga[16];
+  stage_rows(qb + (long)q0 * C, C, N - q0, Pw, QW, lane, 64, scale);
+  wave_sync();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) qa[j] = *reinterpret_cast<const float2*>(&Pw[r * ALD + 4 * j + 2 * h]);
+  wave_sync();
+  stage_rows(gb + (long)q0 * C, C, N - q0, Pw, QW, lane, 64, 1.f);
+  wave_sync();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) ga[j] = *reinterpret_cast<const float2*>(&Pw[r * ALD + 4 * j + 2 * h]);
+  float L[16], Dr[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = q0 + acc_row(i, h);
+    L[i] = row < N ? lse[(long)bh * N + row] : INFINITY;        // p = exp(s - inf) = 0 for rows past the end
+    Dr[i] = row < N ? D[(long)bh * N + row] : 0.f;
   }
+  f32x16 dQ[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dQ[0][i] = 0.f; dQ[1][i] = 0.f; }
+  const int nchunk = (Nk + KC - 1) / KC;
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();
+    stage_rows(kb + (long)c * KC * C, C, Nk - c * KC, Ks, KC, tid, 256, 1.f);
+    stage_rows(vb + (long)c * KC * C, C, Nk - c * KC, Vs, KC, tid, 256, 1.f);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 S, dP;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float2 kf = *reinterpret_cast<const float2*>(&Ks[(32 * t + r) * ALD + 4 * j + 2 * h]);
+        const float2 vf = *reinterpret_cast<const float2*>(&Vs[(32 * t + r) * ALD + 4 * j + 2 * h]);
+        S = mfma32(qa[j].x, kf.x, S);
+        dP = mfma32(ga[j].x, vf.x, dP);
+        S = mfma32(qa[j].y, kf.y, S);
+        dP = mfma32(ga[j].y, vf.y, dP);
+      }
+      const int keyi = c * KC + 32 * t + r;
+      const bool kok = keyi < Nk;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rl = acc_row(i, h);
+        const float p = kok ? expf(S[i] - L[i]) : 0.f;
+        float mk = 1.f;
+        if (thresh != 0u) mk = fs_dropout_keep((uint32_t)(((long)bh * N + q0 + rl) * Nk) + (uint32_t)keyi, key, thresh) ? drop_scale : 0.f;
+        Pw[rl * ALD + 32 * t + r] = p * (mk * dP[i] - Dr[i]) * scale;
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float2 da = *reinterpret_cast<const float2*>(&Pw[r * ALD + 4 * j + 2 * h]);
+      const int kk = 4 * j + 2 * h;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dQ[dt] = mfma32(da.x, Ks[kk * ALD + 32 * dt + r], dQ[dt]);
+        dQ[dt] = mfma32(da.y, Ks[(kk + 1) * ALD + 32 * dt + r], dQ[dt]);
+      }
+    }
+    wave_sync();
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = q0 + acc_row(i, h);
+    if (row >= N) continue;
+    float* drow = dq + ((long)b * N + row) * C + hd * HD;
+    drow[r] = dQ[0][i];
+    drow[32 + r] = dQ[1][i];
+  }
+}
+
+// dK = dS^T Q, dV = P~^T dO: a workgroup owns 64 keys and streams query blocks [qb_begin, qb_end) of 128 rows; the four
+// waves' partial tiles are summed through LDS in a fixed order.  atomics != 0 (several query ranges per key chunk): the
+// result is added to zero-initialised dk / dv.
+__global__ __launch_bounds__(256) void attn_mfma_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, const float* __restrict__ go,
+                                                                const float* __restrict__ lse, const float* __restrict__ D,
+                                                                float* __restrict__ dk, float* __restrict__ dv, int N, int Nk, int heads,
+                                                                float scale, float drop_scale, uint32_t thresh, uint32_t key,
+                                                                int blocks_per_split, int atomics) {
+  __shared__ __attribute__((aligned(16))) float Ks[KC * ALD], Vs[KC * ALD], Qs[4][QW * ALD], Gs[4][QW * ALD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int c = blockIdx.x, bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int C = heads * HD;
+  const float* qb = q + (long)b * N * C + hd * HD;
+  const float* gb = go + (long)b * N * C + hd * HD;
+  const float* kb = k + (long)b * Nk * C + hd * HD;
+  const float* vb = v + (long)b * Nk * C + hd * HD;
+  stage_rows(kb + (long)c * KC * C, C, Nk - c * KC, Ks, KC, tid, 256, 1.f);
+  stage_rows(vb + (long)c * KC * C, C, Nk - c * KC, Vs, KC, tid, 256, 1.f);
   __syncthreads();
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = row < N;
-  float qr[HD], gr[HD], dqr[HD];
-  float L = 0.f;
+  float* Qw = Qs[wave];
+  float* Gw = Gs[wave];
+  f32x16 dK[2][2], dV[2][2];
 #pragma unroll
-  for (int d = 0; d < HD; ++d) { qr[d] = 0.f; gr[d] = 0.f; }     // idle rows must contribute exact zeros
-  if (active) {
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int d = 0; d < HD; d += 4) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(q + ((long)b * N + row) * C + h * HD + d);
-      const f32x4 u = *reinterpret_cast<const f32x4*>(go + ((long)b * N + row) * C + h * HD + d);
-      qr[d] = t.x; qr[d + 1] = t.y; qr[d + 2] = t.z; qr[d + 3] = t.w;
-      gr[d] = u.x; gr[d + 1] = u.y; gr[d + 2] = u.z; gr[d + 3] = u.w;
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dK[t][dt][i] = 0.f; dV[t][dt][i] = 0.f; }
+  const int nqb = (N + 127) / 128;
+  const int qb_begin = blockIdx.z * blocks_per_split;
+  const int qb_end = qb_begin + blocks_per_split < nqb ? qb_begin + blocks_per_split : nqb;
+  for (int qblk = qb_begin; qblk < qb_end; ++qblk) {
+    const int q0 = qblk * 128 + wave * QW;
+    stage_rows(qb + (long)q0 * C, C, N - q0, Qw, QW, lane, 64, 1.f);
+    stage_rows(gb + (long)q0 * C, C, N - q0, Gw, QW, lane, 64, 1.f);
+    float L[16], Dr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = q0 + acc_row(i, h);
+      L[i] = row < N ? lse[(long)bh * N + row] : INFINITY;
+      Dr[i] = row < N ? D[(long)bh * N + row] : 0.f;
     }
-    L = lse[(long)bh * N + row];
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 S, dP;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float2 qf = *reinterpret_cast<const float2*>(&Qw[r * ALD + 4 * j + 2 * h]);
+        const float2 gf = *reinterpret_cast<const float2*>(&Gw[r * ALD + 4 * j + 2 * h]);
+        const float2 kf = *reinterpret_cast<const float2*>(&Ks[(32 * t + r) * ALD + 4 * j + 2 * h]);
+        const float2 vf = *reinterpret_cast<const float2*>(&Vs[(32 * t + r) * ALD + 4 * j + 2 * h]);
+        S = mfma32(qf.x, kf.x, S);
+        dP = mfma32(gf.x, vf.x, dP);
+        S = mfma32(qf.y, kf.y, S);
+        dP = mfma32(gf.y, vf.y, dP);
+      }
+      const int keyi = c * KC + 32 * t + r;
+      const bool kok = keyi < Nk;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rl = acc_row(i, h);
+        const float p = kok ? expf(S[i] * scale - L[i]) : 0.f;
+        float mk = 1.f;
+        if (thresh != 0u) mk = fs_dropout_keep((uint32_t)(((long)bh * N + q0 + rl) * Nk) + (uint32_t)keyi, key, thresh) ? drop_scale : 0.f;
+        const float pt = p * mk;
+        const float ds = p * (mk * dP[i] - Dr[i]) * scale;
+        // contract over the query (row) index: register i of this lane is A[key r][query rl]
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dV[t][dt] = mfma32(pt, Gw[rl * ALD + 32 * dt + r], dV[t][dt]);
+          dK[t][dt] = mfma32(ds, Qw[rl * ALD + 32 * dt + r], dK[t][dt]);
+        }
+      }
+    }
+    wave_sync();
   }
-#pragma unroll
-  for (int d = 0; d < HD; ++d) dqr[d] = 0.f;
-  const uint32_t ebase = (uint32_t)(((long)bh * N + row) * Nk);
-  // D = sum_j p_j * dp_j  (dp_j = mask_j * drop_scale * (go . V_j))
-  float Dsum = 0.f;
-  if (active)
-    for (int j = 0; j < Nk; ++j) {
-      float s = 0.f, gv = 0.f;
-#pragma unroll
-      for (int d = 0; d < HD; ++d) { s += qr[d] * Ks[j * HD + d]; gv += gr[d] * Vs[j * HD + d]; }
-      const float p = expf(s * scale - L);
-      const float mk = (thresh == 0u) ? 1.f : (fs_dropout_keep(ebase + j, key, thresh) ? drop_scale : 0.f);
-      Dsum += p * mk * gv;
-    }
-  for (int j = 0; j < Nk; ++j) {
-    float ds = 0.f, pt = 0.f;
-    if (active) {
-      float s = 0.f, gv = 0.f;
-#pragma unroll
-      for (int d = 0; d < HD; ++d) { s += qr[d] * Ks[j * HD + d]; gv += gr[d] * Vs[j * HD + d]; }
-      const float p = expf(s * scale - L);
-      const float mk = (thresh == 0u) ? 1.f : (fs_dropout_keep(ebase + j, key, thresh) ? drop_scale : 0.f);
-      pt = p * mk;                                  // dropped-out probability (multiplies V)
-      ds = p * (mk * gv - Dsum) * scale;            // d(q.k_j)
-#pragma unroll
-      for (int d = 0; d < HD; ++d) dqr[d] += ds * Ks[j * HD + d];
-    }
-    // block reduction of dK_j += ds * q, dV_j += pt * go over the rows of this block (wave shuffle, then LDS atomics)
-#pragma unroll
-    for (int d = 0; d < HD; ++d) {
-      float a = wave_sum(ds * qr[d]);
-      float c2 = wave_sum(pt * gr[d]);
-      if ((threadIdx.x & 63) == 0) { atomicAdd(&dKs[j * HD + d], a); atomicAdd(&dVs[j * HD + d], c2); }
-    }
-  }
-  if (active) {
-#pragma unroll
-    for (int d = 0; d < HD; d += 4)
-      *reinterpret_cast<f32x4*>(dq + ((long)b * N + row) * C + h * HD + d) = f32x4{dqr[d], dqr[d + 1], dqr[d + 2], dqr[d + 3]};
-  }
+  // sum the four waves' partial tiles in wave order: red[tensor][key][d]
   __syncthreads();
-  for (int i = threadIdx.x; i < Nk * HD; i += blockDim.x) {
-    const int j = i / HD, d = i - j * HD;
-    atomicAdd(&dk[((long)b * Nk + j) * C + h * HD + d], dKs[i]);
-    atomicAdd(&dv[((long)b * Nk + j) * C + h * HD + d], dVs[i]);
+  float* red = &Qs[0][0];                              // 2 * 64 * 64 floats = 32 KB <= 4 * QW * ALD floats
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int a0 = (32 * t + acc_row(i, h)) * HD + 32 * dt + r;
+            red[a0] = (w == 0 ? 0.f : red[a0]) + dK[t][dt][i];
+            red[KC * HD + a0] = (w == 0 ? 0.f : red[KC * HD + a0]) + dV[t][dt][i];
+          }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 2 * KC * 16; i += 256) {
+    const int which = i / (KC * 16), rem = i - which * KC * 16;
+    const int kk = rem >> 4, c4 = (rem & 15) * 4;
+    const int keyi = c * KC + kk;
+    if (keyi >= Nk) continue;
+    const float* src = red + which * KC * HD + kk * HD + c4;
+    float* dst = (which ? dv : dk) + ((long)b * Nk + keyi) * C + hd * HD + c4;
+    if (atomics) {
+      atomicAdd(dst, src[0]); atomicAdd(dst + 1, src[1]); atomicAdd(dst + 2, src[2]); atomicAdd(dst + 3, src[3]);
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = f32x4{src[0], src[1], src[2], src[3]};
+    }
   }
 }
 
@@ -417,36 +631,46 @@ int fs_residual_droppath(const float* x, const float* y, float* out, long n, lon
 
 int fs_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int N, int Nk, int heads,
                      float scale, float drop_p, uint32_t key, hipStream_t stream) {
-  FS_REQUIRE(q && k && v && o && lse && B > 0 && N > 0 && Nk > 0 && Nk <= NKMAX && heads > 0 && drop_p >= 0.f && drop_p < 1.f);
-  FS_REQUIRE((long)B * heads * N * Nk < 4294967296L);
+  FS_REQUIRE(q && k && v && o && lse && B > 0 && N > 0 && Nk > 0 && heads > 0 && drop_p >= 0.f && drop_p < 1.f);
+  FS_REQUIRE((long)B * heads * N * Nk < 4294967296L && (long)B * heads < 65536);
   float ds = 1.f; uint32_t thresh = 0u;
   if (drop_p > 0.f) { ds = 1.0f / (float)(1.0 - (double)drop_p); thresh = (uint32_t)((double)drop_p * 4294967296.0); }
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(N, 128), B * heads), dim3(128), 0, stream, q, k, v, o, lse, N, Nk, heads, scale, ds,
+  hipLaunchKernelGGL(attn_mfma_fwd_kernel, dim3(cdiv(N, 128), B * heads), dim3(256), 0, stream, q, k, v, o, lse, N, Nk, heads, scale, ds,
                      thresh, key);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
 
-// dq overwritten; dk / dv overwritten (zeroed here, accumulated with atomics)
-int fs_attention_bwd(const float* q, const float* k, const float* v, const float* go, const float* lse, float* dq, float* dk,
-                     float* dv, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key, hipStream_t stream) {
-  FS_REQUIRE(q && k && v && go && lse && dq && dk && dv && B > 0 && N > 0 && Nk > 0 && Nk <= NKMAX && heads > 0);
-  const size_t kvbytes = (size_t)B * Nk * heads * HD * sizeof(float);
-  hipError_t e = hipMemsetAsync(dk, 0, kvbytes, stream);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(dv, 0, kvbytes, stream);
-  if (e != hipSuccess) return (int)e;
+// dq / dk / dv overwritten.  o = the forward's output; scratch = B*heads*N floats (row sums of dO * O).
+int fs_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse, float* dq,
+                     float* dk, float* dv, float* scratch, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key,
+                     hipStream_t stream) {
+  FS_REQUIRE(q && k && v && o && go && lse && dq && dk && dv && scratch && B > 0 && N > 0 && Nk > 0 && heads > 0);
+  FS_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (long)B * heads * N * Nk < 4294967296L && (long)B * heads < 65536);
   float ds = 1.f; uint32_t thresh = 0u;
   if (drop_p > 0.f) { ds = 1.0f / (float)(1.0 - (double)drop_p); thresh = (uint32_t)((double)drop_p * 4294967296.0); }
-  static bool attr_set = false;
-  const int smem = 4 * NKMAX * HD * (int)sizeof(float);
-  if (!attr_set) {
-    e = hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(cdiv(N, 128), B * heads), dim3(128), smem, stream, q, k, v, go, lse, dq, dk, dv, N, Nk,
+  const long rows = (long)B * heads * N;
+  hipLaunchKernelGGL(attn_rowdot_kernel, dim3(cdiv(rows * 16, 256)), dim3(256), 0, stream, go, o, scratch, B, N, heads);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_mfma_bwd_dq_kernel, dim3(cdiv(N, 128), B * heads), dim3(256), 0, stream, q, k, v, go, lse, scratch, dq, N, Nk,
                      heads, scale, ds, thresh, key);
+  FS_LAUNCH_CHECK();
+  // key chunks x (batch, head) workgroups; when that does not fill the chip the query range is split too (atomics into zeroed dk/dv)
+  const int nkc = cdiv(Nk, KC), nqb = cdiv(N, 128);
+  int nsplit = cdiv(512, (long)nkc * B * heads);
+  if (nsplit > nqb) nsplit = nqb;
+  if (nsplit > 64) nsplit = 64;
+  const int bps = cdiv(nqb, nsplit);
+  nsplit = cdiv(nqb, bps);
+  if (nsplit > 1) {
+    const size_t kvbytes = (size_t)B * Nk * heads * HD * sizeof(float);
+    hipError_t e = hipMemsetAsync(dk, 0, kvbytes, stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(dv, 0, kvbytes, stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(attn_mfma_bwd_dkv_kernel, dim3(nkc, B * heads, nsplit), dim3(256), 0, stream, q, k, v, go, lse, scratch, dk, dv, N, Nk,
+                     heads, scale, ds, thresh, key, bps, nsplit > 1 ? 1 : 0);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -25,6 +25,8 @@ SIGNATURES = {
     "fs_edge_loss_bwd": "pplfppp",
     "fs_gauss_grid_fwd": "pppiiii",
     "fs_gauss_grid_bwd": "ppppiiii",
+    "fs_grid_upsample_fwd": "ppiiiii",
+    "fs_grid_upsample_bwd": "ppiiiii",
     "fs_grid_sample_fwd": "pppiiiiiii",
     "fs_grid_sample_label": "ppppiiiii",
     "fs_grid_sample_bwd_grid": "ppppiiiiiii",
@@ -67,7 +69,7 @@ SIGNATURES = {
     "fs_dwconv3_bwd_weight": "pppiiii",
     "fs_residual_droppath": "pppllfu",
     "fs_attention_fwd": "pppppiiiiffu",
-    "fs_attention_bwd": "ppppppppiiiiffu",
+    "fs_attention_bwd": "ppppppppppiiiiffu",
 }
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 

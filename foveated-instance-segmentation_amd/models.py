@@ -104,8 +104,11 @@ class DeformSegmentationModule(nn.Module):
         self.padding_size_x = self.padding_size_y = int(cfg.MODEL.gaussian_radius)
         self.input_size = tuple(T.saliency_input_size)
         self.input_size_net = tuple(T.task_input_size)
-        if tuple(self.input_size_net) != tuple(self.input_size):
-            raise NotImplementedError("task_input_size must equal saliency_input_size (models/models.py:968 assumes it)")
+        ti, si = tuple(int(v) for v in self.input_size_net), tuple(int(v) for v in self.input_size)
+        if ti != si and (ti[0] % si[0] or ti[1] % si[1]):
+            raise NotImplementedError("task_input_size must be an integer multiple of saliency_input_size (grid up-sampling, models/models.py:621-631)")
+        if cfg.DATASET.segm_downsampling_rate != 1:
+            raise NotImplementedError("DATASET.segm_downsampling_rate must be 1 (grid_y == grid, models/models.py:627)")
         k = 2 * self.padding_size_x + 1
         self.filter = _FilterHolder(k, cfg.MODEL.gaussian_radius)
         self.register_buffer("g1d", torch.from_numpy(make_gaussian_1d(k, cfg.MODEL.gaussian_radius)), persistent=False)
@@ -135,8 +138,14 @@ class DeformSegmentationModule(nn.Module):
         return self.net_compress.softmax_nhwc(s), x_low
 
     def create_grid(self, xs):
-        """xs (B,1,hs,ws) -> grid (B,hs,ws,2); replication pad folded in (models/models.py:594-637,821)."""
-        return ops.GaussGrid.apply(xs, self.g1d, self.padding_size_x)
+        """xs (B,1,hs,ws) -> grid (B,ht,wt,2) at the task network's input size; replication pad folded in
+        (models/models.py:594-637,821).  When task_input_size != saliency_input_size the (hs,ws) grid is bilinearly up-sampled
+        (nn.Upsample(size=input_size_net, mode='bilinear'), :621-631); grid_y is the same tensor (segm_downsampling_rate 1)."""
+        grid = ops.GaussGrid.apply(xs, self.g1d, self.padding_size_x)
+        ht, wt = int(self.input_size_net[0]), int(self.input_size_net[1])
+        if (ht, wt) != (grid.shape[1], grid.shape[2]):
+            grid = ops.GridUpsample.apply(grid, ht, wt)
+        return grid
 
     @torch.no_grad()
     def unwarp(self, pred, grid, seg_size):

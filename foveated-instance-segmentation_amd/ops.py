@@ -703,6 +703,25 @@ class GaussGrid(Function):
         return dxs, None, None
 
 
+class GridUpsample(Function):
+    """nn.Upsample(size=(H,W), mode='bilinear') of the grid (B,h,w,2) -> (B,H,W,2) (models/models.py:621-631)."""
+
+    @staticmethod
+    def forward(ctx, grid, H, W):
+        B, h, w, _ = grid.shape
+        out = torch.empty(B, H, W, 2, device=grid.device, dtype=torch.float32)
+        hip.call("fs_grid_upsample_fwd", hip.ptr(grid.contiguous()), hip.ptr(out), B, h, w, H, W)
+        ctx.cfg = (B, h, w, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, h, w, H, W = ctx.cfg
+        d = torch.empty(B, h, w, 2, device=g.device, dtype=torch.float32)
+        hip.call("fs_grid_upsample_bwd", hip.ptr(g.contiguous()), hip.ptr(d), B, h, w, H, W)
+        return d, None, None
+
+
 class GridSample(Function):
     """x (B,C,H,W) NCHW, grid (B,h,w,2) -> (B,h,w,C) NHWC; gradient w.r.t. the grid (and, when asked,
     w.r.t. x by scatter-add)."""
@@ -865,7 +884,7 @@ class ResidualDropPath(Function):
 
 
 class Attention(Function):
-    """softmax(q k^T / sqrt(64)) (dropout p) v per head; q (B,N,C), k/v (B,Nk,C), C = heads*64, Nk <= 128."""
+    """softmax(q k^T / sqrt(64)) (dropout p) v per head on the matrix cores; q (B,N,C), k/v (B,Nk,C), C = heads*64, any Nk."""
 
     @staticmethod
     def forward(ctx, q, k, v, heads, p, key):
@@ -874,17 +893,20 @@ class Attention(Function):
         assert C == heads * 64, "head_dim must be 64"
         o = torch.empty_like(q)
         lse = torch.empty(B * heads * N, device=q.device, dtype=torch.float32)
-        hip.call("fs_attention_fwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o), hip.ptr(lse), B, N, Nk, heads, 0.125, float(p), int(key))
-        ctx.save_for_backward(q, k, v, lse)
+        _launch("attn_fwd", 4.0 * B * heads * N * Nk * 64, "fs_attention_fwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o), hip.ptr(lse),
+                B, N, Nk, heads, 0.125, float(p), int(key))
+        ctx.save_for_backward(q, k, v, o, lse)
         ctx.cfg = (heads, float(p), int(key))
         return o
 
     @staticmethod
     def backward(ctx, go):
-        q, k, v, lse = ctx.saved_tensors
+        q, k, v, o, lse = ctx.saved_tensors
         heads, p, key = ctx.cfg
         B, N, C = q.shape
+        Nk = k.shape[1]
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        hip.call("fs_attention_bwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(go.contiguous()), hip.ptr(lse), hip.ptr(dq), hip.ptr(dk),
-                 hip.ptr(dv), B, N, k.shape[1], heads, 0.125, p, key)
+        scratch = torch.empty(B * heads * N, device=q.device, dtype=torch.float32)
+        _launch("attn_bwd", 14.0 * B * heads * N * Nk * 64, "fs_attention_bwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o),
+                hip.ptr(go.contiguous()), hip.ptr(lse), hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), hip.ptr(scratch), B, N, Nk, heads, 0.125, p, key)
         return dq, dk, dv, None, None, None

@@ -51,6 +51,11 @@ int fs_edge_loss_bwd(const float* xs, const float* t, long n, float coef, const 
 int fs_gauss_grid_fwd(const float* xs, const double* g1d, float* grid, int B, int hs, int ws, int pad, fs_stream_t stream);
 int fs_gauss_grid_bwd(const float* xs, const double* g1d, const float* dgrid, float* dxs, int B, int hs, int ws, int pad,
                       fs_stream_t stream);
+/* nn.Upsample(size=(H,W), mode='bilinear') of the deformation grid, align_corners=False: grid (B,h,w,2) -> out (B,H,W,2); the
+ * task network may run at a higher resolution than the saliency map (TRAIN.task_input_size != saliency_input_size).
+ * The backward needs integer factors H/h, W/w.  models/models.py:621-631. */
+int fs_grid_upsample_fwd(const float* grid, float* out, int B, int h, int w, int H, int W, fs_stream_t stream);
+int fs_grid_upsample_bwd(const float* g, float* dgrid, int B, int h, int w, int H, int W, fs_stream_t stream);
 /* F.grid_sample(x, grid): bilinear / zeros / align_corners=False, bit-exact with ATen-CPU.
  * x (B,C,H,W) NCHW; out (B,h,w,C) if nhwc_out else (B,C,h,w).  models/models.py:909. */
 int fs_grid_sample_fwd(const float* x, const float* grid, float* out, int B, int C, int H, int W, int h, int w, int nhwc_out,
@@ -202,11 +207,16 @@ int fs_dwconv3_bwd_weight(const float* x, const float* dy, float* dw, int B, int
 /* out = x + DropPath_p(y) (per-sample keep, hash keyed); x NULL -> out = scaled y (the backward of the y branch). */
 int fs_residual_droppath(const float* x, const float* y, float* out, long n, long per_sample, float drop_p, uint32_t key,
                          fs_stream_t stream);
-/* softmax(q k^T * scale) (dropout p) v per head; head_dim 64, Nk <= 128 reduced key/value tokens; lse = B*heads*N floats. */
+/* softmax(q k^T * scale) (dropout p) v per head on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32
+ * accumulate); head_dim 64, any number Nk of sequence-reduced key/value tokens (streamed in chunks of 64, online softmax);
+ * q/o (B,N,heads*64), k/v (B,Nk,heads*64); lse = B*heads*N floats (log-sum-exp per query row, kept for the backward).
+ * Replaces SegformerEfficientSelfAttention's matmul-softmax-dropout-matmul (transformers 4.46.2, models/segformer.py:2,88-100). */
 int fs_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int N, int Nk, int heads,
                      float scale, float drop_p, uint32_t key, fs_stream_t stream);
-int fs_attention_bwd(const float* q, const float* k, const float* v, const float* go, const float* lse, float* dq, float* dk,
-                     float* dv, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key, fs_stream_t stream);
+/* Backward of the above: dq, dk, dv overwritten.  o = the forward's output, go = its gradient, scratch = B*heads*N floats. */
+int fs_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse, float* dq,
+                     float* dk, float* dv, float* scratch, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key,
+                     fs_stream_t stream);
 
 /* ---- optimiser ------------------------------------------------------------------------------- */
 /* torch.optim.Adam(weight_decay) step over a flat fp32 arena of n (multiple of 4) elements; step >= 1;

@@ -48,6 +48,15 @@ def rmsrel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
+def analytic_zero_grad(name, training):
+    """Parameters whose gradient is analytically zero, so both sides hold only rounding noise: a conv bias in front of a
+    batch-statistics BatchNorm (C1's cls_net convs carry biases, model_utils.py:227-236), and the bias of the 1x1 conv in
+    front of the spatial softmax (shift invariance)."""
+    if name.endswith("net_compress.conv_last.bias"):
+        return True
+    return training and "cls_net.layer" in name and name.endswith(".0.bias")
+
+
 class replay:
     """with replay(root, trace): the oracle's activation sites take the branches recorded in `trace` (an ops.ACT_TRACE
     list filled by a forward of the HIP module tree `root`; names are module paths relative to `root`)."""
@@ -581,9 +590,36 @@ def _hip_module():
     return m.to(DEV)
 
 
+_PRISTINE = {}
+
+
+def _restore(m):
+    """Back to the name-keyed initial state.  The parity tests never step an optimiser on these shared modules, so the only
+    tensors that move are the buffers (BatchNorm running statistics / counters in train-mode forwards): the first call keeps a
+    copy of every buffer and a checksum of the parameters, later calls copy the buffers back (a full name-keyed re-init of the
+    130 M parameters costs ~5 s per call, and the suite asks for it ~100 times)."""
+    snap = _PRISTINE.get(id(m))
+    if snap is None:
+        fovealseg.weights.apply_name_keyed_init(m)
+        bufs = {k: v.detach().clone() for k, v in m.named_buffers()}
+        csum = float(sum(p.detach().double().sum() for p in m.parameters()))
+        _PRISTINE[id(m)] = (m, bufs, csum)
+        return
+    _, bufs, csum = snap
+    with torch.no_grad():
+        for k, v in m.named_buffers():
+            v.copy_(bufs[k])
+    for mod in m.modules():
+        if hasattr(mod, "_pending_batches"):
+            mod._pending_batches = 0
+    assert float(sum(p.detach().double().sum() for p in m.parameters())) == csum, "a test modified the shared module's parameters"
+
+
 @pytest.fixture(scope="module")
 def hipmod():
-    return _hip_module()
+    m = _hip_module()
+    _restore(m)
+    return m
 
 
 def _sub(m, path):
@@ -601,7 +637,7 @@ def _set_drop(m, p):
 @pytest.fixture(scope="module")
 def oracle():
     o = O.OracleDeformSeg()
-    fovealseg.weights.apply_name_keyed_init(o)
+    _restore(o)
     O.assign_paths(o)
     return o
 
@@ -618,7 +654,7 @@ def _run_oracle_block(oblk, name, rel, ins, train):
 # One tolerance table for all three precision modes: with the activation branches replayed the backward is a
 # smooth function on both sides, so f16x2 / bf16x3 meet the same bounds as the fp32-MFMA mode.
 TOL_BLOCK_OUT, TOL_BLOCK_DIN, TOL_BLOCK_DW = 2e-5, 2e-4, 5e-4
-TOL_E2E_GRAD = 2e-3          # rms-relative, per parameter tensor, through the full depth of the network (fwd ~100 layers + bwd)
+TOL_E2E_GRAD = 1e-3          # rms-relative, per parameter tensor, through the full depth of the network (fwd ~100 layers + bwd)
 
 
 @pytest.mark.parametrize("name", ["basic", "bottleneck", "hrmodule4"])
@@ -626,8 +662,8 @@ TOL_E2E_GRAD = 2e-3          # rms-relative, per parameter tensor, through the f
 def test_g7_blocks(golden, hipmod, oracle, name, mode, prec):
     g = golden(f"g7_{name}_{mode}")
     prefix = str(g["prefix"])
-    fovealseg.weights.apply_name_keyed_init(hipmod)
-    fovealseg.weights.apply_name_keyed_init(oracle)
+    _restore(hipmod)
+    _restore(oracle)
     blk, oblk = _sub(hipmod, prefix), _sub(oracle, prefix)
     blk.train(mode != "eval")
     oblk.train(mode != "eval")
@@ -659,13 +695,13 @@ def test_g7_blocks(golden, hipmod, oracle, name, mode, prec):
     for k, p in params.items():                           # EVERY parameter gradient of the block
         assert relerr(p.grad.cpu(), oparams[k].grad) <= TOL_BLOCK_DW, k
     _set_drop(blk, 0.3)
-    fovealseg.weights.apply_name_keyed_init(hipmod)
-    fovealseg.weights.apply_name_keyed_init(oracle)
+    _restore(hipmod)
+    _restore(oracle)
 
 
 def test_g8_hrnet_eval(golden, hipmod, prec):
     g = golden("g8_hrnet_eval")
-    fovealseg.weights.apply_name_keyed_init(hipmod)
+    _restore(hipmod)
     hipmod.eval()
     with torch.no_grad():
         feat = hipmod.encoder(T(g["x"]).to(DEV), return_feature_maps=True)[0]
@@ -679,8 +715,8 @@ def test_g8_hrnet_eval(golden, hipmod, prec):
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_g9_c1(golden, hipmod, oracle, mode, prec):
     g = golden(f"g9_c1_{mode}")
-    fovealseg.weights.apply_name_keyed_init(hipmod)
-    fovealseg.weights.apply_name_keyed_init(oracle)
+    _restore(hipmod)
+    _restore(oracle)
     hipmod.decoder.train(mode == "train")
     oracle.decoder.train(mode == "train")
     gg = torch.Generator().manual_seed(int(g["seed"]))
@@ -703,10 +739,14 @@ def test_g9_c1(golden, hipmod, oracle, mode, prec):
     assert relerr(fd.grad.cpu(), fr.grad) <= 2e-4
     assert rmsrel(fr.grad[:, ::60, 20:36, 20:36], T(g["dfeat_crop"])) <= 2e-2     # replayed oracle vs the reference's gradient
     po = dict(oracle.decoder.named_parameters())
+    scale = float(hipmod.decoder.cls_net.layer2[0].conv1[0].weight.grad.abs().max())
     for k, q in hipmod.decoder.named_parameters():        # every decoder parameter
+        if analytic_zero_grad(k, mode == "train"):
+            assert float(q.grad.abs().max()) <= 1e-3 * scale, k
+            continue
         assert relerr(q.grad.cpu(), po[k].grad) <= 5e-4, k
-    fovealseg.weights.apply_name_keyed_init(hipmod)
-    fovealseg.weights.apply_name_keyed_init(oracle)
+    _restore(hipmod)
+    _restore(oracle)
 
 
 class _InjectValue(torch.autograd.Function):
@@ -734,7 +774,7 @@ def test_g11_end_to_end(golden, hipmod, oracle, prec):
     checked with the reference's grid injected (bit-identical labels and x_sampled)."""
     try:
         g = golden("g11_e2e_eval")
-        fovealseg.weights.apply_name_keyed_init(hipmod)
+        _restore(hipmod)
         hipmod.eval()
         feed = _feed(g)
         with torch.no_grad():
@@ -748,7 +788,7 @@ def test_g11_end_to_end(golden, hipmod, oracle, prec):
         g = golden("g11_e2e_train_p0")
         _set_drop(hipmod, 0.0)
         # (a) free running
-        fovealseg.weights.apply_name_keyed_init(hipmod)
+        _restore(hipmod)
         hipmod.train()
         feed = _feed(g)
         hipmod.zero_grad()
@@ -761,8 +801,8 @@ def test_g11_end_to_end(golden, hipmod, oracle, prec):
         grid_free = hipmod.create_grid(hipmod.saliency(feed["img_data"], feed["focus_point"])[0]).detach().cpu().numpy()
         assert np.abs(grid_free - g["grid"]).max() <= 3e-5
         # (b) reference grid injected on both sides; the oracle replays the device's activation branches
-        fovealseg.weights.apply_name_keyed_init(hipmod)
-        fovealseg.weights.apply_name_keyed_init(oracle)
+        _restore(hipmod)
+        _restore(oracle)
         hipmod.train()
         oracle.train()
         ref_grid = T(g["grid"]).to(DEV)
@@ -793,34 +833,31 @@ def test_g11_end_to_end(golden, hipmod, oracle, prec):
         params, oparams = dict(hipmod.named_parameters()), dict(oracle.named_parameters())
         worst = {}
         for n, q in params.items():
-            if q.grad is None or n not in oparams or oparams[n].grad is None:
+            if q.grad is None or n not in oparams or oparams[n].grad is None or analytic_zero_grad(n, True):
                 continue
             e = rmsrel(q.grad.cpu(), oparams[n].grad)
             grp = n.split(".")[0]
             if e > worst.get(grp, ("", 0.0))[1]:
                 worst[grp] = (n, e)
         print("g11 worst rms-relative gradient error per net", prec, worst)
-        # encoder + decoder: EVERY parameter-gradient tensor, one bound for all three modes.  The saliency side passes through
-        # the clamp mask of create_grid (ill-conditioned, see g4) and keeps the norm bound of round 1.
-        for grp in ("encoder", "decoder"):
+        # EVERY parameter-gradient tensor of all four nets, one bound for all three modes (measured: 0.9e-4 .. 2.4e-4).  With the
+        # same grid on both sides even the saliency side (through the clamp mask of create_grid) is tight.
+        for grp in ("encoder", "decoder", "localization", "net_compress"):
             assert worst[grp][1] <= TOL_E2E_GRAD, (prec, worst[grp])
-        for n, ref in zip(g["gn_names"], g["gn"]):
-            if str(n).startswith("localization") or str(n).startswith("net_compress"):
-                gn = float(params[str(n)].grad.norm())
-                assert abs(gn - float(ref)) <= 5e-2 * max(abs(float(ref)), 1e-6), (n, gn, ref)
-            else:                                                                  # replayed oracle vs the reference's own norms
-                gn = float(oparams[str(n)].grad.norm())
-                assert abs(gn - float(ref)) <= 2e-2 * max(abs(float(ref)), 1e-6), (n, gn, ref)
+        for n, ref in zip(g["gn_names"], g["gn"]):                                 # replayed oracle vs the reference's own norms
+            gn = float(oparams[str(n)].grad.norm())
+            tol = 5e-2 if (str(n).startswith("localization") or str(n).startswith("net_compress")) else 2e-2
+            assert abs(gn - float(ref)) <= tol * max(abs(float(ref)), 1e-6), (n, gn, ref)
     finally:
         _set_drop(hipmod, 0.3)
-        fovealseg.weights.apply_name_keyed_init(hipmod)
-        fovealseg.weights.apply_name_keyed_init(oracle)
+        _restore(hipmod)
+        _restore(oracle)
 
 
 def test_dropout_replay_basic_block(hipmod, oracle, prec):
     """Train-mode BasicBlock with Dropout(0.3): the kernel's hash mask AND its activation branches replayed in the oracle."""
-    fovealseg.weights.apply_name_keyed_init(hipmod)
-    fovealseg.weights.apply_name_keyed_init(oracle)
+    _restore(hipmod)
+    _restore(oracle)
     path = "stage3.1.branches.1.2"
     blk = _sub(hipmod.encoder, path).train()
     oblk = _sub(oracle.encoder, path).train()
@@ -857,7 +894,7 @@ def test_dropout_replay_basic_block(hipmod, oracle, prec):
 # full depth at the bench shape: HRNetV2 + C1 + Dice/Focal, train mode, B = 64 at 80x80, every precision mode
 # ------------------------------------------------------------------------------------------------
 FULL_DEPTH_LOGIT_TOL = 1e-4       # north_star: "fp32 logits within 1e-4"
-FULL_DEPTH_GRAD_TOL = 2e-3        # rms-relative per parameter-gradient tensor, the same for f32 / bf16x3 / f16x2
+FULL_DEPTH_GRAD_TOL = 4e-4        # rms-relative per parameter-gradient tensor, the same for f32 / bf16x3 / f16x2 (measured worst: 1.0e-4 / 1.3e-4 / 1.1e-4)
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
@@ -877,8 +914,8 @@ def test_full_depth_b64_modes(hipmod, oracle, mode):
     gt = torch.where(disc, cls.expand(B, 80, 80), torch.full((B, 80, 80), 50))
     fovealseg.hip.set_conv_precision(mode)
     try:
-        fovealseg.weights.apply_name_keyed_init(hipmod)
-        fovealseg.weights.apply_name_keyed_init(oracle)
+        _restore(hipmod)
+        _restore(oracle)
         hipmod.train()
         oracle.train()
         _set_drop(hipmod, 0.0)
@@ -917,8 +954,8 @@ def test_full_depth_b64_modes(hipmod, oracle, mode):
         fovealseg.hip.set_conv_precision("f16x2")
         _set_drop(hipmod, 0.3)
         hipmod.zero_grad(set_to_none=True)
-        fovealseg.weights.apply_name_keyed_init(hipmod)
-        fovealseg.weights.apply_name_keyed_init(oracle)
+        _restore(hipmod)
+        _restore(oracle)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1077,7 +1114,7 @@ def test_deeplab_encoder_vs_oracle(mode, prec):
         assert relerr(pm[k].grad.cpu(), po[k].grad) <= tol_grad, k
 
 
-DEEPLAB_TRAIN_GRAD_TOL = 0.25
+DEEPLAB_TRAIN_GRAD_TOL = 5e-3     # was 0.25 before the activation replay; measured 3e-4 .. 1.3e-3 in all modes
 
 
 def test_deeplab_blocks_train(prec):
@@ -1209,7 +1246,9 @@ def test_layernorm_gelu_dwconv_droppath():
     assert torch.equal(ad.grad.cpu(), torch.ones(6, 10, 64)) and relerr(yd.grad.cpu(), (keep / 0.75).expand(6, 10, 64)) <= 1e-6
 
 
-@pytest.mark.parametrize("heads,N,Nk,p", [(1, 200, 100, 0.0), (5, 77, 100, 0.2), (2, 130, 25, 0.2)])
+# Nk = 100 / 400: the sequence-reduced key counts at 80x80 / 160x160 inputs (BASELINE configs[3]); ragged N and Nk; N < one wave tile
+@pytest.mark.parametrize("heads,N,Nk,p", [(1, 200, 100, 0.0), (5, 77, 100, 0.2), (2, 130, 25, 0.2), (2, 1600, 400, 0.2), (1, 300, 7, 0.0),
+                                         (8, 25, 25, 0.0), (1, 6400, 100, 0.2)])
 def test_attention_vs_torch(heads, N, Nk, p):
     g = torch.Generator().manual_seed(43)
     B, C = 2, heads * 64
@@ -1331,3 +1370,88 @@ def test_segformer_through_module_surface():
     loss.mean().backward()
     assert np.isfinite(float(loss.detach()))
     assert module.encoder.segformer.encoder.block[2][20].mlp.dense1.weight.grad is not None
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs[3] / configs[4]: task network at 160x160 on an 80x80 saliency grid (grid up-sampling,
+# models/models.py:621-631); DeepLab behind a 2048x2048 -> 80x80 warp at the per-GPU batch of the 8-GPU config.
+# "parity unpinned" for the SegFormer / DeepLab encoders themselves (see their oracle headers); what is checked here
+# is the grid path against torch, and that the named configurations RUN end to end (forward, backward, finite, shapes).
+# ------------------------------------------------------------------------------------------------
+def test_grid_upsample_vs_torch():
+    g = torch.Generator().manual_seed(5)
+    for (h, w, H, W) in ((80, 80, 160, 160), (20, 30, 60, 60), (16, 16, 16, 16)):
+        grid = torch.rand(3, h, w, 2, generator=g) * 2 - 1
+        gr = grid.clone().requires_grad_(True)
+        ref = F.interpolate(gr.permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+        cot = torch.randn(ref.shape, generator=g)
+        ref.backward(cot)
+        gd = grid.to(DEV).requires_grad_(True)
+        out = ops.GridUpsample.apply(gd, H, W)
+        out.backward(cot.to(DEV))
+        assert out.shape == (3, H, W, 2)
+        assert float((out.detach().cpu() - ref.detach()).abs().max()) <= 1e-6
+        assert relerr(gd.grad.cpu(), gr.grad) <= 1e-5
+
+
+def test_config3_segformer_task160():
+    """BASELINE configs[3]: SegFormer encoder (fc_dim 1024), task_input_size (160,160) on the (80,80) saliency grid."""
+    from fovealseg import train
+    cfg = fovealseg.lvis50_cfg()
+    cfg.MODEL.arch_encoder, cfg.MODEL.fc_dim = "segformer", 1024
+    cfg.TRAIN.task_input_size = (160, 160)
+    module, nets = train.build_module(cfg, device=DEV)
+    module.train()
+    X, Fp, Y, cls = train.synthetic_batch(2, 512, 512, seed=9, device=DEV)
+    feed = {"img_data": X, "seg_label": Y, "focus_point": Fp, "cls_label": cls}
+    xs, _ = module.saliency(X, Fp)
+    grid = module.create_grid(xs)
+    assert grid.shape == (2, 160, 160, 2)
+    # the up-sampled grid against torch on the 80x80 grid the module computes
+    g80 = ops.GaussGrid.apply(xs, module.g1d, module.padding_size_x).detach().cpu()
+    ref = F.interpolate(g80.permute(0, 3, 1, 2), size=(160, 160), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    assert float((grid.detach().cpu() - ref).abs().max()) <= 1e-6
+    loss, acc, edge = module(feed)
+    loss.mean().backward()
+    assert feed["seg_label"].shape == (2, 160, 160) and feed["seg_label"].dtype == torch.int64
+    assert np.isfinite(float(loss.detach())) and 0.0 <= float(acc) <= 1.0
+    for n, p_ in module.named_parameters():
+        if p_.requires_grad and not n.startswith("encoder.decode_head"):
+            assert p_.grad is not None and bool(torch.isfinite(p_.grad).all()), n
+    assert float(module.localization.fov_expand_1.weight.grad.abs().max()) > 0     # the gradient reaches the saliency net through the up-sampled grid
+    # evaluation caller on the same configuration
+    module.eval()
+    with torch.no_grad():
+        outs = module({"img_data": X, "seg_label": Y, "focus_point": Fp, "cls_label": cls}, is_inference=True)
+    assert len(outs) == 6 and all(np.isfinite(float(o)) for o in outs)
+
+
+def test_config4_deeplab_2048():
+    """BASELINE configs[4] at its per-GPU size: DeepLab encoder, 2048x2048 input -> (80,80) foveated warp, batch 16."""
+    from fovealseg import train
+    cfg = fovealseg.lvis50_cfg()
+    cfg.MODEL.arch_encoder = "deeplab"
+    module, nets = train.build_module(cfg, device=DEV)
+    module.train()
+    B, H = 16, 2048
+    X, Fp, Y, cls = train.synthetic_batch(B, H, H, seed=4, device=DEV)
+    # front-end properties at this size (size-independent): constant image samples to the constant, label map is binary,
+    # area pooling of the disc mask keeps its mean
+    xs, x_low = module.saliency(X, Fp)
+    assert x_low.shape == (B, 80, 80, 5) and abs(float(xs.sum()) - B) <= 1e-3
+    grid = module.create_grid(xs)
+    ones = ops.GridSample.apply(torch.ones(B, 3, H, H, device=DEV), grid.detach())
+    inside = (grid.detach().abs() < 0.999).all(-1)
+    assert float((ones[inside] - 1).abs().max()) <= 2e-7
+    lab = ops.grid_sample_label(Y, grid.detach())
+    assert set(torch.unique(lab).tolist()) <= {0, 1}
+    ap = ops.area_pool(Y, 80, 80)
+    assert abs(float(ap.mean()) - float(Y.mean())) <= 1e-5
+    feed = {"img_data": X, "seg_label": Y, "focus_point": Fp, "cls_label": cls}
+    loss, acc, edge = module(feed)
+    loss.mean().backward()
+    assert feed["seg_label"].shape == (B, 80, 80)
+    assert np.isfinite(float(loss.detach())) and np.isfinite(float(edge.detach()))
+    for n, p_ in module.named_parameters():
+        if p_.requires_grad:
+            assert p_.grad is not None and bool(torch.isfinite(p_.grad).all()), n
