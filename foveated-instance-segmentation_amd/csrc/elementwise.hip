@@ -5,6 +5,7 @@
 // models/hrnetv2_nodownsp.py:46-64 (BasicBlock), :228-252 (fuse), :434-442 (concat),
 // models/model_utils.py:254-255 (AvgPool2d(10)).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -213,12 +214,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int c0, int rows_per_block, int act, int training,
                                                            float drop_scale, uint32_t drop_thresh,
                                                            uint32_t drop_key, float* __restrict__ dy, float* __restrict__ dres,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                           int reverse) {
   RowWalk w(C);
   if (blockIdx.x == 0 && dgamma != nullptr)
     for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
-      dbeta[cc] = (float)sums[cc];
-      dgamma[cc] = (float)sums[Ctot + cc];
+      dbeta[cc] = (accumulate ? dbeta[cc] : 0.f) + (float)sums[cc];
+      dgamma[cc] = (accumulate ? dgamma[cc] : 0.f) + (float)sums[Ctot + cc];
     }
   if (!w.active()) return;
   const int c = 4 * w.col;
@@ -229,9 +231,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     mg[j] = training ? (float)(sums[c + j] / (double)M) : 0.f;
     mgx[j] = training ? (float)(sums[Ctot + c + j] / (double)M) : 0.f;
   }
-  const long rb = (long)blockIdx.x * rows_per_block;
+  // reverse = 1: workgroups are dispatched in blockIdx order, so the first ones take the LAST rows -- the rows the reduce pass
+  // read last and the 256 MB Infinity Cache most likely still holds (dz + y of a 64-channel 80x80 layer are 210 MB)
+  const long rb = (long)(reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rows_per_block;
   long re = rb + rows_per_block; if (re > M) re = M;
-  for (long r = rb + w.r0; r < re; r += w.rpi) {
+  auto finish = [&](long r, f32x4 g, const f32x4 yy) {
+    if (dres != nullptr) *reinterpret_cast<f32x4*>(dres + r * ld + c) = g;
+    const f32x4 xh = (yy - mu) * is;
+    f32x4 d = ga * (g - mg - xh * mgx);
+    if (drop_thresh != 0u) {
+      const uint32_t e = (uint32_t)(r * ld + c0 + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = fs_dropout_keep(e + j, drop_key, drop_thresh) ? d[j] * drop_scale : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(dy + r * ld + c) = d;
+  };
+  long r = rb + w.r0;
+  if (act == FS_ACT_NONE || mask != nullptr) {
+    // two rows per trip, all loads issued before the first use (as in the reduce pass): more bytes in flight per CU
+    const long step = w.rpi;
+    for (; r + step < re; r += 2 * step) {
+      f32x4 g[2], yy[2];
+      unsigned m[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const long o = (r + u * step) * ld + c;
+        g[u] = *reinterpret_cast<const f32x4*>(dz + o);
+        yy[u] = *reinterpret_cast<const f32x4*>(y + o);
+        m[u] = act != FS_ACT_NONE ? (unsigned)mask[o >> 2] : 0xFu;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[u][j] = ((m[u] >> j) & 1u) ? g[u][j] : 0.f;
+        finish(r + u * step, g[u], yy[u]);
+      }
+    }
+  }
+  for (; r < re; r += w.rpi) {
     f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * ld + c);
     if (act != FS_ACT_NONE) {
       if (mask != nullptr) {
@@ -244,15 +281,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         for (int j = 0; j < 4; ++j) g[j] *= fs_act_mask(zz[j], act);
       }
     }
-    if (dres != nullptr) *reinterpret_cast<f32x4*>(dres + r * ld + c) = g;
-    const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + r * ld + c) - mu) * is;
-    f32x4 d = ga * (g - mg - xh * mgx);
-    if (drop_thresh != 0u) {
-      const uint32_t e = (uint32_t)(r * ld + c0 + c);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) d[j] = fs_dropout_keep(e + j, drop_key, drop_thresh) ? d[j] * drop_scale : 0.f;
-    }
-    *reinterpret_cast<f32x4*>(dy + r * ld + c) = d;
+    finish(r, g, *reinterpret_cast<const f32x4*>(y + r * ld + c));
   }
 }
 
@@ -539,9 +568,11 @@ int fs_bn_act_fwd(const float* y, const float* mean, const float* invstd, const 
 // Backward of out = act(bn(y) + res).  training=1: batch statistics (sum terms); 0: running stats.
 // dy = gradient w.r.t. the (dropped-out) conv output, multiplied by the dropout mask when
 // drop_p > 0; dres (nullable) = gradient w.r.t. res; dgamma/dbeta overwritten.
+static const int g_bn_reverse = [] { const char* e = getenv("FS_BN_REVERSE"); return (e && e[0] == '0') ? 0 : 1; }();
+
 int fs_bn_act_bwd(const float* dz, const float* z, const unsigned char* mask, const float* y, const float* mean, const float* invstd,
                   const float* gamma, long M, int C, int act, int training, float drop_p, uint32_t drop_key, float* dy,
-                  float* dres, float* dgamma, float* dbeta, double* sums, hipStream_t stream) {
+                  float* dres, float* dgamma, float* dbeta, double* sums, int accumulate_affine, hipStream_t stream) {
   FS_REQUIRE(dz && y && mean && invstd && gamma && dy && dgamma && dbeta && sums && M > 0 && C % 4 == 0);
   FS_REQUIRE(act == FS_ACT_NONE || z != nullptr || mask != nullptr);
   hipError_t e = hipMemsetAsync(sums, 0, 2 * C * sizeof(double), stream);
@@ -556,7 +587,7 @@ int fs_bn_act_bwd(const float* dz, const float* z, const unsigned char* mask, co
     FS_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, stream, dz + c0, z ? z + c0 : nullptr,
                        mask ? mask + c0 / 4 : nullptr, y + c0, mean + c0, invstd + c0, gamma + c0, sums + c0, M, Cc, C, C, c0, rpb, act, training, scale, thresh, drop_key,
-                       dy + c0, dres ? dres + c0 : nullptr, dgamma + c0, dbeta + c0);
+                       dy + c0, dres ? dres + c0 : nullptr, dgamma + c0, dbeta + c0, accumulate_affine, g_bn_reverse);
     FS_LAUNCH_CHECK();
   }
   return FS_OK;

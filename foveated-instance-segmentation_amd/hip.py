@@ -43,7 +43,7 @@ SIGNATURES = {
     "fs_bn_finalize_slab": "piliffpppp",
     "fs_bn_eval_prepare": "ppifpp",
     "fs_bn_act_fwd": "pppppppplii",
-    "fs_bn_act_bwd": "pppppppliiifuppppp",
+    "fs_bn_act_bwd": "pppppppliiifupppppi",
     "fs_hr_fuse_fwd": "pppipiiiii",
     "fs_relu_bwd": "pppl",
     "fs_upsample_slice_fwd": "piiiipiiii",

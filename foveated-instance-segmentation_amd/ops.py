@@ -194,10 +194,10 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1, w_amax=None):
     return dx
 
 
-# When True (set by train.create_optimizers), weight/affine gradients are written straight into the
-# pre-allocated `.grad` views of the flat gradient arena and the autograd function returns None for
-# them: no temporary, no AccumulateGrad add.  Valid because every parameter of this model is used
-# exactly once per backward and the arena is re-zeroed every step (train_step).
+# When True (set by train.create_optimizers), weight/affine gradients are ADDED straight into the
+# pre-allocated `.grad` views of the flat gradient arena (conv weights and BatchNorm affines alike) and
+# the autograd function returns None for them: no temporary, no AccumulateGrad add.  The arena is
+# zeroed once per step (optimizer.zero_grad), so repeated backwards accumulate exactly like `.grad`.
 DIRECT_GRAD = False
 
 
@@ -362,7 +362,7 @@ class ConvBnAct(Function):
         _launch("bn_bwd", 4.0 * M * C * (3 + m["has_res"]) + (M * C // 4 if amask is not None else 0),
                 "fs_bn_act_bwd", hip.ptr(dz), hip.ptr(z), hip.ptr(amask), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), M, C,
                 m["act"], 1 if m["training"] else 0, float(m["drop_p"]), int(m["drop_key"]), hip.ptr(dy), hip.ptr(dres),
-                hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums))
+                hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums), 1 if direct_affine else 0)
         tgt = _direct_grad_target(w)
         if not WGRAD_FIRST:
             dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax) if ctx.needs_input_grad[0] else None

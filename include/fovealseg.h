@@ -145,10 +145,11 @@ int fs_bn_eval_prepare(const float* running_mean, const float* running_var, int 
  * backward passes read one byte instead of four floats of `out`.  models/hrnetv2_nodownsp.py:51-52,56-62. */
 int fs_bn_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* res,
                   float* out, unsigned char* mask, long M, int C, int act, fs_stream_t stream);
-/* Backward of the above; the activation derivative comes from `mask` when given, else from z (= out). */
+/* Backward of the above; the activation derivative comes from `mask` when given, else from z (= out).
+ * accumulate_affine != 0: dgamma / dbeta are ADDED to (gradient-arena targets, like fs_conv2d_bwd_weight's accumulate), else overwritten. */
 int fs_bn_act_bwd(const float* dz, const float* z, const unsigned char* mask, const float* y, const float* mean, const float* invstd, const float* gamma,
                   long M, int C, int act, int training, float drop_p, uint32_t drop_key, float* dy, float* dres, float* dgamma,
-                  float* dbeta, double* sums, fs_stream_t stream);
+                  float* dbeta, double* sums, int accumulate_affine, fs_stream_t stream);
 
 /* ---- HRNet multi-resolution fuse / concat ------------------------------------------------------ */
 /* out = [relu](sum_t up(terms[t])), terms at (th[t],tw[t]) bilinearly up-sampled (align_corners=False).

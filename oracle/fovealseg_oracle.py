@@ -51,14 +51,27 @@ def _site(mod: nn.Module, leaf: str) -> str:
     return (base + "." + leaf).strip(".")
 
 
+class _MaskedPass(torch.autograd.Function):
+    """t where mask else 0, forward and backward; keeps only the bool mask (1 byte per element) for the backward."""
+
+    @staticmethod
+    def forward(ctx, t, mask):
+        ctx.save_for_backward(mask)
+        return torch.where(mask, t, torch.zeros((), dtype=t.dtype))
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return torch.where(mask, g, torch.zeros((), dtype=g.dtype)), None
+
+
 def _relu(name: str, t: torch.Tensor, six: bool = False) -> torch.Tensor:
     if ACT_REPLAY is None or name not in ACT_REPLAY:
         return F.relu6(t) if six else F.relu(t)
-    m = ACT_REPLAY[name].to(t.dtype)
+    out = _MaskedPass.apply(t, ACT_REPLAY[name])
     if six:
-        hi = ACT_REPLAY_HI[name].to(t.dtype)
-        return t * m + 6.0 * hi
-    return t * m
+        out = out + 6.0 * ACT_REPLAY_HI[name].to(t.dtype)
+    return out
 
 
 class ORelu(nn.Module):
@@ -353,7 +366,11 @@ class OClsNet(nn.Module):
 
     def forward(self, x):
         x = self.layer3(self.layer2(x))
-        x = F.avg_pool2d(x, (10, 10), stride=1)
+        if tuple(x.shape[-2:]) == (10, 10):
+            x = F.avg_pool2d(x, (10, 10), stride=1)          # the reference: AvgPool2d((10,10)) -> FC(512), 80x80 inputs only
+        else:
+            # other input sizes fail in the reference (model_utils.py:254-255); the build pools globally (DESIGN.md "Divergences")
+            x = x.mean((2, 3), keepdim=True)
         return self.fc(x.view(x.size(0), -1))
 
 

@@ -46,7 +46,7 @@ def main():
             tf = timed(lambda: hip.call("fs_bn_act_fwd", hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(beta), hip.ptr(r),
                                         hip.ptr(z), hip.ptr(mask), M, C, 1), reps)
             tb = timed(lambda: hip.call("fs_bn_act_bwd", hip.ptr(dz), None, hip.ptr(mask), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma),
-                                        M, C, 1, 1, 0.3, 77, hip.ptr(dy), hip.ptr(dr), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums)), reps)
+                                        M, C, 1, 1, 0.3, 77, hip.ptr(dy), hip.ptr(dr), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums), 0), reps)
             bf = 4.0 * M * C * (2 + has_res) + M * C / 4
             bb = 4.0 * M * C * (5 + has_res) + 2 * M * C / 4
             out.append(f"res={int(has_res)} fwd {tf:6.1f} us {bf / tf / 1e3:6.0f} GB/s | bwd {tb:6.1f} us {bb / tb / 1e3:6.0f} GB/s")
