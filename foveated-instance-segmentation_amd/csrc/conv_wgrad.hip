@@ -47,16 +47,28 @@ struct WgArgs {
   unsigned x_bytes, dy_bytes;
 };
 
-template <class P, int NR, int NS>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
+// NG = patch streams ("groups" of 4 waves) per workgroup.  NG = 1: 256 threads, two workgroups per CU.  NG = 2: 512 threads, one
+// workgroup per CU whose two groups take alternate patches of the workgroup's range and add their accumulators through LDS before
+// the split-K atomics: the same 8 waves per CU feed the matrix cores, but only half as many partial tiles reach the L2 atomic
+// units (256 x 147 KB instead of 512 x 147 KB per 3x3 launch; the atomics were a third of this kernel's time).
+template <class P, int NR, int NS, int NG>
+__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void conv_wgrad_class_kernel(WgArgs a) {
   typedef typename P::x8 X8;
   typedef typename P::x4 X4;
   constexpr int NT = NR * NS, NPL = P::NPL;
-  __shared__ __attribute__((aligned(16))) unsigned char Xl[NPL * X_PLANE];
-  __shared__ __attribute__((aligned(16))) unsigned char Yl[NPL * Y_PLANE];
-  __shared__ unsigned amax_cell[2][2];      // [patch parity][X, dY]
+  constexpr int GROUP_LDS = NPL * (X_PLANE + Y_PLANE);
+  constexpr int XCHG = NG == 2 ? NT * 4 * 16 * 64 * 4 : 0;                 // [tap][wave][reg][lane] floats of one group
+  constexpr int LDS_BYTES = NG * GROUP_LDS > XCHG ? NG * GROUP_LDS : XCHG;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  __shared__ unsigned amax_cells[NG][2][2];      // [group][patch parity][X, dY]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = NG == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // wave-uniform
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  // the group's operand images start at byte gx (X planes) / gy (dY planes) of `lds`; folded into the precomputed offsets below
+  const int gx = grp * GROUP_LDS, gy = gx + NPL * X_PLANE;
+  unsigned char* const Xl = lds;
+  unsigned char* const Yl = lds;
+  unsigned (*amax_cell)[2] = amax_cells[grp];
   const int wm = wave >> 1, wn = wave & 1;
   const int ntile = a.tiles_ci * a.tiles_co;
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous range so the
@@ -88,8 +100,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
     const int py = p / a.Pw, px = p - py * a.Pw;
     ycode[i] = (p < npix && co0 + 4 * cq < a.Cout) ? ((py << 16) | px) : -1;
   }
-  const int xw = (cq >> 3) * X_HALF + (tid >> 4) * 64 + (cq & 7) * 8;     // + i*1024 + plane*X_PLANE
-  const int yw = (cq >> 3) * Y_HALF + (tid >> 4) * 64 + (cq & 7) * 8;     // + i*1024 + plane*Y_PLANE
+  const int xw = gx + (cq >> 3) * X_HALF + (tid >> 4) * 64 + (cq & 7) * 8;     // + i*1024 + plane*X_PLANE
+  const int yw = gy + (cq >> 3) * Y_HALF + (tid >> 4) * 64 + (cq & 7) * 8;     // + i*1024 + plane*Y_PLANE
   const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.x, a.x_bytes);
   const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(a.dy, a.dy_bytes);
 
@@ -103,9 +115,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
       int pidx = 16 * ks + 8 * lh + 4 * t + q;
       if (pidx >= npix) pidx = 0;             // padded k: dY is zero there, any valid X address will do
       const int py = pidx / a.Pw, px = pidx - py * a.Pw;
-      xb[ks][t] = wm * X_HALF + (py * Wh + px) * 64 + (cb + 4 * pp) * 2;
+      xb[ks][t] = gx + wm * X_HALF + (py * Wh + px) * 64 + (cb + 4 * pp) * 2;
     }
-  const int yb = wn * Y_HALF + (8 * lh + q) * 64 + (cb + 4 * pp) * 2;      // + ks*1024 + t*256 + plane*Y_PLANE
+  const int yb = gy + wn * Y_HALF + (8 * lh + q) * 64 + (cb + 4 * pp) * 2;      // + ks*1024 + t*256 + plane*Y_PLANE
   const int rowoff1 = Wh * 64;
 
   f32x16 acc[NT];
@@ -120,7 +132,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
   __syncthreads();
   int E = 2 * EMIN - 1, par = 0;
 
-  for (int patch = p_begin; patch < p_end; ++patch) {
+  const int niter = (p_end - p_begin + NG - 1) / NG;
+  for (int it = 0; it < niter; ++it) {
+    // group g takes patches p_begin + g, + NG, ...; a group without a patch in the last round runs it on zeros (same barriers)
+    const int patch_raw = p_begin + it * NG + grp;
+    const bool pvalid = patch_raw < p_end;
+    const int patch = pvalid ? patch_raw : p_begin;
     const int b = patch / tpi;
     const int trem = patch - b * tpi;
     const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
@@ -131,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
     for (int i = 0; i < NXI; ++i) {
       const int hy = xcode[i] >> 16, hx = xcode[i] & 0xffff;
       const int iy = a.sm * (y0 + hy) + a.cy, ix = a.sm * (x0 + hx) + a.cx;
-      const bool ok = xcode[i] >= 0 && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx;
+      const bool ok = pvalid && xcode[i] >= 0 && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx;
       const unsigned off = (unsigned)(((b * a.Hx + iy) * a.Wx + ix) * a.Cin + ci0 + 4 * cq) * 4u;
       rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? (int)off : (int)OOB, 0, 0));
     }
@@ -139,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
     for (int i = 0; i < NYI; ++i) {
       const int py = ycode[i] >> 16, px = ycode[i] & 0xffff;
       const int y = y0 + py, x = x0 + px;
-      const bool ok = ycode[i] >= 0 && y < a.H && x < a.W;
+      const bool ok = pvalid && ycode[i] >= 0 && y < a.H && x < a.W;
       const unsigned off = (unsigned)(((b * a.H + y) * a.W + x) * a.Cout + co0 + 4 * cq) * 4u;
       ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, ok ? (int)off : (int)OOB, 0, 0));
     }
@@ -231,6 +248,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
   const int co = co0 + 32 * wn + (lane & 31);
   const int Eo = E - 28;                                   // two factors: the combined exponent can leave the float range
   const float fo1 = P::SCALED ? pow2f(Eo / 2) : 1.f, fo2 = P::SCALED ? pow2f(Eo - Eo / 2) : 1.f;
+  if (NG == 2) {
+    // group 1 hands its (already unscaled) accumulators to group 0 through LDS: [tap][wave][reg][lane], lane-contiguous
+    __syncthreads();                                       // every wave is done with the operand images
+    float* xw_ = reinterpret_cast<float*>(lds);
+    if (grp == 1) {
+#pragma unroll
+      for (int tap = 0; tap < NT; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xw_[((tap * 4 + wave) * 16 + r) * 64 + lane] = acc[tap][r] * fo1 * fo2;
+    }
+    __syncthreads();
+    if (grp == 1) return;
+  }
+  const float* xch = reinterpret_cast<const float*>(lds);
   if (co < a.Cout && p_begin < p_end) {
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
@@ -239,7 +270,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (ci < a.Cin) atomicAdd(&a.dw[(ftap * a.Cin + ci) * a.Cout + co], acc[tap][r] * fo1 * fo2);
+        float v = acc[tap][r] * fo1 * fo2;
+        if (NG == 2) v += xch[((tap * 4 + wave) * 16 + r) * 64 + lane];
+        if (ci < a.Cin) atomicAdd(&a.dw[(ftap * a.Cin + ci) * a.Cout + co], v);
       }
     }
   }
@@ -267,20 +300,33 @@ void choose_wgrad_patch(int H, int W, int NR, int NS, int& Ph, int& Pw) {
 }  // namespace
 
 namespace {
+// FS_WGRAD_GROUPS=2 selects the two-group variant for the 9-tap class.  Measured (profiles/r02/wgrad_groups_ab.txt): alone it is
+// 7 % faster in f16x2 (145 -> 134 us on 64->64 @ 80x80; half the atomic traffic) and +-0 in bf16x3, but in the training step it is
+// 0.5-1.5 % SLOWER in both modes (one 512-thread workgroup with 147 KB of LDS per CU leaves no room for the other streams'
+// workgroups to fill this kernel's load phases), so the default stays one group per workgroup.
+static const int g_wgrad_groups = [] { const char* e = getenv("FS_WGRAD_GROUPS"); return (e && e[0] == '2') ? 2 : 1; }();
+
 template <class P, int NR, int NS>
 int launch_class(WgArgs a, int ntile, hipStream_t stream) {
   choose_wgrad_patch(a.H, a.W, NR, NS, a.Ph, a.Pw);
   a.tiles_y = cdiv(a.H, a.Ph); a.tiles_x = cdiv(a.W, a.Pw);
   a.npatch = a.B * a.tiles_y * a.tiles_x;
-  // two workgroups fit per CU (LDS, registers): one full round of 512 workgroups, never a short second round.
+  // 512 patch streams = 8 waves on every CU, never a short second round: 512 workgroups of one group (two per CU), or -- 9-tap
+  // class with FS_WGRAD_GROUPS=2 -- 256 workgroups of two groups (half the split-K atomics).
   // (A wave-specialised variant -- 4 producer + 4 consumer waves, double-buffered LDS, one workgroup per CU -- measured
   // +14 % on this kernel alone and -1 % on the training step, where kernels of other HRNet branches share the CUs.)
-  int nsplit = 512 / ntile;
+  const int ng = (NR * NS == 9 && g_wgrad_groups == 2) ? 2 : 1;
+  int nsplit = (512 / ng) / ntile;
   if (nsplit < 1) nsplit = 1;
-  if (nsplit > a.npatch) nsplit = a.npatch;
+  if (nsplit > cdiv(a.npatch, ng)) nsplit = cdiv(a.npatch, ng);
   a.patches_per_split = cdiv(a.npatch, nsplit);
   nsplit = cdiv(a.npatch, a.patches_per_split);
-  hipLaunchKernelGGL((conv_wgrad_class_kernel<P, NR, NS>), dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
+  if (ng == 2) {
+    if constexpr (NR * NS == 9)
+      hipLaunchKernelGGL((conv_wgrad_class_kernel<P, NR, NS, 2>), dim3((unsigned)(ntile * nsplit)), dim3(512), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((conv_wgrad_class_kernel<P, NR, NS, 1>), dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
+  }
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
