@@ -298,16 +298,17 @@ def main():
 
 # Front-end / loss / optimiser kernels (HBM or gather-latency bound): timer kind -> description
 FRONTEND_KINDS = {
-    "fe_gaze_lowres": "gaze_lowres_kernel (K1: bilinear 1024^2 -> 80^2 taps + gaze map)",
-    "fe_area_pool": "area_pool_kernel (K3: label 1024^2 -> 80^2 area pooling, the only full-resolution pass)",
-    "fe_gauss_grid_fwd": "gauss_grid_fwd_kernel (K4: separable Gaussian saliency accumulation -> grid)",
-    "fe_gauss_grid_bwd": "gauss_grid_bwd_kernel",
-    "fe_grid_sample_fwd": "grid_sample_fwd_kernel (K5: foveated bilinear gather of the image)",
-    "fe_grid_sample_label": "grid_sample_label_kernel (K5: label gather + truncation)",
-    "fe_grid_sample_bwd_grid": "grid_sample_bwd_grid_kernel (K6: d loss / d grid)",
-    "fe_seg_loss_fwd": "seg_loss_fwd_kernel (K10/K11: Focal + Dice + accuracies over pred)",
-    "fe_seg_loss_bwd": "seg_loss_bwd_kernel",
-    "fe_adam": "adam_kernel (one launch per arena; 16 B read + 12 B written per parameter)",
+    # timer kind: (kernel name in the rocprofv3 tables, description)
+    "fe_gaze_lowres": ("gaze_lowres_kernel", "K1: bilinear 1024^2 -> 80^2 taps + gaze map (gather: 4 taps per output)"),
+    "fe_area_pool": ("area_pool_kernel", "K3: label 1024^2 -> 80^2 area pooling, the only full-resolution pass"),
+    "fe_gauss_grid_fwd": ("gauss_grid_fwd_kernel", "K4: separable 91-tap Gaussian saliency accumulation -> grid (arithmetic-bound: 3 x 2 x 91 fp64 FMAs per grid point)"),
+    "fe_gauss_grid_bwd": ("gauss_grid_bwd_kernel", "K4 backward"),
+    "fe_grid_sample_fwd": ("grid_sample_fwd_kernel", "K5: foveated bilinear gather of the image (4 taps x 3 planes per output, one 64-B sector each)"),
+    "fe_grid_sample_label": ("grid_sample_label_kernel", "K5: label gather + truncation"),
+    "fe_grid_sample_bwd_grid": ("grid_sample_bwd_grid_kernel", "K6: d loss / d grid"),
+    "fe_seg_loss_fwd": ("seg_loss_fwd_kernel", "K10/K11: Focal + Dice + accuracies over pred (3 passes over 51 classes per pixel: exp/log-bound)"),
+    "fe_seg_loss_bwd": ("seg_loss_bwd_kernel", "K10/K11 backward"),
+    "fe_adam": ("adam_kernel", "one launch per arena; 16 B read + 12 B written per parameter"),
 }
 
 
@@ -364,13 +365,18 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
         out["roofline_bn_bwd"] = hbm_entry(summ["bn_bwd"], "BatchNorm + activation backward (one C-ABI call; algorithmic bytes = dz, conv output and mask read once, "
                                            "dy [and the residual gradient] written once)", ["bn_bwd_reduce_kernel", "bn_bwd_apply_kernel"])
     fe = {}
-    for kind, desc in FRONTEND_KINDS.items():
+    for kind, (kname, desc) in FRONTEND_KINDS.items():
         if kind in summ:
             kk = summ[kind]
             gbs = kk["flops"] / (kk["total_ms"] * 1e-3) / 1e9
-            fe[kind[3:]] = {"kernel": desc, "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4),
-                            "avg_launch_us": round(1000.0 * kk["total_ms"] / kk["launches"], 2), "mb_per_launch": round(kk["flops"] / kk["launches"] / 1e6, 3),
-                            "launches_per_step": kk["launches"] // nsteps}
+            us = 1000.0 * kk["total_ms"] / kk["launches"]
+            fe[kind[3:]] = {"kernel": f"{kname} ({desc})", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(us, 2),
+                            "mb_per_launch": round(kk["flops"] / kk["launches"] / 1e6, 3), "launches_per_step": kk["launches"] // nsteps}
+            tr = _profiled_traffic(kname)
+            if tr is not None:            # what actually crossed the fabric (64-B sectors of a gather, re-reads): counter bytes / launch time
+                fe[kind[3:]]["traffic"] = tr
+                fe[kind[3:]]["traffic_gbs"] = round(tr["hbm_bytes_per_launch"] / (us * 1e-6) / 1e9, 1)
     if fe:
         fe["note"] = "algorithmic bytes (SURVEY.md 8(d)): every operand element the kernel needs read once, every result written once; the gather kernels touch 4 taps per output"
         out["frontend"] = fe

@@ -124,60 +124,104 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
   const int bg = K - 1;
   double focal = 0.0;
   float cnt[6] = {0, 0, 0, 0, 0, 0};
-  // every lane of a wave makes the same number of trips (inactive pixels contribute zeros): the per-class probability sums
-  // are reduced across the wave in registers, so LDS sees one atomic per wave and class instead of one per lane
+  // per-class probability sums stay in registers over the thread's pixels (KMAX floats per lane) and are reduced across the
+  // wave ONCE after the loop: one LDS atomic per wave and class, instead of a 6-step shuffle tree per class and pixel
   const int lane = threadIdx.x & 63;
+  float spl[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) spl[k] = 0.f;
   for (int p0 = chunk * blockDim.x; p0 < HW; p0 += blocks_per_img * blockDim.x) {
     const int p = p0 + threadIdx.x;
-    const bool live = p < HW;
-    const int pc = live ? p : HW - 1;
-    const int t = (int)gt[(long)b * HW + pc];
+    if (p >= HW) continue;
+    const int t = (int)gt[(long)b * HW + p];
+    // the pixel's K logits are loaded ONCE, all loads in flight together (a runtime-K loop of load -> compare made every one of
+    // the 3 x 51 loads wait for the previous: 36 us of pure latency per pixel), and the three passes run on registers
+    float v[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) v[k] = k < K ? pb[(long)k * HW + p] : -INFINITY;
     float mx = -INFINITY; int am = 0;
-    for (int k = 0; k < K; ++k) { const float v = pb[(long)k * HW + pc]; if (v > mx) { mx = v; am = k; } }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) if (v[k] > mx) { mx = v[k]; am = k; }
     float se = 0.f;
-    for (int k = 0; k < K; ++k) se += expf(pb[(long)k * HW + pc] - mx);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) if (k < K) se += expf(v[k] - mx);
     const float lse = logf(se);
-    for (int k = 0; k < K; ++k) {
-      const float pk = live ? expf(pb[(long)k * HW + pc] - mx - lse) : 0.f;
-      const float ws = wave_sum(pk);
-      if (lane == 0) atomicAdd(&sp[k], ws);
-      if (live && k == t) { atomicAdd(&si[k], pk); atomicAdd(&sc[k], 1.f); }
+    float vt = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        const float pk = expf(v[k] - mx - lse);
+        spl[k] += pk;
+        if (k == t) { atomicAdd(&si[k], pk); atomicAdd(&sc[k], 1.f); vt = v[k]; }
+      }
     }
-    if (!live) continue;
-    const float logpt = pb[(long)t * HW + p] - mx - lse;
+    const float logpt = vt - mx - lse;
     const float pt = expf(logpt);
     focal += (double)(-powf(1.f - pt, gamma) * logpt);
     const bool vg = t < bg, vp = am < bg, bgg = t == bg, bgp = am == bg, eq = am == t;
     cnt[0] += (vg && eq); cnt[1] += (vg && (vg == vp)); cnt[2] += (vg || vp);
     cnt[3] += (bgg && eq); cnt[4] += (bgg && (bgg == bgp)); cnt[5] += (bgg || bgp);
   }
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    if (k < K) {
+      const float ws = wave_sum(spl[k]);
+      if (lane == 0) atomicAdd(&sp[k], ws);
+    }
+  }
   __syncthreads();
+  // this workgroup's record [3K + 1 + 6]: plain stores, summed by the finalize kernel -- no zero-initialisation of the scratch and no
+  // same-address double atomics from every workgroup
+  double* rec = accum + (long)blockIdx.x * (3 * K + 7);
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    atomicAdd(&accum[k], (double)sp[k]);
-    atomicAdd(&accum[K + k], (double)si[k]);
-    atomicAdd(&accum[2 * K + k], (double)sc[k]);
+    rec[k] = (double)sp[k];
+    rec[K + k] = (double)si[k];
+    rec[2 * K + k] = (double)sc[k];
   }
   focal = block_sum<double>(focal, dred);
-  if (threadIdx.x == 0) atomicAdd(&accum[3 * K], focal);
+  if (threadIdx.x == 0) rec[3 * K] = focal;
   for (int j = 0; j < 6; ++j) {
     const double v = block_sum<double>((double)cnt[j], dred);
-    if (threadIdx.x == 0) atomicAdd(&accum[3 * K + 1 + b * 6 + j], v);
+    if (threadIdx.x == 0) rec[3 * K + 1 + j] = v;
   }
 }
 
 // out[0]=dice+focal, out[1]=focal, out[2]=dice, out[3..6]=acc, acc_bin_fg, acc_cls_fbg, acc_bin_fbg
 // coef (2K floats): A_k = present/K * 2 I/Kc^2, B_k = -present/K * 2/Kc  (for the backward)
-__global__ void seg_loss_finalize_kernel(const double* __restrict__ accum, int B, int K, int HW, float eps,
-                                         float* __restrict__ out, float* __restrict__ coef) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double dice = 0.0;
-  for (int k = 0; k < K; ++k) {
-    const float I = (float)accum[K + k];
-    const float card = (float)accum[k] + (float)accum[2 * K + k];
-    const bool present = accum[2 * K + k] > 0.0;
+// accum = [B * blocks_per_img] records of (3K + 7) doubles (seg_loss_fwd_kernel); one workgroup sums them and finalises
+__global__ __launch_bounds__(1024) void seg_loss_finalize_kernel(const double* __restrict__ accum, int B, int K, int HW, int blocks_per_img,
+                                                                 float eps, float* __restrict__ out, float* __restrict__ coef) {
+  __shared__ double tot[3 * KMAX + 1];
+  __shared__ double img[4][16];
+  const int R = 3 * K + 7, nrec = B * blocks_per_img;
+  // column sums over the records: wave w takes entries w, w + 16, ...; its lanes stride over the records
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int e = wv; e < 3 * K + 1; e += nw) {
+    double s = 0.0;
+    for (int i = lane; i < nrec; i += 64) s += accum[(long)i * R + e];
+    s = wave_sum_d(s);
+    if (lane == 0) tot[e] = s;
+  }
+  // per-image accuracies: thread b sums the six counters of its image's records
+  double a[4] = {0, 0, 0, 0};
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    double c[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < blocks_per_img; ++j)
+      for (int q = 0; q < 6; ++q) c[q] += accum[(long)(b * blocks_per_img + j) * R + 3 * K + 1 + q];
+    const float ufg = (float)c[2] + 1e-10f, ubg = (float)c[5] + 1e-10f;
+    const float cls_fg = (float)c[0] / ufg, bin_fg = (float)c[1] / ufg, cls_bg = (float)c[3] / ubg, bin_bg = (float)c[4] / ubg;
+    a[0] += cls_fg; a[1] += bin_fg; a[2] += cls_fg * 0.5f + cls_bg * 0.5f; a[3] += bin_fg * 0.5f + bin_bg * 0.5f;
+  }
+  for (int j = 0; j < 4; ++j) a[j] = block_sum<double>(a[j], img[j]);
+  __syncthreads();
+  double lk = 0.0;
+  if (threadIdx.x < K) {
+    const int k = threadIdx.x;
+    const float I = (float)tot[K + k];
+    const float card = (float)tot[k] + (float)tot[2 * K + k];
+    const bool present = tot[2 * K + k] > 0.0;
     const float den = fmaxf(card, eps);
-    const float l = present ? 1.f - 2.f * I / den : 0.f;
-    dice += (double)l;
+    lk = present ? (double)(1.f - 2.f * I / den) : 0.0;
     float A = 0.f, Bc = 0.f;
     if (present) {
       Bc = -2.f / den / (float)K;
@@ -185,15 +229,10 @@ __global__ void seg_loss_finalize_kernel(const double* __restrict__ accum, int B
     }
     coef[k] = A; coef[K + k] = Bc;
   }
+  const double dice = block_sum<double>(lk, img[0]);
+  if (threadIdx.x != 0) return;
   const float dl = (float)(dice / (double)K);
-  const float fl = (float)(accum[3 * K] / ((double)B * HW));
-  double a[4] = {0, 0, 0, 0};
-  for (int b = 0; b < B; ++b) {
-    const double* c = accum + 3 * K + 1 + b * 6;
-    const float ufg = (float)c[2] + 1e-10f, ubg = (float)c[5] + 1e-10f;
-    const float cls_fg = (float)c[0] / ufg, bin_fg = (float)c[1] / ufg, cls_bg = (float)c[3] / ubg, bin_bg = (float)c[4] / ubg;
-    a[0] += cls_fg; a[1] += bin_fg; a[2] += cls_fg * 0.5f + cls_bg * 0.5f; a[3] += bin_fg * 0.5f + bin_bg * 0.5f;
-  }
+  const float fl = (float)(tot[3 * K] / ((double)B * HW));
   out[0] = dl + fl; out[1] = fl; out[2] = dl;
   for (int j = 0; j < 4; ++j) out[3 + j] = (float)(a[j] / (double)B);
 }
@@ -279,12 +318,10 @@ int fs_pred_assemble_bwd(const float* dpred, const float* cls, const float* m, f
 int fs_seg_loss_fwd(const float* pred, const long long* gt, int B, int K, int HW, float gamma, float eps, double* accum,
                     float* out, float* coef, hipStream_t stream) {
   FS_REQUIRE(pred && gt && accum && out && coef && B > 0 && K > 1 && K <= KMAX && HW > 0);
-  hipError_t e = hipMemsetAsync(accum, 0, (3 * K + 1 + 6 * B) * sizeof(double), stream);
-  if (e != hipSuccess) return (int)e;
-  int bpi = cdiv(HW, 1024); if (bpi < 1) bpi = 1;
+  const int bpi = cdiv(HW, 1024);           // = the record count the header documents: B * ceil(HW / 1024)
   hipLaunchKernelGGL(seg_loss_fwd_kernel, dim3(B * bpi), dim3(256), 0, stream, pred, gt, accum, K, HW, bpi, gamma);
   FS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(64), 0, stream, accum, B, K, HW, eps, out, coef);
+  hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(1024), 0, stream, accum, B, K, HW, bpi, eps, out, coef);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

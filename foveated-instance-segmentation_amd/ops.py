@@ -602,7 +602,7 @@ class SegLoss(Function):
     @staticmethod
     def forward(ctx, pred, gt, gamma):
         B, K, H, W = pred.shape
-        accum = torch.empty(3 * K + 1 + 6 * B, device=pred.device, dtype=torch.float64)
+        accum = torch.empty(B * ((H * W + 1023) // 1024) * (3 * K + 7), device=pred.device, dtype=torch.float64)
         out = torch.empty(7, device=pred.device, dtype=torch.float32)
         coef = torch.empty(2 * K, device=pred.device, dtype=torch.float32)
         _launch("fe_seg_loss_fwd", 4.0 * B * H * W * (K + 2), "fs_seg_loss_fwd", hip.ptr(pred), hip.ptr(gt), B, K, H * W, float(gamma), 1e-7, hip.ptr(accum), hip.ptr(out),

@@ -185,7 +185,8 @@ int fs_pred_assemble_fwd(const float* cls, const float* m, float* pred, int B, i
 int fs_pred_assemble_bwd(const float* dpred, const float* cls, const float* m, float* dcls, float* dm, int B, int K, int HW,
                          fs_stream_t stream);
 /* out[7] = {dice+focal, focal, dice, acc, acc_bin_fg, acc_cls_fbg, acc_bin_fbg}; models/models.py:87-120,378-474,1057-1078.
- * accum = (3K+1+6B) doubles scratch, coef = 2K floats kept for the backward. */
+ * accum = B * ceil(HW/1024) * (3K+7) doubles of scratch (one record per workgroup, no initialisation needed),
+ * coef = 2K floats kept for the backward. */
 int fs_seg_loss_fwd(const float* pred, const long long* gt, int B, int K, int HW, float gamma, float eps, double* accum,
                     float* out, float* coef, fs_stream_t stream);
 int fs_seg_loss_bwd(const float* pred, const long long* gt, const float* coef, const float* gout, float* dpred, int B, int K,
