@@ -1490,3 +1490,32 @@ def test_config4_deeplab_2048():
     for n, p_ in module.named_parameters():
         if p_.requires_grad:
             assert p_.grad is not None and bool(torch.isfinite(p_.grad).all()), n
+
+
+def test_config2_hrnet_640_per_gpu_shape():
+    """BASELINE configs[2] at its per-GPU shape: HRNetV2, LVIS-50 'sp60000' geometry (640x640 zero-padded frames), batch 32 per
+    GPU (256 global over 8 ranks; the ranks differ only in their shard, tests/test_ddp_gloo.py covers the exchange).  One full
+    optimisation step through train_step in the headline arithmetic, then the evaluation caller on the same batch."""
+    from fovealseg import train
+    fovealseg.hip.set_conv_precision("bf16x3")
+    try:
+        cfg = fovealseg.lvis50_cfg()
+        module, nets = train.build_module(cfg, device=DEV)
+        module.train()
+        opts = train.create_optimizers(nets, cfg)
+        try:
+            batch = train.synthetic_batch(32, 640, 640, seed=2, device=DEV)
+            p0 = opts[0].flat.data.clone()
+            out = train.train_step(module, opts, batch, cfg, epoch=1, cur_iter=0)
+            torch.cuda.synchronize()
+            loss, acc, edge = (float(o.detach()) for o in out)
+            assert np.isfinite(loss) and np.isfinite(edge) and 0.0 <= acc <= 1.0
+            assert bool(torch.isfinite(opts[0].flat.grad).all()) and float(opts[0].flat.grad.abs().max()) > 0
+            assert float((opts[0].flat.data - p0).abs().max()) > 0            # the encoder arena stepped
+            module.eval()
+            outs = train.eval_step(module, batch)
+            assert len(outs) == 6 and all(np.isfinite(float(o)) for o in outs)
+        finally:
+            ops.DIRECT_GRAD = False
+    finally:
+        fovealseg.hip.set_conv_precision("f16x2")
