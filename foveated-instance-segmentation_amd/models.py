@@ -116,11 +116,13 @@ class DeformSegmentationModule(nn.Module):
 
     def _check_cfg(self):
         c = self.cfg
-        off = [("MODEL.upsample", c.MODEL.upsample), ("MODEL.loss_at_high_res", c.MODEL.loss_at_high_res),
+        off = [("MODEL.loss_at_high_res", c.MODEL.loss_at_high_res),
                ("MODEL.gt_gradient", c.MODEL.gt_gradient), ("TRAIN.opt_deform_LabelEdge", c.TRAIN.opt_deform_LabelEdge)]
         for name, val in off:
             if val:
                 raise NotImplementedError(f"{name}=True is outside the built hot path (SURVEY.md Appendix A)")
+        if c.MODEL.upsample and c.MODEL.rev_deform_interp != "nearest":
+            raise NotImplementedError("MODEL.upsample needs rev_deform_interp='nearest' (the reference's 'tri' default calls an undefined name)")
         if c.MODEL.uniform_sample != "":
             raise NotImplementedError("MODEL.uniform_sample must be '' (learned sampling)")
         if c.TRAIN.def_saliency_pad_mode != "replication":
@@ -191,10 +193,22 @@ class DeformSegmentationModule(nn.Module):
         if joint:
             loss = loss + edge_loss
         acc = out[3].detach()
+        accs = (out[4].detach(), out[5].detach(), out[6].detach())
+        if cfg.MODEL.upsample:
+            # models/models.py:869-873,933-940,1074-1083: the loss stays at the sampled resolution, the four accuracies are taken at
+            # FULL resolution on the prediction warped back through the inverse grid (never-claimed pixels filled from their
+            # nearest claimed neighbour) against the original label map.  No gradient flows through this branch.
+            with torch.no_grad():
+                Hf, Wf = int(y.shape[2]), int(y.shape[3])
+                pred_full, _hole = ops.unwarp_nearest(pred.detach().contiguous(), grid.detach(), Hf, Wf)
+                y_hs = y[:, 0].long()
+                gt_hs = y_hs * cls[:, :, None] + (1 - y_hs) * (cfg.DATASET.num_class - 1)
+                full = ops.SegLoss.apply(pred_full, gt_hs.contiguous(), 5.0)
+                acc, accs = full[3], (full[4], full[5], full[6])
         if joint:
             if not is_inference:
                 return loss, acc, edge_loss
-            return loss, acc, edge_loss, out[4].detach(), out[5].detach(), out[6].detach()
+            return loss, acc, edge_loss, accs[0], accs[1], accs[2]
         if not is_inference:
             return loss, acc
-        return loss, acc, out[4].detach(), out[5].detach(), out[6].detach()
+        return loss, acc, accs[0], accs[1], accs[2]

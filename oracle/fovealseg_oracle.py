@@ -535,8 +535,9 @@ class OracleDeformSeg(nn.Module):
         return create_grid(xs_hm, self.filter.weight, self.P_basis, self.hs, self.ws)
 
     def forward(self, feed: Dict[str, torch.Tensor], is_inference=False, drop_fn: Optional[DropFn] = None,
-                return_intermediates=False):
+                return_intermediates=False, upsample=False):
         x, y = feed["img_data"], feed["seg_label"]
+        y_full = y
         xs, x_low = self.saliency(x, feed["focus_point"])
         grid = self.grid_from_saliency(xs)
         e_loss = edge_loss(xs, y, self.hs, self.ws, self.edge_scale)
@@ -549,6 +550,14 @@ class OracleDeformSeg(nn.Module):
         gt = compose_gt(label, feed["cls_label"])
         loss = dice_loss_multiclass(pred, gt) + focal_loss(pred, gt) + e_loss      # :1057-1069
         acc = accuracies(pred, gt)
+        if upsample:
+            # MODEL.upsample (models/models.py:869-873,933-940,1074-1083): accuracies at full resolution on the prediction warped
+            # back through the inverse grid with nearest hole filling, against the original label; the loss is unchanged
+            with torch.no_grad():
+                H, W = y_full.shape[-2:]
+                pred_full, _ = unwarp_nearest_ref(pred.detach(), grid.detach(), H, W)
+                y_hs = y_full.reshape(y_full.shape[0], H, W).long()
+                acc = accuracies(pred_full, compose_gt(y_hs, feed["cls_label"]))
         inter = dict(x_low=x_low, xs=xs, grid=grid, x_sampled=x_s, label=label, feat=feat[0], pred=pred, gt=gt)
         if return_intermediates:
             return loss, acc, e_loss, inter

@@ -282,3 +282,97 @@ def test_unwarp_nearest_ragged_widths(Hs, Ws, C):
     want, whole = O.unwarp_nearest_ref(pred, grid, Hs, Ws)
     assert torch.equal(hole.cpu(), whole)
     assert torch.equal(out.cpu(), want)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# f-1, the dataset contract: fovealseg.data.PreprocessDataset against records taken from the REFERENCE class on the same
+# synthetic tree (tests/golden/make_dataset_pin.py -> g16_dataset.json / .npz)
+# ------------------------------------------------------------------------------------------------------------------
+def _dataset_pin():
+    import importlib.util
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("_make_dataset_pin", os.path.join(here, "make_dataset_pin.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)               # defines TREE / write_tree; the reference is imported only by its main()
+    with open(os.path.join(here, "g16_dataset.json")) as f:
+        pin = json.load(f)
+    assert [list(t) for t in mod.TREE] == pin["tree"]
+    return mod, pin, np.load(os.path.join(here, "g16_dataset.npz"))
+
+
+def _build_dataset(tmp_path):
+    mod, pin, arrays = _dataset_pin()
+    data_path, raw = mod.write_tree(str(tmp_path))
+    ds = data.PreprocessDataset(data_path=data_path, marker="sp60000", dataset_partition="train", dataset_name="lvis", coco_root=raw)
+    return ds, pin, arrays
+
+
+def test_preprocess_dataset_file_contract_matches_reference(tmp_path):
+    ds, pin, arrays = _build_dataset(tmp_path)
+    assert (ds.HC, ds.WC, len(ds)) == (pin["HC"], pin["WC"], pin["len"])       # 640 / 640 / 5: the reference's 'cityscpaes' typo included
+    mine = sorted(ds.data_info, key=lambda r: r["fpath_Y"])
+    keys = ("idx_H", "idx_W", "Y_cls_s", "pad_left", "pad_right", "pad_top", "pad_bottom")
+    for r, want in zip(mine, pin["data_info"]):
+        assert os.path.relpath(r["fpath_Y"], str(tmp_path)) == want["fpath_Y"]
+        assert os.path.relpath(r["fpath_X"], str(tmp_path)) == want["fpath_X"]   # incl. the val2017 / test2017 fallback lookups
+        assert {k: r[k] for k in keys} == {k: want[k] for k in keys}
+    # the CPU oracle of the ingest step (ingest_sample_ref) against the reference's own __getitem__ output for these samples
+    for r, want in zip(mine, pin["data_info"]):
+        s = ds[ds.data_info.index(r)]
+        X, F2, Y, cls = O.ingest_sample_ref(s.img.numpy(), s.mask.numpy(), s.pads, s.focus, s.frame, s.cls)
+        key = os.path.basename(r["fpath_Y"]).split(".")[0]
+        assert list(X.shape) == want["X_shape"] and list(Y.shape) == want["Y_shape"]
+        assert str(X.dtype) == want["X_dtype"] and str(Y.dtype) == want["Y_dtype"] and str(cls.dtype) == want["cls_dtype"]
+        assert np.array_equal(X[:, ::37, ::41].numpy(), arrays[key + ":Xcrop"]) and np.array_equal(Y[:, ::37, ::41].numpy(), arrays[key + ":Ycrop"])
+        assert float(X.double().sum()) == want["X_sum"] and float(Y.double().sum()) == want["Y_sum"]
+        assert np.array_equal(F2.numpy(), arrays[key + ":F2"]) and int(cls[0]) == want["cls"]
+    # batches() feeds DevicePrefetcher: lists of decoded samples, ragged tail kept
+    sizes = [len(b) for b in ds.batches(2)]
+    assert sizes == [2, 2, 1] and all(isinstance(s, data.Sample) for b in ds.batches(2) for s in b)
+
+
+@pytest.mark.gpu
+def test_preprocess_dataset_device_ingest_matches_reference(tmp_path):
+    ds, pin, arrays = _build_dataset(tmp_path)
+    mine = sorted(range(len(ds)), key=lambda i: ds.data_info[i]["fpath_Y"])
+    samples = [ds[i] for i in mine]
+    X, F2, Y, cls = data.ingest_batch(samples, device="cuda", channels=4)          # all five pad to 640 x 640: one batch
+    assert X.shape == (5, 4, 640, 640) and Y.shape == (5, 1, 640, 640) and cls.dtype == torch.int64
+    for b, want in enumerate(pin["data_info"]):
+        key = os.path.basename(want["fpath_Y"]).split(".")[0]
+        assert np.array_equal(X[b, :, ::37, ::41].cpu().numpy(), arrays[key + ":Xcrop"])      # bit-identical to the reference's floats
+        assert np.array_equal(Y[b, :, ::37, ::41].cpu().numpy(), arrays[key + ":Ycrop"])
+        assert float(X[b].double().sum()) == want["X_sum"] and float(Y[b].double().sum()) == want["Y_sum"]
+        assert np.array_equal(F2[b].cpu().numpy(), arrays[key + ":F2"]) and int(cls[b, 0]) == want["cls"]
+    # and through the prefetcher, as the training loop would consume it
+    got = list(data.DevicePrefetcher(ds.batches(5, indices=mine), device="cuda", channels=4))
+    assert len(got) == 1 and torch.equal(got[0][0], X) and torch.equal(got[0][2], Y)
+
+
+@pytest.mark.gpu
+def test_upsample_branch_full_resolution_accuracies():
+    """MODEL.upsample=True inside forward (models/models.py:869-873,933-940,1074-1083): loss at the sampled resolution, the four
+    accuracies at FULL resolution on the un-warped prediction (inverse grid + nearest fill), against the oracle's restatement."""
+    cfg = fovealseg.lvis50_cfg()
+    cfg.MODEL.upsample = True
+    module, _ = train.build_module(cfg, device="cuda")
+    module.eval()
+    o = O.OracleDeformSeg()
+    fovealseg.weights.apply_name_keyed_init(o)
+    o.eval()
+    X, Fp, Y, cls = train.synthetic_batch(2, 160, 160, seed=21, device="cpu")
+    with torch.no_grad():
+        got = module({"img_data": X.cuda(), "seg_label": Y.cuda(), "focus_point": Fp.cuda(), "cls_label": cls.cuda()}, is_inference=True)
+        ref = o({"img_data": X, "seg_label": Y.clone(), "focus_point": Fp, "cls_label": cls}, is_inference=True, upsample=True)
+        low = o({"img_data": X, "seg_label": Y.clone(), "focus_point": Fp, "cls_label": cls}, is_inference=True, upsample=False)
+    got = np.array([float(v) for v in got])
+    ref = np.array([float(v) for v in ref])
+    assert len(got) == 6
+    assert abs(got[0] - ref[0]) <= 2e-3 and abs(got[2] - ref[2]) <= 1e-5            # loss (unchanged by the branch), edge loss
+    assert np.abs(got[[1, 3, 4, 5]] - ref[[1, 3, 4, 5]]).max() <= 5e-3, (got, ref)   # full-resolution accuracies
+    assert abs(float(low[0]) - ref[0]) <= 1e-6                                        # the branch does not touch the loss
+    with pytest.raises(NotImplementedError):
+        bad = fovealseg.lvis50_cfg()
+        bad.MODEL.upsample, bad.MODEL.rev_deform_interp = True, "tri"
+        train.build_module(bad, device="cuda")
