@@ -1519,3 +1519,16 @@ def test_config2_hrnet_640_per_gpu_shape():
             ops.DIRECT_GRAD = False
     finally:
         fovealseg.hip.set_conv_precision("f16x2")
+
+
+def test_dice_known_answers_unpinned_toolbelt():
+    """The hand-derived Dice known answers (A18, toolbelt absent -> parity otherwise unpinned) through the HIP loss kernel."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_dice_unpinned.json")) as f:
+        kat = json.load(f)
+    for c in kat["cases"]:
+        pred = torch.tensor(c["logits"], dtype=torch.float32, device=DEV)
+        gt = torch.tensor(c["gt"], dtype=torch.int64, device=DEV)
+        out = ops.SegLoss.apply(pred, gt, 5.0)
+        assert abs(float(out[2]) - c["dice"]) <= 2e-7, (c["name"], float(out[2]), c["dice"])

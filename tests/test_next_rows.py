@@ -376,3 +376,62 @@ def test_upsample_branch_full_resolution_accuracies():
         bad = fovealseg.lvis50_cfg()
         bad.MODEL.upsample, bad.MODEL.rev_deform_interp = True, "tri"
         train.build_module(bad, device="cuda")
+
+
+# ---------------------------------------------------------------------------- f-2 / f-4 on the device --------------
+@pytest.mark.gpu
+def test_device_meter_on_gpu_matches_running_average():
+    """f-2: DeviceMeter fed with the step's 0-d CUDA outputs reproduces utils.AverageMeter's weighted running average
+    (train_deform_semantic.py:100-123: update(val) per iteration, .average() at the end) without reading the device per step."""
+    meter = train.DeviceMeter(["loss", "acc", "edge"], device="cuda")
+    g = torch.Generator().manual_seed(5)
+    vals = torch.rand(17, 3, generator=g, dtype=torch.float64)
+    weights = [1.0 + (i % 3) for i in range(17)]
+    for row, w in zip(vals, weights):
+        meter.update([v.to("cuda") for v in row], weight=w)              # tensors stay on the device
+    avg = meter.averages(reduce=False)
+    want = (vals * torch.tensor(weights)[:, None]).sum(0) / sum(weights)
+    for k, name in enumerate(("loss", "acc", "edge")):
+        assert abs(avg[name] - float(want[k])) <= 1e-12
+    meter.update([0.5, 0.25, torch.tensor(2.0)], weight=2.0)            # python floats / CPU tensors are accepted too
+    assert abs(meter.averages(reduce=False)["loss"] - (float(want[0]) * sum(weights) + 1.0) / (sum(weights) + 2.0)) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_checkpoint_of_the_real_module_on_gpu(tmp_path):
+    """f-4 on the real module: the four files hold exactly the reference's state_dict keys (tests/golden/g15_state_dict.json, dumped
+    from the reference module), a fresh module + optimisers resumed from them reproduce the saved one's next training step bit for bit
+    in the deterministic part (forward loss) and carry the Adam state."""
+    import json
+    with open(os.path.join(GOLD, "g15_state_dict.json")) as f:
+        pin = json.load(f)
+    cfg = fovealseg.lvis50_cfg()
+    module, nets = train.build_module(cfg, device="cuda")
+    module.train()
+    opts = train.create_optimizers(nets, cfg)
+    try:
+        batch = train.synthetic_batch(2, 256, 256, seed=8, device="cuda")
+        fovealseg.ops.DropoutState.seed, fovealseg.ops.DropoutState.step = 9, 0
+        train.train_step(module, opts, batch, cfg, epoch=1, cur_iter=0)
+        train.save_checkpoint(str(tmp_path), "last", nets, opts, extra={"iter": 1})
+        want_keys = {"encoder": [], "decoder": [], "saliency": [], "compress": []}
+        prefix = {"encoder.": "encoder", "decoder.": "decoder", "localization.": "saliency", "net_compress.": "compress"}
+        for k, shape, _ in pin:
+            for p, name in prefix.items():
+                if k.startswith(p):
+                    want_keys[name].append((k[len(p):], shape))
+        for name, want in want_keys.items():
+            sd = torch.load(tmp_path / f"{name}_epoch_last.pth", map_location="cpu", weights_only=True)
+            assert [(k, list(v.shape)) for k, v in sd.items()] == want, name          # the reference's keys, order and shapes per file
+        loss_next = float(train.train_step(module, opts, batch, cfg, epoch=1, cur_iter=1)[0])
+
+        module2, nets2 = train.build_module(cfg, device="cuda", init="random")
+        module2.train()
+        opts2 = train.create_optimizers(nets2, cfg)
+        extra = train.load_checkpoint(str(tmp_path), "last", nets2, opts2)
+        assert extra == {"iter": 1} and [o.t for o in opts2] == [1, 1, 1, 1]
+        loss_resumed = float(train.train_step(module2, opts2, batch, cfg, epoch=1, cur_iter=1)[0])
+        # same weights, same BN buffers, same dropout counter -> same forward; bwd-weight float atomics do not enter the forward
+        assert abs(loss_resumed - loss_next) <= 1e-6 * max(1.0, abs(loss_next)), (loss_resumed, loss_next)
+    finally:
+        fovealseg.ops.DIRECT_GRAD = False

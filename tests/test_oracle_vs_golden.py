@@ -251,3 +251,19 @@ def test_g13_segformer_oracle_vs_transformers(golden):
     assert np.abs(outs[3][0].numpy() - g["stage3"]).max() <= 1e-4
     assert np.abs(cat[0, :, 32:48, 32:48].numpy() - g["crop"]).max() <= 1e-4
     assert np.abs(cat.mean(dim=(0, 2, 3)).numpy() - g["chan_mean"]).max() <= 1e-4
+
+
+def test_dice_known_answers_unpinned_toolbelt():
+    """A18: pytorch_toolbelt 0.8.0 is absent, so the Dice restatement cannot be pinned to the package; these are hand-derived
+    known answers (tests/golden/kat_dice_unpinned.json, derivation in each case's "why") that any correct restatement of
+    DiceLoss('multiclass', from_logits=True, smooth=0, eps=1e-7) must reproduce: sums over batch and pixels, classes absent
+    from the target zeroed, mean over ALL classes."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_dice_unpinned.json")) as f:
+        kat = json.load(f)
+    for c in kat["cases"]:
+        pred = torch.tensor(c["logits"], dtype=torch.float32)
+        gt = torch.tensor(c["gt"], dtype=torch.int64)
+        got = float(O.dice_loss_multiclass(pred, gt))
+        assert abs(got - c["dice"]) <= 2e-7, (c["name"], got, c["dice"])
