@@ -194,18 +194,21 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1, w_amax=None):
     return dx
 
 
-# When True (set by train.create_optimizers), weight/affine gradients are ADDED straight into the
-# pre-allocated `.grad` views of the flat gradient arena (conv weights and BatchNorm affines alike) and
-# the autograd function returns None for them: no temporary, no AccumulateGrad add.  The arena is
-# zeroed once per step (optimizer.zero_grad), so repeated backwards accumulate exactly like `.grad`.
-DIRECT_GRAD = False
+# Weight / affine gradients of a parameter whose `.grad` IS its slice of a flat gradient arena (train.FlatParams registers the
+# slice as `p._fs_grad_home`) are ADDED straight into that slice by the kernels (conv weights and BatchNorm affines alike) and
+# the autograd function returns None for them: no temporary, no AccumulateGrad add.  The decision is per parameter -- there is
+# no process-wide mode: a parameter outside any arena, or whose `.grad` was re-pointed (module.zero_grad() -> None -> a fresh
+# tensor), takes the ordinary autograd path.  The arena is zeroed once per step (optimizer.zero_grad), so repeated backwards
+# accumulate exactly like `.grad`.  DIRECT_GRAD = False (or FS_DIRECT_GRAD=0) switches the direct path off altogether.
+DIRECT_GRAD = os.environ.get("FS_DIRECT_GRAD", "1") != "0"
 
 
 def _direct_grad_target(p):
-    if not p.is_leaf:
+    home = getattr(p, "_fs_grad_home", None)
+    if not DIRECT_GRAD or home is None or not p.is_leaf:
         return None
     g = p.grad
-    if DIRECT_GRAD and g is not None and g.shape == p.shape and g.stride() == p.stride() and g.is_cuda:
+    if g is not None and g.is_cuda and g.data_ptr() == home[0].data_ptr() + 4 * home[1] and g.shape == p.shape and g.stride() == p.stride():
         return g
     return None
 

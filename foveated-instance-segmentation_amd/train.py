@@ -42,6 +42,7 @@ class FlatParams:
             view.copy_(p.data)
             p.data = view
             p.grad = self.grad.as_strided(size, dense, o)
+            p._fs_grad_home = (self.grad, o)          # ops._direct_grad_target: kernels may add into this slice while .grad points at it
             del stride
         self.offsets = offs
         # max|w| bits per parameter, kept current by refresh_amax(): the f16x2 conv kernels scale the weights by it
@@ -147,8 +148,6 @@ def create_optimizers(nets, cfg):
     if cfg.TRAIN.optim.lower() != "adam":
         raise NotImplementedError("only TRAIN.optim='adam' is usable in the reference (the sgd branch returns undefined names)")
     T = cfg.TRAIN
-    from . import ops
-    ops.DIRECT_GRAD = True      # gradients land directly in the flat arenas (see ops.DIRECT_GRAD)
     mk = lambda net, mult, zoom: FlatAdam(list(net.parameters()), lr=T.lr_encoder, weight_decay=T.weight_decay,  # noqa: E731
                                           lr_mult=mult, zoom=zoom)
     return (mk(net_encoder, T.lr_mult_encoder, False), mk(net_decoder, T.lr_mult_decoder, False),
@@ -212,9 +211,40 @@ def broadcast_parameters(optimizers, module=None, src=0):
         dist.broadcast(opt.flat.data, src=src)
         opt.flat.refresh_amax()          # the arena was rewritten behind the parameters' version counters
     if module is not None:
-        for b in module.buffers():
-            if b.dtype.is_floating_point:
-                dist.broadcast(b, src=src)
+        broadcast_buffers(module, src=src)
+
+
+class FlatBuffers:
+    """Every float32 buffer of `module` (BatchNorm running statistics, the reference SyncBN's three extra buffers, the Gaussian
+    filter) re-homed into ONE flat tensor; the registered buffers become views, so the kernels that update running statistics
+    through their pointers keep working and the per-step buffer broadcast is a single collective."""
+
+    def __init__(self, module):
+        bufs = [b for _, b in module.named_buffers() if b.dtype == torch.float32]
+        assert bufs, "module has no float buffers"
+        offs, n = [], 0
+        for b in bufs:
+            offs.append(n)
+            n += (b.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.data = torch.zeros(n, device=bufs[0].device, dtype=torch.float32)
+        for b, o in zip(bufs, offs):
+            view = self.data[o:o + b.numel()].view(b.shape)
+            view.copy_(b)
+            b.data = view
+        self.buffers, self.offsets = bufs, offs
+
+
+def broadcast_buffers(module, src=0):
+    """DDP(broadcast_buffers=True) semantics (train_deform_semantic.py:395; torch DDP syncs module buffers from rank 0 at the start of
+    every training forward): after this call every rank holds rank 0's BatchNorm running statistics.  One collective over the
+    module's flat buffer arena (built on first use)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    flat = getattr(module, "_fs_flat_buffers", None)
+    if flat is None:
+        flat = FlatBuffers(module)
+        object.__setattr__(module, "_fs_flat_buffers", flat)      # not a submodule / buffer: keep it out of state_dict
+    dist.broadcast(flat.data, src=src)
 
 
 def allreduce_gradients(optimizers):
@@ -251,6 +281,7 @@ def train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=0):
         opt.zero_grad()
     adjust_learning_rate(optimizers, cur_iter, cfg, epoch=epoch)
     DropoutState.step += 1
+    broadcast_buffers(module)          # no-op on one rank; DDP syncs buffers from rank 0 before every training forward
     out = module(feed, epoch=epoch, cur_iter=cur_iter)
     loss = out[0]
     loss.mean().backward()

@@ -90,7 +90,15 @@ def _module_worker(rank, world, port, out):
         assert ops.rsck(w).is_contiguous() and not w.is_contiguous()          # RSCK storage survives the move into the arena
         assert w.data_ptr() >= optimizers[0].flat.data.data_ptr()
         train.broadcast_parameters(optimizers, module)
-        digest = [float(o.flat.data.double().sum()) for o in optimizers] + [float(module.encoder.bn1.running_mean.sum())]
+        # the float buffers now live in one flat arena (train.FlatBuffers): registered buffers are views, state_dict unchanged
+        fb = module._fs_flat_buffers
+        rm = module.encoder.bn1.running_mean
+        assert fb.data.data_ptr() <= rm.data_ptr() < fb.data.data_ptr() + 4 * fb.data.numel()
+        assert "_fs_flat_buffers" not in dict(module.named_buffers()) and len(module.state_dict()) == 2830
+        rm.add_(float(rank))                              # ranks drift apart again (per-rank BatchNorm updates) ...
+        train.broadcast_buffers(module)                   # ... and the per-step sync brings rank 0's statistics back
+        digest = [float(o.flat.data.double().sum()) for o in optimizers] + [float(module.encoder.bn1.running_mean.sum()),
+                                                                            float(fb.data.double().sum())]
         for opt in optimizers:
             opt.zero_grad()
         _fill_grads(optimizers, rank)
@@ -110,7 +118,7 @@ def _module_worker(rank, world, port, out):
         out[rank] = dict(digest=digest, ok=ok, tot=tot, avg=avg, nparams=[len(o.flat.params) for o in optimizers],
                          numel=[o.flat.numel for o in optimizers])
     finally:
-        ops.DIRECT_GRAD = False
+        pass          # (round 1 reset a process-global here; the direct-gradient decision is per parameter now)
     dist.barrier()
     dist.destroy_process_group()
 

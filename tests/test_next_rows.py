@@ -434,4 +434,4 @@ def test_checkpoint_of_the_real_module_on_gpu(tmp_path):
         # same weights, same BN buffers, same dropout counter -> same forward; bwd-weight float atomics do not enter the forward
         assert abs(loss_resumed - loss_next) <= 1e-6 * max(1.0, abs(loss_next)), (loss_resumed, loss_next)
     finally:
-        fovealseg.ops.DIRECT_GRAD = False
+        pass          # (round 1 reset a process-global here; the direct-gradient decision is per parameter now)
