@@ -319,8 +319,10 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
 
     def entry(kk, desc, kname):
         ach = kk["flops"] / (kk["total_ms"] * 1e-3) / 1e12
+        tr = _profiled_traffic(kname)
         return {"kernel": desc, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": _profiled_traffic(kname),
+                "frac": round(ach / peak, 4), "traffic": tr["hbm_bytes_per_launch"] if tr else None, "traffic_unit": "HBM bytes per launch",
+                "traffic_source": tr["source"] if tr else None,
                 "launches_per_step": kk["launches"] // nsteps,
                 "avg_launch_us": round(1000.0 * kk["total_ms"] / kk["launches"], 2),
                 "gflop_per_launch": round(kk["flops"] / kk["launches"] / 1e9, 3),
@@ -329,11 +331,11 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
     def hbm_entry(kk, desc, knames):
         ach = kk["flops"] / (kk["total_ms"] * 1e-3) / 1e9
         parts = [_profiled_traffic(k) for k in knames]
-        traffic = None
+        traffic, source = None, None
         if all(parts):
-            traffic = {"hbm_bytes_per_launch": sum(t["hbm_bytes_per_launch"] for t in parts), "source": parts[0]["source"]}
+            traffic, source = sum(t["hbm_bytes_per_launch"] for t in parts), parts[0]["source"]
         return {"kernel": desc, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": source,
                 "launches_per_step": kk["launches"] // nsteps,
                 "avg_launch_us": round(1000.0 * kk["total_ms"] / kk["launches"], 2),
                 "mb_per_launch": round(kk["flops"] / kk["launches"] / 1e6, 2),
@@ -374,8 +376,8 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
                             "frac": round(gbs / PEAK_HBM_GBS, 4), "avg_launch_us": round(us, 2),
                             "mb_per_launch": round(kk["flops"] / kk["launches"] / 1e6, 3), "launches_per_step": kk["launches"] // nsteps}
             tr = _profiled_traffic(kname)
+            fe[kind[3:]]["traffic"] = tr["hbm_bytes_per_launch"] if tr else None
             if tr is not None:            # what actually crossed the fabric (64-B sectors of a gather, re-reads): counter bytes / launch time
-                fe[kind[3:]]["traffic"] = tr
                 fe[kind[3:]]["traffic_gbs"] = round(tr["hbm_bytes_per_launch"] / (us * 1e-6) / 1e9, 1)
     if fe:
         fe["note"] = "algorithmic bytes (SURVEY.md 8(d)): every operand element the kernel needs read once, every result written once; the gather kernels touch 4 taps per output"
