@@ -49,7 +49,8 @@ def _profiled_traffic(kernel):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 table = json.load(f)
-            hits = [v for k, v in table.items() if k == kernel or k.startswith(kernel + "<")]      # template instances of one kernel
+            # all template instances of one kernel: "name" matches "name<...>", "name<a, b" matches "name<a, b, c>"
+            hits = [v for k, v in table.items() if k == kernel or k.startswith(kernel + "<") or ("<" in kernel and k.startswith(kernel))]
             n = sum(v["launches"] for v in hits)
             avg = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n
             return {"hbm_bytes_per_launch": int(avg), "source": rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
@@ -348,7 +349,7 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
             "over the C-ABI call incl. its weight pack pre-kernel, peak = dense 16-bit MFMA peak / MFMAs per product)", "conv3x3_halo_kernel")
         if "wgrad3x3" in summ:
             out["roofline_wgrad"] = entry(summ["wgrad3x3"], f"conv_wgrad_class_kernel<{tag},3,3> (3x3 stride-1 bwd-weight, 9 taps per workgroup)",
-                                          f"conv_wgrad_class_kernel<fs_split::{tag}, 3, 3>")
+                                          f"conv_wgrad_class_kernel<fs_split::{tag}, 3, 3")
         if "conv_affine" in summ:
             out["roofline_other_convs"] = entry(
                 summ["conv_affine"], f"conv_tapset_kernel<{tag}> (strided 3x3 forward + bwd-data sub-problems) + conv_igemm_split_kernel<{tag}> (1x1 convs "
