@@ -59,6 +59,25 @@ def _profiled_traffic(kernel):
     return None
 
 
+def _profiled_mfma_busy(mode):
+    """MFMA-pipe busy fraction and sustained clock of the dominant kernel from the committed SQ-counter passes
+    (profiles/r02/pmc/sq_<mode>_conv3x3_halo_kernel_fwd_shape0.txt: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)), or None."""
+    import ast
+    import re
+    rel = f"profiles/r02/pmc/sq_{mode}_conv3x3_halo_kernel_fwd_shape0.txt"
+    try:
+        vals = {}
+        for line in open(os.path.join(ROOT, rel)):
+            m = re.search(r"(\{.*\})", line)
+            if m:
+                vals.update(ast.literal_eval(m.group(1)))
+        per_xcd = vals["GRBM_GUI_ACTIVE"] / 8.0
+        return {"mfma_pipe_busy": round(vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (per_xcd * 1024.0), 3),
+                "sustained_clock_ghz": round(per_xcd / (vals["_dur"] * 1e3), 2), "shape": "64->64 3x3 @ 80x80, B=64", "source": rel}
+    except Exception:
+        return None
+
+
 def _threads():
     try:          # the GPU box exposes 128 logical CPUs but grants a 16-core share
         return min(16, len(os.sched_getaffinity(0)))
@@ -359,6 +378,7 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
         if "conv_wgrad" in summ:
             out["roofline_wgrad"] = entry(summ["conv_wgrad"], "conv_wgrad_taps_kernel<3|9> + conv_wgrad_kernel (bwd-weight, fp32 MFMA)", "conv_wgrad_taps_kernel")
     if "roofline" in out:
+        out["roofline"]["mfma_utilisation"] = _profiled_mfma_busy(mode)       # offline SQ counters of the same kernel (rocprofv3 --pmc)
         out["roofline"]["serial_ms_per_step"] = round(1000.0 * serial_elapsed / nsteps, 2)
         out["roofline"]["measured"] = "second pass of the same K steps with branch streams serialised, HIP events per launch on the launch stream"
     if "bn_fwd" in summ:
