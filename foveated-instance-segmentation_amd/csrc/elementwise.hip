@@ -425,6 +425,36 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   atomicAdd(&out[c], s);
 }
 
+// the same for C % 4 == 0, C <= 1024: 16-byte loads over the RowWalk layout (all 256 threads busy for any C, four rows in flight),
+// per-workgroup partials through LDS, one atomic per column and workgroup
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ x, long M, int C, int rows_per_block, float* __restrict__ out) {
+  extern __shared__ float csm[];   // [rpi][C]
+  RowWalk w(C);
+  const int c = 4 * w.col;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (w.active()) {
+    const long rb = (long)blockIdx.x * rows_per_block;
+    long re = rb + rows_per_block; if (re > M) re = M;
+    long r = rb + w.r0;
+    const long step = w.rpi;
+    for (; r + 3 * step < re; r += 4 * step) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + r * C + c);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(x + (r + step) * C + c);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(x + (r + 2 * step) * C + c);
+      const f32x4 a3 = *reinterpret_cast<const f32x4*>(x + (r + 3 * step) * C + c);
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; r < re; r += step) s += *reinterpret_cast<const f32x4*>(x + r * C + c);
+    *reinterpret_cast<f32x4*>(&csm[w.r0 * C + c]) = s;
+  }
+  __syncthreads();
+  for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
+    float a = 0.f;
+    for (int r = 0; r < w.rpi; ++r) a += csm[r * C + cc];
+    atomicAdd(&out[cc], a);
+  }
+}
+
 // ---- global average pool over HW (AvgPool2d((10,10)) on a 10x10 map) ---------------------------
 __global__ void avgpool_fwd_kernel(const float* __restrict__ x, int B, int HW, int C, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -671,6 +701,14 @@ int fs_colsum(const float* x, long M, int C, float* out, hipStream_t stream) {
   FS_REQUIRE(x && out && M > 0 && C > 0);
   hipError_t e = hipMemsetAsync(out, 0, C * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
+  if (C % 4 == 0 && C <= 1024 && ((size_t)x & 15) == 0) {
+    const int rpb = rows_per_block_for(M, C);
+    const int cw = C / 4;
+    int rpi = 256 / cw; if (rpi < 1) rpi = 1;
+    hipLaunchKernelGGL(colsum4_kernel, dim3(cdiv(M, rpb)), dim3(256), (size_t)rpi * C * sizeof(float), stream, x, M, C, rpb, out);
+    FS_LAUNCH_CHECK();
+    return FS_OK;
+  }
   int chunks = (int)((M + 255) / 256); if (chunks > 512) chunks = 512;
   const int rpb = (int)((M + chunks - 1) / chunks);
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 256), cdiv(M, rpb)), dim3(256), 0, stream, x, M, C, rpb, out);

@@ -1532,3 +1532,13 @@ def test_dice_known_answers_unpinned_toolbelt():
         gt = torch.tensor(c["gt"], dtype=torch.int64, device=DEV)
         out = ops.SegLoss.apply(pred, gt, 5.0)
         assert abs(float(out[2]) - c["dice"]) <= 2e-7, (c["name"], float(out[2]), c["dice"])
+
+
+@pytest.mark.parametrize("M,C", [(409600, 64), (1000, 512), (77, 1024), (300, 51), (4096, 1280), (5, 4), (12345, 240)])
+def test_colsum_bias_gradient(M, C):
+    """fs_colsum (bias gradients): the 16-byte RowWalk kernel (C % 4 == 0, C <= 1024) and the scalar fallback, ragged row counts."""
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g)
+    got = ops.colsum(x.to(DEV), C).cpu()
+    want = x.double().sum(0)
+    assert float((got.double() - want).abs().max()) <= 2e-6 * max(1.0, float(x.abs().sum(0).max()))
