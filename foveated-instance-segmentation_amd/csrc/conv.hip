@@ -1023,6 +1023,14 @@ bool use_tapset(const ConvArgs& c) {
          (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;        // the tap-class kernel addresses the source with 32-bit byte offsets too
 }
 
+// 1x1 / stride-1 layers go to the GEMM kernel with pre-split weights (conv_pointwise.hip) when the caller handed over its scratch.
+static const bool g_pointwise = [] { const char* e = getenv("FS_POINTWISE"); return !(e && e[0] == '0'); }();
+bool use_pointwise(const ConvArgs& c) {
+  return g_pointwise && g_conv_precision >= 1 && c.ws_ != nullptr && fs_pointwise_eligible(c.Cs, c.Cd, c.R, c.S, c.stride, c.pad, c.dil) &&
+         c.Hs == c.Hd && c.Ws == c.Wd && c.ws_bytes_ >= fs_pointwise_pack_bytes(g_conv_precision, c.Cs, c.Cd) &&
+         (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL && (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;
+}
+
 // The channel-aligned kernels (plain / halo / tap-class) address the SOURCE tensor with 32-bit BYTE offsets into a raw buffer
 // resource (AffArgs::src_bytes), so the source must stay below 4 GB -- 2^30 elements, not 2^31; larger problems take the
 // 64-bit-indexed conv_igemm_kernel.
@@ -1070,6 +1078,10 @@ int launch_affine(const ConvArgs& c, long M) {
     return fs_halo_conv3x3(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cs, c.Cd,
                            c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key,
                            c.stream_);
+  if (use_pointwise(c))
+    return fs_pointwise_conv(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, (long)c.B * c.Hd * c.Wd, c.Cs, c.Cd,
+                             c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key,
+                             c.stream_);
   if (!c.transposed || c.stride == 1) return launch_affine_one(a);
   // stride>1 bwd-data: one dense sub-problem per output parity class (oy0, ox0).  dX pixel y receives
   // tap r iff (y + pad - r) % stride == 0, i.e. r = r0 + stride*t with r0 = (oy0 + pad) % stride, and then
@@ -1143,12 +1155,16 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
     const long t = tapset_pack_bytes(Cs, Cd, R * S);
     if (t > need) need = t;
   }
+  if (g_pointwise && H == Ho && W == Wo && fs_pointwise_eligible(Cs, Cd, R, S, stride, pad, dil)) {
+    const long t = fs_pointwise_pack_bytes(g_conv_precision, Cs, Cd);
+    if (t > need) need = t;
+  }
   return need;
 }
 
 // include/fovealseg.h: fs_conv2d_kernel_choice -- which kernel family the conv entry points select for this problem under the current
 // precision mode and `ws_bytes` of scratch (host-side predicate, no launch; the dispatch below uses the same functions).
-// 0 = generic 64-bit-indexed kernel, 1 = plain aligned implicit GEMM, 2 = halo-tiled 3x3, 3 = tap-class kernel.
+// 0 = generic 64-bit-indexed kernel, 1 = plain aligned implicit GEMM, 2 = halo-tiled 3x3, 3 = tap-class kernel, 4 = 1x1 GEMM kernel.
 int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                             int transposed, long ws_bytes) {
   ConvArgs c{nullptr, nullptr, nullptr, nullptr, B, transposed ? Ho : H, transposed ? Wo : W, transposed ? Cout : Cin,
@@ -1159,6 +1175,7 @@ int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Co
   if (!transposed && use_tapset(c) && (g_tapset_all || !use_halo(c))) return 3;
   if (transposed && stride == 1 && use_tapset(c) && (g_tapset_all || !use_halo(c))) return 3;
   if (use_halo(c)) return 2;
+  if (use_pointwise(c)) return 4;
   if (transposed && stride > 1 && use_tapset(c)) return 3;     // the multi-tap parity sub-problems
   return 1;
 }

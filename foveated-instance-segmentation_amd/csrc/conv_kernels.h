@@ -21,6 +21,14 @@ int fs_halo_conv3x3(int mode, const float* src, const float* w, const float* bia
 const unsigned* fs_f16_weight_amax(const float* w, long n, void* ws, const unsigned* w_amax, hipStream_t stream, int* err);
 int fs_weight_amax_segments_impl(const float* arena, const long* offsets, const long* sizes, int nparams, unsigned* out, hipStream_t stream);
 
+// ---- conv_pointwise.hip: 1x1 / stride 1 / pad 0 as a GEMM with pre-split weights (forward and bwd-data).  mode: 1 = bf16x3, 2 = f16x2 ----
+bool fs_pointwise_eligible(int Cs, int Cd, int R, int S, int stride, int pad, int dil);
+long fs_pointwise_pack_bytes(int mode, int Cs, int Cd);
+// M = B*H*W rows; transposed = 1: bwd-data (src = dY with Cs = Cout channels, dst = dX with Cd = Cin).  stats: [ceil(M/128)][Cd][2] or null.
+int fs_pointwise_conv(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
+                      long M, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,
+                      hipStream_t stream);
+
 // ---- conv_wgrad.hip: split-precision weight gradient, one launch per tap class (dw zeroed by the caller or accumulated into) ----
 // any square filter / stride whose tap classes have at most 2 taps per dimension (3x3 s2/s4, 1x1 any stride), plus 3x3 s1
 bool fs_wgrad_split_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil);

@@ -1,0 +1,337 @@
+// 1x1 / stride-1 convolution (forward and bwd-data) = the GEMM  Y[M rows][N] = X[M][K] W[K][N]  in split precision
+// (conv_split.h: f16x2 = two scaled fp16 planes / 3 MFMAs per product, bf16x3 = three bf16 planes / 6 MFMAs; fp32 accumulate).
+// The Mix-FFN / attention projections of SegFormer, the bottleneck 1x1 convs of HRNet's layer1 and of ResNet-101, HRNet's fuse
+// 1x1s.  Same machinery as conv3x3_halo_kernel (conv_halo.hip) without the halo:
+//   * a workgroup (4 waves, 2 x 2) owns 128 consecutive rows (pixels) and 64 * NW output channels;
+//   * per ROUND it loads, (scales,) splits and writes to LDS TWO 32-channel chunks of its rows (one chunk per round would put
+//     three barriers around 12-24 MFMAs per wave: the plain kernel's problem), then runs their 4 k16 steps;
+//   * the weights are split ahead of time by a pack kernel into the order the B fragments are consumed,
+//     Wp[g = 2 * chunk + s][plane][n][16], so a B fragment is one 16-byte global load per lane straight into the MFMA
+//     operand registers, two steps ahead of use;
+//   * f16x2 range handling as in the halo kernel: running exponent E over the rounds, accumulators rescaled when it grows,
+//     one exponent per weight tensor; result = acc * 2^(E-14) * 2^(Ew-14).
+// The plain kernel (conv_igemm_split_kernel) splits both operands inside the kernel for every 32-channel stage and re-reads the
+// A tile once per 64 output channels: 60 VALU instructions per MFMA on 64->256 @ 80x80 (profiles/r01/pmc/...shape5.txt).
+#include "conv_split.h"
+#include "conv_kernels.h"
+
+namespace {
+
+using namespace fs_split;
+
+constexpr int XLD = 40;            // 16-bit elements per LDS row (80 bytes): 32 k + 16 B pad
+constexpr int ROWS = 128;
+constexpr int RC = 2;              // chunks per round
+constexpr int IMG = ROWS * XLD;    // one chunk image of one plane
+constexpr int NITEM = 4;           // float4 loads per thread and chunk: rows (tid >> 3) + 32 i, channels 4 (tid & 7)
+
+struct PwArgs {
+  const float* src; const unsigned char* ws; const unsigned* ew; const float* bias; float* dst; float* stats;
+  long M;
+  int Cs, Cd, Npad, nchunk;
+  int nx, ny;
+  unsigned src_bytes, ws_bytes, dst_bytes;
+  float drop_scale; uint32_t drop_thresh, drop_key;
+};
+
+// Wp[g = 2 * chunk + s][plane][n][j] = plane-th term of Wt[k = 32 * chunk + 16 * s + j][n] (scaled by 2^(14-Ew) in f16x2), behind a
+// HDR-byte header.  forward: Wt[k][n] = W[k][n] (K = Cin, N = Cout); bwd-data: Wt[k][n] = W[n][k] (K = Cout, N = Cin).
+template <class P>
+__global__ __launch_bounds__(256) void conv1x1_pack_kernel(const float* __restrict__ w, unsigned char* __restrict__ ws, const unsigned* __restrict__ ew,
+                                                           int Cin, int Cout, int transposed, int Ks, int Ns, int Npad, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  (void)Cin;
+  const float sc = P::SCALED ? pow2f(14 - exponent_of_bits(*ew)) : 1.f;
+  typename P::T* wp = reinterpret_cast<typename P::T*>(ws + HDR);
+  const int n = (int)(idx % Npad);
+  const int g = (int)(idx / Npad);
+  const int k0 = g * 16;
+  typename P::x8 p[P::NPL][2];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = k0 + j;
+    float v = 0.f;
+    if (n < Ns && k < Ks) v = transposed ? w[(long)n * Cout + k] : w[(long)k * Cout + n];
+    typename P::T t[P::NPL];
+    P::split(v * sc, t);
+#pragma unroll
+    for (int pl = 0; pl < P::NPL; ++pl) p[pl][j >> 3][j & 7] = t[pl];
+  }
+#pragma unroll
+  for (int pl = 0; pl < P::NPL; ++pl) {
+    typename P::x8* o = reinterpret_cast<typename P::x8*>(wp + (((long)g * P::NPL + pl) * Npad + n) * 16);
+    o[0] = p[pl][0]; o[1] = p[pl][1];
+  }
+}
+
+template <class P, int NW>
+__global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(PwArgs a) {
+  typedef typename P::x8 X8;
+  typedef typename P::x4 X4;
+  constexpr int NPL = P::NPL;
+  __shared__ __attribute__((aligned(16))) typename P::T Ah[NPL * RC * IMG];
+  __shared__ unsigned amax_cell[2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nwg = a.nx * a.ny;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd = nwg >> 3, rm = nwg & 7;
+  const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;      // XCD-aware: the ny channel tiles of a row tile share an L2
+  const int mt = wg / a.ny;
+  const int n0 = (wg - mt * a.ny) * 64 * NW;
+  const long m0 = (long)mt * ROWS;
+
+  if (tid < 2) amax_cell[tid] = 0u;
+  const int q = tid & 7;
+  long goff[NITEM];          // element offset of (row, channel quad) in the source, -1 past the last row
+#pragma unroll
+  for (int i = 0; i < NITEM; ++i) {
+    const long row = m0 + (tid >> 3) + 32 * i;
+    goff[i] = row < a.M ? row * a.Cs + 4 * q : -1;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(a.src, a.src_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.ws, a.ws_bytes);
+
+  f32x4 ra[RC][NITEM];
+  auto load_round = [&](int round) {
+#pragma unroll
+    for (int cc = 0; cc < RC; ++cc) {
+      const int c0 = (round * RC + cc) * 32;
+      const bool cok = c0 + 4 * q < a.Cs;
+#pragma unroll
+      for (int i = 0; i < NITEM; ++i) {
+        const bool ok = cok && goff[i] >= 0;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? (int)((unsigned)(goff[i] + c0) * 4u) : (int)OOB, 0, 0);
+        ra[cc][i] = __builtin_bit_cast(f32x4, v);
+      }
+    }
+  };
+  auto tile_amax = [&](int cell) {
+    float m = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < RC; ++cc)
+#pragma unroll
+      for (int i = 0; i < NITEM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(ra[cc][i][e]));
+    m = wave_max(m);
+    if (lane == 0) atomicMax(&amax_cell[cell], __builtin_bit_cast(unsigned, m));
+  };
+  auto store_round = [&](float sc) {
+#pragma unroll
+    for (int cc = 0; cc < RC; ++cc)
+#pragma unroll
+      for (int i = 0; i < NITEM; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        X4 p[NPL];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          typename P::T t[NPL];
+          P::split(P::SCALED ? ra[cc][i][e] * sc : ra[cc][i][e], t);
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) p[pl][e] = t[pl];
+        }
+        const int o = cc * IMG + row * XLD + 4 * q;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Ah[pl * RC * IMG + o]) = p[pl];
+      }
+  };
+
+  int rowbase[2];          // LDS element offset of this lane's A rows (two 32-row tiles of the wave's 64 rows)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) rowbase[mi] = (64 * wm + 32 * mi + row_perm(l31)) * XLD + 8 * lh;
+  const int bvoff = HDR + ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2;      // sub-tile j: + j * 64 columns = j * 2048 bytes
+  const int plane_bytes = a.Npad * 32;
+  const int step_bytes = NPL * plane_bytes;
+  const int G = a.nchunk * 2;                                             // k16 steps that carry data
+  const int nround = (a.nchunk + RC - 1) / RC;
+
+  X8 fa[2][2][NPL];       // [buffer][mi][plane]
+  X8 fb[3][NW][NPL];      // ring: fragments run 2 steps ahead of the MFMAs (4 steps per round: 4 % 3 != 0, so the slot is g % 3)
+  auto load_b = [&](int g, X8 (&dst)[NW][NPL]) {
+    const int gg = g < G ? g : G - 1;            // steps past the last chunk multiply zeros of A: any finite B will do
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff + j * 2048, gg * step_bytes + pl * plane_bytes, 0);
+        dst[j][pl] = __builtin_bit_cast(X8, v);
+      }
+  };
+
+  f32x16 acc[2][NW];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.f;
+  int E = EMIN;
+  load_round(0);
+  __syncthreads();                        // amax cells zeroed before the first atomic
+  // rounds are processed three at a time so that the B ring slot (g % 3) is a compile-time constant: 3 rounds = 12 steps
+  for (int r3 = 0; r3 < nround; r3 += 3) {
+    if (r3 == 0) { load_b(0, fb[0]); load_b(1, fb[1]); }
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      const int round = r3 + rr;
+      if (round < nround) {
+        if (P::SCALED) tile_amax(round & 1);
+        __syncthreads();                      // amax complete; every wave has finished reading the previous round's images
+        if (P::SCALED) {
+          const int ec = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[round & 1]));
+          if (ec > E) {
+            if (round > 0) {
+              const float f = pow2f(E - ec);
+#pragma unroll
+              for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int j = 0; j < NW; ++j)
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) acc[mi][j][r] *= f;
+            }
+            E = ec;
+          }
+          if (tid == 0) amax_cell[(round + 1) & 1] = 0u;
+        }
+        store_round(pow2f(14 - E));
+        __syncthreads();
+        if (round + 1 < nround) load_round(round + 1);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) fa[0][mi][pl] = *reinterpret_cast<const X8*>(&Ah[pl * RC * IMG + rowbase[mi]]);
+#pragma unroll
+        for (int step = 0; step < 2 * RC; ++step) {
+          const int gl = rr * 2 * RC + step;             // step index within the 3-round group: compile-time
+          if (step + 1 < 2 * RC) {
+            const int cc = (step + 1) >> 1, s2 = (step + 1) & 1;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int pl = 0; pl < NPL; ++pl)
+                fa[(step + 1) & 1][mi][pl] = *reinterpret_cast<const X8*>(&Ah[pl * RC * IMG + cc * IMG + rowbase[mi] + 16 * s2]);
+          }
+          load_b(round * 2 * RC + step + 2, fb[(gl + 2) % 3]);
+          __builtin_amdgcn_sched_barrier(0);
+          const X8(&A)[2][NPL] = fa[step & 1];
+          const X8(&Bf)[NW][NPL] = fb[gl % 3];
+#pragma unroll
+          for (int j = 0; j < NW; ++j)
+#pragma unroll
+            for (int t = 0; t < P::NTERM; ++t) {
+              acc[0][j] = P::mfma(A[0][P::ta(t)], Bf[j][P::tb(t)], acc[0][j]);
+              acc[1][j] = P::mfma(A[1][P::ta(t)], Bf[j][P::tb(t)], acc[1][j]);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue ----
+  __syncthreads();
+  float f1 = 1.f, f2 = 1.f;
+  if (P::SCALED) {
+    const int Ew = exponent_of_bits(*a.ew);
+    const int es = E + Ew - 28;
+    const bool one = es >= -126 && es <= 127;
+    f1 = one ? pow2f(es) : pow2f(E - 14);
+    f2 = one ? 1.f : pow2f(Ew - 14);
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
+  float csum[NW], csq[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    csum[j] = 0.f; csq[j] = 0.f;
+    const int n = n0 + 64 * j + 32 * wn + l31;
+    if (n >= a.Cd) continue;
+    const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // accumulator row r of tile mi = tile row (r&3) + 8 (r>>2) + 4 lh; LDS row permutation: tile row t holds pixel row_perm(t)
+        const int trow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const long row = m0 + 64 * wm + 32 * mi + row_perm(trow);
+        const bool live = row < a.M;
+        const unsigned e = (unsigned)(row * a.Cd + n);                 // element index (< 2^30: dst_bytes < 4 GB)
+        float v = P::SCALED ? fmaf(acc[mi][j][r] * f2, f1, bv) : acc[mi][j][r] + bv;
+        if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+        v = live ? v : 0.f;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
+        csum[j] += v; csq[j] += v * v;
+      }
+    }
+  }
+  if (a.stats != nullptr) {
+    float* red = reinterpret_cast<float*>(&Ah[0]);     // [wm][64*NW cols][2]; the operand images are dead since the barrier above
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const float s1 = csum[j] + __shfl_xor(csum[j], 32, 64), s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
+      const int col = 64 * j + 32 * wn + l31;
+      if (lh == 0) { red[(wm * 64 * NW + col) * 2] = s1; red[(wm * 64 * NW + col) * 2 + 1] = s2; }
+    }
+    __syncthreads();
+    for (int t = tid; t < 128 * NW; t += 256) {
+      const int col = t >> 1, which = t & 1;
+      const float v = red[col * 2 + which] + red[(64 * NW + col) * 2 + which];
+      if (n0 + col < a.Cd) a.stats[((long)mt * a.Cd + n0 + col) * 2 + which] = v;
+    }
+  }
+}
+
+static inline int pw_nw(int Cd) { return Cd >= 128 ? 2 : 1; }
+
+template <class P>
+static int run_pointwise(PwArgs& a, const float* w, void* ws, const unsigned* w_amax, int Cin, int Cout, int transposed, int nw, hipStream_t stream) {
+  int e = FS_OK;
+  a.ew = P::SCALED ? fs_f16_weight_amax(w, (long)Cin * Cout, ws, w_amax, stream, &e) : nullptr;
+  if (e != FS_OK) return e;
+  const long total = (long)a.nchunk * 2 * a.Npad;
+  hipLaunchKernelGGL((conv1x1_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws), a.ew,
+                     Cin, Cout, transposed, a.Cs, a.Cd, a.Npad, total);
+  FS_LAUNCH_CHECK();
+  if (nw == 2) hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 2>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 1>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+}  // namespace
+
+bool fs_pointwise_eligible(int Cs, int Cd, int R, int S, int stride, int pad, int dil) {
+  return R == 1 && S == 1 && stride == 1 && pad == 0 && dil == 1 && Cs % 4 == 0 && Cd % 4 == 0 && Cs >= 32;
+}
+
+long fs_pointwise_pack_bytes(int mode, int Cs, int Cd) {
+  const int nw = pw_nw(Cd), npl = mode == 2 ? 2 : 3;
+  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 64 * nw - 1) / (64 * nw)) * 64 * nw;
+  return HDR + nchunk * 2 * npl * Npad * 16 * 2;
+}
+
+int fs_pointwise_conv(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
+                      long M, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,
+                      hipStream_t stream) {
+  PwArgs a;
+  a.src = src; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = dst; a.stats = stats;
+  a.M = M; a.Cs = Cs; a.Cd = Cd;
+  const int nwp = pw_nw(Cd);
+  a.Npad = ((Cd + 64 * nwp - 1) / (64 * nwp)) * 64 * nwp;
+  a.nchunk = (Cs + 31) / 32;
+  a.nx = cdiv(M, ROWS);
+  // 128-column workgroups (two sub-tiles per wave, the A tile split once for twice the MFMAs) while the grid still fills the chip
+  const int nw = (nwp == 2 && (long)a.nx * (a.Npad / 128) >= 440) ? 2 : 1;
+  a.ny = nw == 2 ? a.Npad / 128 : (Cd + 63) / 64;
+  const long pack_bytes = fs_pointwise_pack_bytes(mode, Cs, Cd);
+  if (pack_bytes >= 2147483647L || (size_t)M * Cs * 4 >= 4294967000UL || (size_t)M * Cd * 4 >= 4294967000UL) return FS_ERR_ARG;
+  a.src_bytes = (unsigned)((size_t)M * Cs * 4);
+  a.dst_bytes = (unsigned)((size_t)M * Cd * 4);
+  a.ws_bytes = (unsigned)pack_bytes;
+  a.drop_scale = drop_scale; a.drop_thresh = drop_thresh; a.drop_key = drop_key;
+  return mode == 2 ? run_pointwise<PrecF16>(a, w, ws, w_amax, Cin, Cout, transposed, nw, stream)
+                   : run_pointwise<PrecX3>(a, w, ws, w_amax, Cin, Cout, transposed, nw, stream);
+}

@@ -201,7 +201,7 @@ def test_conv_dispatch_predicate_above_4gb():
             # 1x1 bottleneck conv, B*H*W*256 elements: just below / above 2^30 elements (4 GB)
             below = lib.fs_conv2d_kernel_choice(63, 256, 256, 256, 256, 256, 64, 1, 1, 1, 0, 1, 0, ws)        # 3.94 GB
             above = lib.fs_conv2d_kernel_choice(64, 256, 256, 256, 256, 256, 64, 1, 1, 1, 0, 1, 0, ws)        # 4.00 GB
-            assert below == 1 and above == 0, (mode, below, above)
+            assert below == (4 if mode else 1) and above == 0, (mode, below, above)      # 4 = the 1x1 GEMM kernel of the split modes
             # between 4 and 8 GB (2^30..2^31 elements) -- the range the old `elements < 2^31` guard let through
             assert lib.fs_conv2d_kernel_choice(100, 256, 256, 256, 256, 256, 64, 1, 1, 1, 0, 1, 0, ws) == 0
             # 3x3 stride 1: halo kernel below 4 GB in the split modes, generic above (source or destination)
