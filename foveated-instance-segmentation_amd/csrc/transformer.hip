@@ -130,6 +130,14 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void dwconv3_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
                                                       int C, int flip) {
+  // the 9 x C weights transposed to [tap][channel] in LDS (taps already mirrored for the input gradient): one 16-byte LDS read per
+  // tap and channel quad instead of four scalar global loads -- 36 of the 45 loads a thread issued per output were weight scalars
+  extern __shared__ float wt[];    // [9][C]
+  for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) {
+    const int c = i / 9, t = i - 9 * c;
+    wt[(flip ? 8 - t : t) * C + c] = w[i];
+  }
+  __syncthreads();
   const int cw = C >> 2;
   const long total = (long)B * H * W * cw;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -142,9 +150,8 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(const float* __restrict__ 
       const int dy = t / 3 - 1, dxx = t % 3 - 1;
       const int iy = py + dy, ix = px + dxx;
       if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-      const int wt = flip ? 8 - t : t;
       const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (((long)b * H + iy) * W + ix) * C + c);
-      const f32x4 wv = {w[(c + 0) * 9 + wt], w[(c + 1) * 9 + wt], w[(c + 2) * 9 + wt], w[(c + 3) * 9 + wt]};
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(&wt[t * C + c]);
       acc += xv * wv;
     }
     *reinterpret_cast<f32x4*>(y + pix * C + c) = acc;
@@ -598,8 +605,16 @@ int fs_gelu_bwd(const float* g, const float* x, float* dx, long n, hipStream_t s
 int fs_dwconv3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int flip,
                    hipStream_t stream) {
   FS_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+  FS_REQUIRE(C <= 4096);                                        // 9 x C weights staged in LDS (<= 144 KB)
   int blocks = cdiv((long)B * H * W * (C / 4), 256); if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(dwconv3_kernel, dim3(blocks), dim3(256), 0, stream, x, w, bias, y, B, H, W, C, flip);
+  const int smem = 9 * C * (int)sizeof(float);
+  static int attr_bytes = 0;
+  if (smem > 65536 && smem > attr_bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)dwconv3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_bytes = smem;
+  }
+  hipLaunchKernelGGL(dwconv3_kernel, dim3(blocks), dim3(256), smem, stream, x, w, bias, y, B, H, W, C, flip);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
