@@ -239,16 +239,17 @@ def main():
         # Per-kernel roofline pass.  In the timed region the HRNet branches run on 4 HIP streams, so kernel lifetimes overlap and
         # a per-launch duration is not separable; the same K steps are therefore repeated with the branch streams serialised and
         # every conv / BatchNorm / front-end launch bracketed by HIP events on the launch stream (NOT part of `value`).
-        if not args.no_kernel_timer and world == 1:
+        # (All ranks run it -- train_step holds the gradient all-reduce -- and rank 0's kernels are the ones reported.)
+        if not args.no_kernel_timer:
             saved = Mods.PARALLEL_BRANCHES
             Mods.PARALLEL_BRANCHES = False
             timer = ops.KernelTimer()
             ops.TIMER = timer
             try:
-                torch.cuda.synchronize()
+                barrier()
                 tr0 = time.perf_counter()
                 steps(args.steps)
-                torch.cuda.synchronize()
+                barrier()
                 serial_elapsed = time.perf_counter() - tr0
                 res.update(roofline_entries(mode, timer.summary(), args.steps, serial_elapsed))
             except Exception as exc:                       # the throughput line must survive a failure of the diagnostic pass

@@ -346,6 +346,17 @@ __global__ __launch_bounds__(256) void hr_fuse_fwd_kernel(FuseArgs a) {
   }
 }
 
+// out = a + b [+ c [+ d]] (the gradient sum at a tensor with several consumers); out may alias a.  c, d nullable.
+__global__ __launch_bounds__(256) void add_n_kernel(const float* a, const float* __restrict__ b, const float* __restrict__ c,
+                                                    const float* __restrict__ d, float* out, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+    if (c != nullptr) v += reinterpret_cast<const f32x4*>(c)[i];
+    if (d != nullptr) v += reinterpret_cast<const f32x4*>(d)[i];
+    reinterpret_cast<f32x4*>(out)[i] = v;
+  }
+}
+
 // g = dout * (out > 0)
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                        float* __restrict__ g, long n4) {
@@ -636,6 +647,15 @@ int fs_hr_fuse_fwd(const float* const* terms, const int* th, const int* tw, int 
   const long total = (long)B * Ho * Wo * (C / 4);
   int blocks = cdiv(total, 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(hr_fuse_fwd_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// include/fovealseg.h: fs_add_n
+int fs_add_n(const float* a, const float* b, const float* c, const float* d, float* out, long n, hipStream_t stream) {
+  FS_REQUIRE(a && b && out && n > 0 && n % 4 == 0 && (d == nullptr || c != nullptr));
+  int blocks = cdiv(n / 4, 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(add_n_kernel, dim3(blocks), dim3(256), 0, stream, a, b, c, d, out, n / 4);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

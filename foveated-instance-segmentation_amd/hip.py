@@ -46,6 +46,7 @@ SIGNATURES = {
     "fs_bn_act_bwd": "pppppppliiifupppppi",
     "fs_hr_fuse_fwd": "pppipiiiii",
     "fs_relu_bwd": "pppl",
+    "fs_add_n": "pppppl",
     "fs_upsample_slice_fwd": "piiiipiiii",
     "fs_upsample_slice_bwd": "piiiiipiii",
     "fs_colsum": "plip",

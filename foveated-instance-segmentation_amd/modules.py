@@ -166,8 +166,9 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         id1 = ops.layer_id_from_name(self._path + ".conv1")
         id2 = ops.layer_id_from_name(self._path + ".conv2")
-        o = conv_bn_act(x, self.conv1, self.bn1, ACT_RELU, drop_p=self.drop_p, layer_id=id1)
-        return conv_bn_act(o, self.conv2, self.bn2, ACT_RELU, res=x, drop_p=self.drop_p, layer_id=id2)
+        xa, xr = ops.fan_out(x, 2)              # conv path + residual: their gradients meet in one HIP add
+        o = conv_bn_act(xa, self.conv1, self.bn1, ACT_RELU, drop_p=self.drop_p, layer_id=id1)
+        return conv_bn_act(o, self.conv2, self.bn2, ACT_RELU, res=xr, drop_p=self.drop_p, layer_id=id2)
 
 
 class _ConvBn(nn.Sequential):
@@ -206,8 +207,9 @@ class Bottleneck(nn.Module):
         self.downsample = _ConvBn(cin, planes * 4, 1, 1, False) if down else None
 
     def forward(self, x):
-        r = x if self.downsample is None else self.downsample(x)
-        o = conv_bn_act(x, self.conv1, self.bn1, ACT_RELU)
+        xa, xr = ops.fan_out(x, 2)
+        r = xr if self.downsample is None else self.downsample(xr)
+        o = conv_bn_act(xa, self.conv1, self.bn1, ACT_RELU)
         o = conv_bn_act(o, self.conv2, self.bn2, ACT_RELU)
         return conv_bn_act(o, self.conv3, self.bn3, ACT_RELU, res=r)
 
@@ -260,9 +262,10 @@ class HighResolutionModule(nn.Module):
     def forward(self, xs):
         n = len(self.chans)
         xs = self._run_branches(xs)
+        fan = [ops.fan_out(xs[j], n) for j in range(n)]        # every branch output is read by all n fuse rows
         outs = []
         for i in range(n):
-            terms = [xs[j] if j == i else self.fuse_layers[i][j](xs[j]) for j in range(n)]
+            terms = [fan[j][i] if j == i else self.fuse_layers[i][j](fan[j][i]) for j in range(n)]
             outs.append(ops.HrFuse.apply(xs[i].shape[1], xs[i].shape[2], *terms))
             if ops.ACT_TRACE is not None:
                 ops.ACT_TRACE.append(((self, i), ACT_RELU, outs[-1]))

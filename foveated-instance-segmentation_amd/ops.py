@@ -273,6 +273,44 @@ def pad_in_channels(x, w):
     return torch.nn.functional.pad(x, (0, cp - cin)), PadWeightChannels.apply(w, cp)
 
 
+FANOUT = os.environ.get("FS_FANOUT", "1") != "0"
+
+
+class FanOut(Function):
+    """x -> n aliases of x, one per consumer.  Backward: ONE n-ary HIP add of the consumers' gradients (fs_add_n, up to four at a
+    time) instead of the n - 1 binary ATen adds the autograd engine would issue -- the last ATen compute kernel inside the step."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g if g.is_contiguous() else g.contiguous() for g in grads if g is not None]
+        if not gs:
+            return None, None
+        acc = gs[0]
+        rest = gs[1:]
+        if rest and (acc.numel() % 4 or not acc.is_cuda):
+            for g in rest:
+                acc = acc + g
+            return acc, None
+        while rest:
+            take, rest = rest[:3], rest[3:]
+            out = torch.empty_like(acc)
+            hip.call("fs_add_n", hip.ptr(acc), hip.ptr(take[0]), hip.ptr(take[1]) if len(take) > 1 else None,
+                     hip.ptr(take[2]) if len(take) > 2 else None, hip.ptr(out), acc.numel())
+            acc = out
+        return acc, None
+
+
+def fan_out(x, n):
+    """n references to x for n consumers (n >= 2 and FS_FANOUT on: through FanOut, else x itself n times)."""
+    if n < 2 or not FANOUT or not x.requires_grad:
+        return (x,) * n
+    return FanOut.apply(x, n)
+
+
 FANOUT_SUBSAMPLE = os.environ.get("FS_FANOUT_SUBSAMPLE", "1") != "0"
 
 

@@ -158,6 +158,10 @@ int fs_bn_act_bwd(const float* dz, const float* z, const unsigned char* mask, co
 int fs_hr_fuse_fwd(const float* const* terms, const int* th, const int* tw, int nterms, float* out, int B, int Ho, int Wo, int C,
                    int relu, fs_stream_t stream);
 int fs_relu_bwd(const float* dout, const float* out, float* g, long n, fs_stream_t stream);
+/* out = a + b [+ c [+ d]] over n floats (n % 4 == 0; c, d may be NULL; out may alias a): the sum of the gradients that reach a tensor
+ * with several consumers -- the block input of models/hrnetv2_nodownsp.py:46-64 (conv path + residual), the branch outputs every
+ * fuse row reads (:228-252) -- which the autograd engine would otherwise form with ATen's binary add, one launch per extra consumer. */
+int fs_add_n(const float* a, const float* b, const float* c, const float* d, float* out, long n, fs_stream_t stream);
 /* dst[..., coff:coff+C] = up(src); models/hrnetv2_nodownsp.py:434-442 (interpolate + cat). */
 int fs_upsample_slice_fwd(const float* src, int B, int th, int tw, int C, float* dst, int Ho, int Wo, int Cdst, int coff,
                           fs_stream_t stream);

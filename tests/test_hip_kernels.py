@@ -1542,3 +1542,19 @@ def test_colsum_bias_gradient(M, C):
     got = ops.colsum(x.to(DEV), C).cpu()
     want = x.double().sum(0)
     assert float((got.double() - want).abs().max()) <= 2e-6 * max(1.0, float(x.abs().sum(0).max()))
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 6])
+def test_fan_out_gradient_sum_bit_exact(n):
+    """ops.fan_out: the consumers' gradients are summed by fs_add_n (up to four operands per launch) -- same left-to-right fp32 order
+    as the chain of binary adds the autograd engine would have issued, so bit-exact against it."""
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(3, 40, 24, 20, generator=g).to(DEV).requires_grad_(True)
+    ws = [torch.randn(3, 40, 24, 20, generator=g).to(DEV) for _ in range(n)]
+    parts = ops.fan_out(x, n)
+    assert all(p.data_ptr() == x.data_ptr() for p in parts)
+    sum((p * w).sum() for p, w in zip(parts, ws)).backward()
+    want = ws[0].clone()
+    for w in ws[1:]:
+        want = want + w
+    assert torch.equal(x.grad, want)
