@@ -1004,6 +1004,11 @@ bool use_halo(const ConvArgs& c) {
          (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;        // 32-bit buffer offsets of the source (fs_halo_conv3x3 rejects larger)
 }
 
+// ... and its F(2,3) variant (conv_wino.hip) where the shape additionally allows the pair tiling.
+bool use_wino(const ConvArgs& c) {
+  return use_halo(c) && fs_wino_eligible(g_conv_precision, c.B, c.Hd, c.Wd, c.Cs, c.Cd) && c.ws_bytes_ >= fs_wino_pack_bytes(g_conv_precision, c.Cs, c.Cd);
+}
+
 // Everything else that is channel-aligned, undilated and has scratch goes to the tap-class kernel (conv_tapset.hip).
 static const bool g_tapset_1x1 = [] { const char* e = getenv("FS_TAPSET_1X1"); return e && e[0] == '1'; }();
 static const bool g_tapset_all = [] { const char* e = getenv("FS_TAPSET_ALL"); return e && e[0] == '1'; }();
@@ -1074,6 +1079,9 @@ int launch_affine(const ConvArgs& c, long M) {
     p.cls[0] = FsTapClass{c.pad - (c.R - 1), c.pad - (c.S - 1), c.R, c.S, c.R - 1, -1, c.S - 1, -1};
     return run_tapset(p, c.stream_);
   }
+  if (use_wino(c))
+    return fs_wino_conv3x3(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cs, c.Cd,
+                           c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key, c.stream_);
   if (use_halo(c))
     return fs_halo_conv3x3(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cs, c.Cd,
                            c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key,
@@ -1150,7 +1158,11 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
   if (g_conv_precision < 1) return 0;
   const int Cs = transposed ? Cout : Cin, Cd = transposed ? Cin : Cout;
   long need = 0;
-  if (H == Ho && W == Wo && fs_halo_eligible(H, W, Cs, Cd, R, S, stride, pad, dil)) need = halo_pack_bytes(Cs, Cd);
+  if (H == Ho && W == Wo && fs_halo_eligible(H, W, Cs, Cd, R, S, stride, pad, dil)) {
+    need = halo_pack_bytes(Cs, Cd);
+    const long t = fs_wino_pack_bytes(g_conv_precision, Cs, Cd);       // the F(2,3) variant packs 4 components per filter row
+    if (t > need) need = t;
+  }
   if (tapset_shape_ok(Cs, Cd, R, S, stride, dil)) {
     const long t = tapset_pack_bytes(Cs, Cd, R * S);
     if (t > need) need = t;
@@ -1164,7 +1176,8 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
 
 // include/fovealseg.h: fs_conv2d_kernel_choice -- which kernel family the conv entry points select for this problem under the current
 // precision mode and `ws_bytes` of scratch (host-side predicate, no launch; the dispatch below uses the same functions).
-// 0 = generic 64-bit-indexed kernel, 1 = plain aligned implicit GEMM, 2 = halo-tiled 3x3, 3 = tap-class kernel, 4 = 1x1 GEMM kernel.
+// 0 = generic 64-bit-indexed kernel, 1 = plain aligned implicit GEMM, 2 = halo-tiled 3x3, 3 = tap-class kernel, 4 = 1x1 GEMM kernel,
+// 5 = halo-tiled 3x3 with F(2,3) minimal filtering along the row.
 int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                             int transposed, long ws_bytes) {
   ConvArgs c{nullptr, nullptr, nullptr, nullptr, B, transposed ? Ho : H, transposed ? Wo : W, transposed ? Cout : Cin,
@@ -1174,6 +1187,7 @@ int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Co
   if (!aligned_ok(c)) return 0;
   if (!transposed && use_tapset(c) && (g_tapset_all || !use_halo(c))) return 3;
   if (transposed && stride == 1 && use_tapset(c) && (g_tapset_all || !use_halo(c))) return 3;
+  if (use_wino(c)) return 5;
   if (use_halo(c)) return 2;
   if (use_pointwise(c)) return 4;
   if (transposed && stride > 1 && use_tapset(c)) return 3;     // the multi-tap parity sub-problems
@@ -1187,6 +1201,7 @@ int fs_conv2d_stats_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout
   const long need = fs_conv2d_workspace_bytes(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0);
   if (need > 0 && ws_bytes >= need) {
     const bool halo = H == Ho && W == Wo && fs_halo_eligible(H, W, Cin, Cout, R, S, stride, pad, dil);
+    if (halo && !g_tapset_all && fs_wino_eligible(g_conv_precision, B, Ho, Wo, Cin, Cout)) return fs_wino_stats_slabs(B, Ho, Wo);
     if (halo && !g_tapset_all) return fs_halo_stats_slabs(B, Ho, Wo);
     if (tapset_shape_ok(Cin, Cout, R, S, stride, dil)) return fs_tapset_slabs(B, Ho, Wo, (R + stride - 1) / stride, (S + stride - 1) / stride);
     if (halo) return fs_halo_stats_slabs(B, Ho, Wo);

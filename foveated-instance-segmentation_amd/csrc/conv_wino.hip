@@ -1,0 +1,418 @@
+// 3x3 / stride-1 / pad-1 convolution (forward and bwd-data) with the minimal-filtering identity F(2,3) applied along the image
+// row: two neighbouring output columns (a "pair") are computed from 4 transform-domain products instead of 6 taps, so a 3x3
+// filter costs 3 (rows) x 4 = 12 MFMA steps per pair of pixels where conv_halo.hip spends 18.
+//
+//   inputs of pair j, row y:  d0..d3 = x[y][2j-1 .. 2j+2]          T0 = d0 - d2   T1 = d1 + d2   T2 = d2 - d1   T3 = d1 - d3
+//   filter row (g0 g1 g2):                                         U0 = g0   U1 = (g0+g1+g2)/2   U2 = (g0-g1+g2)/2   U3 = g2
+//   m_c = sum over the 3 filter rows and the input channels of T_c * U_c        (4 independent GEMMs, fp32 accumulate)
+//   out[2j] = m0 + m1 + m2        out[2j+1] = m1 - m2 - m3
+//
+// The transform is exact in the same sense the rest of the path is: T and U are formed in fp32 (one rounding each), THEN split
+// into the 16-bit planes of the precision mode (conv_split.h), so the products carry the mode's operand width; the error
+// against fp64 is measured per layer by tools/conv_accuracy.py (profiles/r02/conv_accuracy_winograd.txt).
+//
+//   workgroup = 256 threads = 4 waves as 2 (component pairs {0,1} / {2,3}) x 2 (32-column halves); it owns 64 pairs
+//   (Ph rows x PP pairs = 128 output pixels) x 64 output channels.  A wave holds 2 components x 64 pairs x 32 columns.
+//   LDS: NPL planes x 4 components x 80 halo slots x 80 B (32 k + 16 B pad), dynamic (76.8 KB in bf16x3, two workgroups per CU).
+//   The batch is tiled as ONE image of B*(H+1) rows (a zero row after every image: the vertical padding neighbours share).
+//   Weights are transformed and split ahead of time by a pack kernel into the order each wave consumes its B fragments.
+//   Epilogue: the two waves of a column half exchange one component through LDS; the {0,1} wave writes the even columns,
+//   the {2,3} wave the odd ones.  BatchNorm partial sums per (tile, column) as in conv_halo.hip.
+#include "conv_split.h"
+#include "conv_kernels.h"
+
+#include <cstdlib>
+
+namespace {
+
+using namespace fs_split;
+
+constexpr int XLD = 40;            // 16-bit elements per LDS slot (80 bytes)
+constexpr int WNS = 80;            // halo slots per component image: (Ph + 2) * PP <= WNS
+constexpr int NITEM = 3;           // (slot, channel quad) items per thread: 8 * WNS <= 256 * NITEM
+constexpr int CPLANE = WNS * XLD;  // elements per component image
+constexpr int PLANE = 4 * CPLANE;  // elements per precision plane
+
+struct WinoArgs {
+  const float* src; const unsigned char* ws; const unsigned* ew; const float* bias; float* dst; float* stats;
+  int B, H, W, Cs, Cd, Npad, nchunk;
+  int Ph, PP, tiles_x, nx, ny, Hv;
+  unsigned src_bytes, ws_bytes, dst_bytes;
+  unsigned magic_pp, magic_hv;
+  float drop_scale; uint32_t drop_thresh, drop_key;
+};
+
+// Weight pack: Up[g4 = ((chunk*3 + ky)*4 + c)*2 + s][plane][n][j] = plane-th term of U_c of filter row ky at
+// (k = 32*chunk + 16*s + j, n), scaled by 2^(14-Ew) in f16x2 (|U| <= 1.5 max|w| stays inside fp16), behind a HDR-byte header.
+//   forward : row ky = W[ky*3 + 0..2][k][n]                     (K = Cin,  N = Cout)
+//   bwd-data: row ky = W[8 - (ky*3 + 0..2)][n][k]               (K = Cout, N = Cin; taps flipped)
+template <class P>
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, unsigned char* __restrict__ ws, const unsigned* __restrict__ ew,
+                                                        int Cin, int Cout, int transposed, int Ks, int Ns, int Npad, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const float sc = P::SCALED ? pow2f(14 - exponent_of_bits(*ew)) : 1.f;
+  typename P::T* wp = reinterpret_cast<typename P::T*>(ws + HDR);
+  const int n = (int)(idx % Npad);
+  const int g4 = (int)(idx / Npad);
+  const int s = g4 & 1, c = (g4 >> 1) & 3, kyc = g4 >> 3;
+  const int chunk = kyc / 3, ky = kyc - 3 * chunk;
+  const int k0 = chunk * 32 + s * 16;
+  typename P::x8 p[P::NPL][2];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = k0 + j;
+    float g[3] = {0.f, 0.f, 0.f};
+    if (n < Ns && k < Ks) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int tap = ky * 3 + kx;
+        g[kx] = transposed ? w[((long)(8 - tap) * Cin + n) * Cout + k] : w[((long)tap * Cin + k) * Cout + n];
+      }
+    }
+    const float u = c == 0 ? g[0] : (c == 3 ? g[2] : (c == 1 ? 0.5f * ((g[0] + g[2]) + g[1]) : 0.5f * ((g[0] + g[2]) - g[1])));
+    typename P::T t[P::NPL];
+    P::split(u * sc, t);
+#pragma unroll
+    for (int pl = 0; pl < P::NPL; ++pl) p[pl][j >> 3][j & 7] = t[pl];
+  }
+#pragma unroll
+  for (int pl = 0; pl < P::NPL; ++pl) {
+    typename P::x8* o = reinterpret_cast<typename P::x8*>(wp + (((long)g4 * P::NPL + pl) * Npad + n) * 16);
+    o[0] = p[pl][0]; o[1] = p[pl][1];
+  }
+}
+
+template <class P>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
+  typedef typename P::x8 X8;
+  typedef typename P::x4 X4;
+  constexpr int NPL = P::NPL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typename P::T* Ah = reinterpret_cast<typename P::T*>(smem);                  // [NPL][4][WNS][XLD]
+  int* rowpix = reinterpret_cast<int*>(smem + NPL * PLANE * 2);                // [64]
+  unsigned* amax_cell = reinterpret_cast<unsigned*>(rowpix + 64);              // [2]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: cp selects the wave's B stream through the SGPR offset operand
+  const int cp = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nwg = a.nx * a.ny;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd = nwg >> 3, rm = nwg & 7;
+  const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
+  const int mt = wg / a.ny;
+  const int n0 = (wg - mt * a.ny) * 64;
+  const int ty = mt / a.tiles_x, tx = mt - ty * a.tiles_x;
+  const int y0 = ty * a.Ph, x0 = tx * 2 * a.PP;
+  const int nslots = (a.Ph + 2) * a.PP, npairs = a.Ph * a.PP;
+  // (image, row) of virtual row vy; gap rows and rows outside the stacked batch get row = H (invalid)
+  auto image_row = [&](int vy, int& bb, int& yy) {
+    const bool in = vy >= 0 && vy < a.B * a.Hv;
+    bb = in ? div_small(vy, a.magic_hv) : 0;
+    yy = in ? vy - bb * a.Hv : a.H;
+  };
+
+  if (tid < 64) {
+    const int p = (tid & ~31) + row_perm(tid & 31);
+    const int py = div_small(p, a.magic_pp), px = p - py * a.PP;
+    int bb, yy;
+    image_row(y0 + py, bb, yy);
+    const bool live = p < npairs && yy < a.H && x0 + 2 * px < a.W;
+    rowpix[tid] = live ? ((bb * a.H + yy) * a.W + x0 + 2 * px) : -1;
+  }
+  if (tid < 2) amax_cell[tid] = 0u;
+  const int q = tid & 7;
+  int goff[NITEM], gmask[NITEM];
+#pragma unroll
+  for (int i = 0; i < NITEM; ++i) {
+    const int slot = (tid >> 3) + 32 * i;
+    const int hy = div_small(slot, a.magic_pp), pj = slot - hy * a.PP;
+    const int ix = x0 + 2 * pj - 1;
+    int bb, iy;
+    image_row(y0 + hy - 1, bb, iy);
+    const bool rowok = slot < nslots && iy < a.H;
+    int m = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m |= (rowok && ix + e >= 0 && ix + e < a.W) ? (1 << e) : 0;
+    gmask[i] = m;
+    goff[i] = ((bb * a.H + (rowok ? iy : 0)) * a.W + ix) * a.Cs + 4 * q;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(a.src, a.src_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.ws, a.ws_bytes);
+
+  f32x4 ra[NITEM][4];
+  auto load_halo = [&](int chunk) {
+    const int c0 = chunk * 32;
+    const bool cok = c0 + 4 * q < a.Cs;
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = cok && ((gmask[i] >> e) & 1);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? (int)((unsigned)(goff[i] + e * a.Cs + c0) * 4u) : (int)OOB, 0, 0);
+        ra[i][e] = __builtin_bit_cast(f32x4, v);
+      }
+  };
+  auto transform = [&]() {               // d0..d3 -> T0..T3 in place
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+      const f32x4 d0 = ra[i][0], d1 = ra[i][1], d2 = ra[i][2], d3 = ra[i][3];
+      ra[i][0] = d0 - d2; ra[i][1] = d1 + d2; ra[i][2] = d2 - d1; ra[i][3] = d1 - d3;
+    }
+  };
+  auto tile_amax = [&](int cell) {       // max |T| of the transformed registers -> LDS cell
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(ra[i][c][e]));
+    m = wave_max(m);
+    if (lane == 0) atomicMax(&amax_cell[cell], __builtin_bit_cast(unsigned, m));
+  };
+  auto store_halo = [&](float sc) {
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+      const int slot = (tid >> 3) + 32 * i;
+      if (slot >= nslots) continue;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        X4 p[NPL];
+        P::split4(P::SCALED ? ra[i][c] * sc : ra[i][c], p);
+        const int o = (c * WNS + slot) * XLD + 4 * q;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Ah[pl * PLANE + o]) = p[pl];
+      }
+    }
+  };
+
+  int rowbase[2][3];                     // [mi][filter row]: element offset of the wave's first component image
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int p = 32 * mi + row_perm(l31);
+    const bool live = p < npairs;
+    const int py = live ? div_small(p, a.magic_pp) : 0, px = live ? p - py * a.PP : 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) rowbase[mi][r] = 2 * cp * CPLANE + ((py + r) * a.PP + px) * XLD + 8 * lh;
+  }
+  const int bvoff = HDR + ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2;
+  const int plane_bytes = a.Npad * 32;
+  const int step_bytes = NPL * plane_bytes;
+  const int G = a.nchunk * 12;           // B fragments this wave consumes
+
+  X8 fa[2][2][NPL];       // [buffer][mi][plane]
+  X8 fb[3][NPL];          // [ring slot][plane]: fragments run 2 steps ahead of the MFMAs
+  auto load_b = [&](int g, X8 (&dst)[NPL]) {
+    const int gg = g < G ? g : G - 1;
+    const int g4 = (gg >> 2) * 8 + 4 * cp + (gg & 3);      // wave-uniform: goes in the scalar offset operand
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff, g4 * step_bytes + pl * plane_bytes, 0);
+      dst[pl] = __builtin_bit_cast(X8, v);
+    }
+  };
+  auto read_a = [&](int step, X8 (&dst)[2][NPL]) {
+    const int ky = step >> 2, ci = (step >> 1) & 1, s2 = step & 1;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+        dst[mi][pl] = *reinterpret_cast<const X8*>(&Ah[pl * PLANE + rowbase[mi][ky] + ci * CPLANE + 16 * s2]);
+  };
+
+  f32x16 acc[2][2];       // [component of the pair][mi]
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ci][mi][r] = 0.f;
+  int E = EMIN;
+  load_b(0, fb[0]);
+  load_b(1, fb[1]);
+  load_halo(0);
+  __syncthreads();                        // amax cells zeroed before the first atomic
+  int g = 0;
+  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    transform();
+    if (P::SCALED) tile_amax(chunk & 1);
+    __syncthreads();                      // amax complete; every wave has finished reading the previous image
+    if (P::SCALED) {
+      const int ec = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[chunk & 1]));
+      if (ec > E) {
+        if (chunk > 0) {
+          const float f = pow2f(E - ec);
+#pragma unroll
+          for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[ci][mi][r] *= f;
+        }
+        E = ec;
+      }
+      if (tid == 0) amax_cell[(chunk + 1) & 1] = 0u;
+    }
+    store_halo(pow2f(14 - E));
+    __syncthreads();
+    if (chunk + 1 < a.nchunk) load_halo(chunk + 1);
+    read_a(0, fa[0]);
+#pragma unroll
+    for (int step = 0; step < 12; ++step) {
+      if (step + 1 < 12) read_a(step + 1, fa[(step + 1) & 1]);
+      load_b(g + 2, fb[(step + 2) % 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      const X8(&A)[2][NPL] = fa[step & 1];
+      const X8(&Bf)[NPL] = fb[step % 3];
+      const int ci = (step >> 1) & 1;
+#pragma unroll
+      for (int t = 0; t < P::NTERM; ++t) {         // smallest terms first, the two pair blocks interleaved
+        acc[ci][0] = P::mfma(A[0][P::ta(t)], Bf[P::tb(t)], acc[ci][0]);
+        acc[ci][1] = P::mfma(A[1][P::ta(t)], Bf[P::tb(t)], acc[ci][1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ++g;
+    }
+  }
+
+  // ---- epilogue: inverse transform across the two component-pair waves, then as conv_halo.hip ----
+  __syncthreads();                        // the halo image is dead
+  float* xch = reinterpret_cast<float*>(smem);             // [wave][2 mi x 16 regs][64 lanes]  (32 KB)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xch[(wave * 32 + mi * 16 + r) * 64 + lane] = cp == 0 ? acc[1][mi][r] : acc[0][mi][r];
+  __syncthreads();
+  float f1 = 1.f, f2 = 1.f;
+  if (P::SCALED) {
+    const int Ew = exponent_of_bits(*a.ew);
+    const int es = E + Ew - 28;
+    const bool one = es >= -126 && es <= 127;
+    f1 = one ? pow2f(es) : pow2f(E - 14);
+    f2 = one ? 1.f : pow2f(Ew - 14);
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
+  float csum = 0.f, csq = 0.f;
+  const int n = n0 + 32 * wn + l31;
+  if (n < a.Cd) {
+    const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const i32x4 pix = *reinterpret_cast<const i32x4*>(&rowpix[32 * mi + 8 * rg + 4 * lh]);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+          const int r = 4 * rg + ri;
+          const float other = xch[((wave ^ 2) * 32 + mi * 16 + r) * 64 + lane];
+          // even column (components 0,1 here, 2 received): m0 + m1 + m2;  odd column (2,3 here, 1 received): m1 - m2 - m3
+          const float m = cp == 0 ? (acc[0][mi][r] + acc[1][mi][r]) + other : (other - acc[0][mi][r]) - acc[1][mi][r];
+          const bool live = pix[ri] >= 0;
+          const unsigned e = (unsigned)(pix[ri] + cp) * (unsigned)a.Cd + (unsigned)n;
+          float v = P::SCALED ? fmaf(m * f2, f1, bv) : m + bv;
+          if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+          v = live ? v : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
+          csum += v; csq += v * v;
+        }
+      }
+    }
+  }
+  if (a.stats != nullptr) {
+    float* red = reinterpret_cast<float*>(smem + 32768);    // [wave][32 cols][2], behind the exchange buffer
+    const float s1 = csum + __shfl_xor(csum, 32, 64), s2 = csq + __shfl_xor(csq, 32, 64);
+    if (lh == 0) { red[(wave * 32 + l31) * 2] = s1; red[(wave * 32 + l31) * 2 + 1] = s2; }
+    __syncthreads();
+    if (tid < 128) {
+      const int col = tid >> 1, which = tid & 1;
+      const int w0 = col >> 5, c31 = col & 31;            // waves w0 (even columns) and w0 + 2 (odd columns)
+      const float v = red[(w0 * 32 + c31) * 2 + which] + red[((w0 + 2) * 32 + c31) * 2 + which];
+      if (n0 + col < a.Cd) a.stats[((long)mt * a.Cd + n0 + col) * 2 + which] = v;
+    }
+  }
+}
+
+const bool g_wino = [] { const char* e = getenv("FS_WINOGRAD"); return !(e && e[0] == '0'); }();
+
+// Ph rows x PP pairs <= 64 pairs per workgroup, halo (Ph+2)*PP <= WNS; fewest tiles over the stacked batch, then smallest halo.
+void wino_plan(int B, int H, int W, int& Ph, int& PP, int& tiles_x, int& nx) {
+  const long rows = (long)B * (H + 1);
+  const int wp = W / 2;
+  long best = -1;
+  Ph = 8; PP = 8;
+  for (int pp = 2; pp <= 32 && pp <= wp; ++pp) {      // div_small needs a divisor >= 2
+    int ph = 64 / pp;
+    while (ph > 1 && (ph + 2) * pp > WNS) --ph;
+    if ((ph + 2) * pp > WNS) continue;
+    const long tiles = (long)cdiv(rows, ph) * cdiv(wp, pp);
+    const long cost = tiles * 1000 + (ph + 2) * pp;
+    if (best < 0 || cost < best) { best = cost; Ph = ph; PP = pp; }
+  }
+  tiles_x = cdiv(wp, PP);
+  nx = cdiv(rows, Ph) * tiles_x;
+}
+
+template <class P>
+int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int Cin, int Cout, int transposed, hipStream_t stream) {
+  int e = FS_OK;
+  a.ew = P::SCALED ? fs_f16_weight_amax(w, (long)9 * Cin * Cout, ws, w_amax, stream, &e) : nullptr;
+  if (e != FS_OK) return e;
+  const long total = (long)a.nchunk * 24 * a.Npad;
+  hipLaunchKernelGGL((wino_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws),
+                     a.ew, Cin, Cout, transposed, a.Cs, a.Cd, a.Npad, total);
+  FS_LAUNCH_CHECK();
+  constexpr int lds = P::NPL * PLANE * 2 + 64 * 4 + 16;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (attr != hipSuccess) return (int)attr;
+  hipLaunchKernelGGL((conv3x3_wino_kernel<P>), dim3((unsigned)(a.nx * a.ny)), dim3(256), lds, stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+}  // namespace
+
+// f16x2 spends half the MFMAs per product, so the doubled split work of the transform only pays from 4 channel chunks up
+// (profiles/r02/winograd_kernel_times.txt: 64 -> 64 @ 80x80 103 us against 94 us, 128 -> 128 @ 40x40 90.6 against 93.7)
+bool fs_wino_eligible(int mode, int B, int H, int W, int Cs, int Cd) {
+  if (mode == 2 && Cs < 128) return false;
+  return g_wino && (mode == 1 || mode == 2) && W % 2 == 0 && W >= 4 && (long)B * (H + 1) < 65536 && Cs % 4 == 0 && Cd % 4 == 0 && Cs >= 32;
+}
+
+long fs_wino_pack_bytes(int mode, int Cs, int Cd) {
+  const int npl = mode == 2 ? 2 : 3;
+  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 63) / 64) * 64;
+  return HDR + nchunk * 24 * npl * Npad * 16 * 2;
+}
+
+int fs_wino_stats_slabs(int B, int H, int W) {
+  int Ph, PP, tx, nx;
+  wino_plan(B, H, W, Ph, PP, tx, nx);
+  return nx;
+}
+
+int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
+                    int B, int H, int W, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh,
+                    uint32_t drop_key, hipStream_t stream) {
+  WinoArgs a;
+  a.src = src; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = dst; a.stats = stats;
+  a.B = B; a.H = H; a.W = W; a.Cs = Cs; a.Cd = Cd;
+  a.Npad = ((Cd + 63) / 64) * 64;
+  a.nchunk = (Cs + 31) / 32;
+  wino_plan(B, H, W, a.Ph, a.PP, a.tiles_x, a.nx);
+  a.ny = a.Npad / 64;
+  a.Hv = H + 1;
+  a.magic_hv = div_magic(a.Hv);
+  a.magic_pp = div_magic(a.PP);
+  const long pack_bytes = fs_wino_pack_bytes(mode, Cs, Cd);
+  if (!fs_wino_eligible(mode, B, H, W, Cs, Cd) || pack_bytes >= 2147483647L || (size_t)B * H * W * Cs * 4 >= 4294967000UL ||
+      (size_t)B * H * W * Cd * 4 >= 4294967000UL)
+    return FS_ERR_ARG;
+  a.src_bytes = (unsigned)((size_t)B * H * W * Cs * 4);
+  a.dst_bytes = (unsigned)((size_t)B * H * W * Cd * 4);
+  a.ws_bytes = (unsigned)pack_bytes;
+  a.drop_scale = drop_scale; a.drop_thresh = drop_thresh; a.drop_key = drop_key;
+  return mode == 2 ? run_wino<PrecF16>(a, w, ws, w_amax, Cin, Cout, transposed, stream)
+                   : run_wino<PrecX3>(a, w, ws, w_amax, Cin, Cout, transposed, stream);
+}

@@ -204,9 +204,15 @@ def test_conv_dispatch_predicate_above_4gb():
             assert below == (4 if mode else 1) and above == 0, (mode, below, above)      # 4 = the 1x1 GEMM kernel of the split modes
             # between 4 and 8 GB (2^30..2^31 elements) -- the range the old `elements < 2^31` guard let through
             assert lib.fs_conv2d_kernel_choice(100, 256, 256, 256, 256, 256, 64, 1, 1, 1, 0, 1, 0, ws) == 0
-            # 3x3 stride 1: halo kernel below 4 GB in the split modes, generic above (source or destination)
+            # 3x3 stride 1: halo kernel (its F(2,3) variant, 5, where the width is even; plain halo, 2, on odd widths) below 4 GB
+            # in the split modes, generic above (source or destination)
             small = lib.fs_conv2d_kernel_choice(64, 80, 80, 64, 80, 80, 64, 3, 3, 1, 1, 1, 0, ws)
-            assert small == (2 if mode else 1), (mode, small)
+            wino_on = os.environ.get("FS_WINOGRAD", "1") != "0"
+            assert small == ((5 if wino_on and mode == 1 else 2) if mode else 1), (mode, small)      # f16x2: from 128 channels up
+            wide = lib.fs_conv2d_kernel_choice(64, 40, 40, 128, 40, 40, 128, 3, 3, 1, 1, 1, 0, ws)
+            assert wide == ((5 if wino_on else 2) if mode else 1), (mode, wide)
+            odd = lib.fs_conv2d_kernel_choice(64, 81, 81, 64, 81, 81, 64, 3, 3, 1, 1, 1, 0, ws)
+            assert odd == (2 if mode else 1), (mode, odd)
             assert lib.fs_conv2d_kernel_choice(2800, 80, 80, 64, 80, 80, 64, 3, 3, 1, 1, 1, 0, ws) == 0       # 4.6 GB source
             # stride 2 forward with a source >= 4 GB and a destination < 4 GB: falls back instead of raising
             assert lib.fs_conv2d_kernel_choice(2800, 80, 80, 64, 40, 40, 128, 3, 3, 2, 1, 1, 0, ws) == 0
