@@ -78,25 +78,31 @@ struct PrecX3 {
     p[1] = (T)r;
     p[2] = (T)(r - (float)p[1]);
   }
-  // the same split on 4 values, written on pairs so that each level is one v_cvt_pk_bf16_f32, a shift, a mask and one packed
-  // subtract per pair (4.5 VALU per value instead of ~6.5 from the scalar form); bit-identical results
+  // the same decomposition on 4 values in integer arithmetic: a plane is the fp32 value rounded to its top 16 bits
+  // ((bits + 0x8000) & 0xffff0000, ties away from zero), the remainder x - plane is exact in fp32, and the third plane takes
+  // what is left (<= 8 significant bits: exact).  x = p0 + p1 + p2 holds exactly, as for split(); the planes can differ from
+  // split()'s in the last place on ties.  6 full-rate VALU per value + 1.5 to pack, no conversion instructions.
   static __device__ __forceinline__ void split4(f32x4 v, x4 (&p)[NPL]) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 pk[NPL];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      f2 x = {v[2 * h], v[2 * h + 1]};
+      unsigned hi[2][NPL];
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        const b2 t = __builtin_convertvector(x, b2);
-        p[pl][2 * h] = t[0]; p[pl][2 * h + 1] = t[1];
-        if (pl + 1 < NPL) {
-          const unsigned u = __builtin_bit_cast(unsigned, t);
-          const f2 hf = {__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
-          x = x - hf;
+      for (int e = 0; e < 2; ++e) {
+        float x = v[2 * h + e];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          const unsigned b = __builtin_bit_cast(unsigned, x);
+          hi[e][pl] = pl + 1 < NPL ? ((b + 0x8000u) & 0xffff0000u) : b;      // last plane: the remainder has <= 8 significant bits
+          if (pl + 1 < NPL) x = x - __builtin_bit_cast(float, hi[e][pl]);
         }
       }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) pk[pl][h] = __builtin_amdgcn_perm(hi[1][pl], hi[0][pl], 0x07060302u);   // {hi[0]>>16, hi[1]>>16}
     }
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) p[pl] = __builtin_bit_cast(x4, pk[pl]);
   }
   static constexpr int NTERM = 6;            // (0,2) (1,1) (2,0) (0,1) (1,0) (0,0)
   static __device__ __forceinline__ constexpr int ta(int t) { return t < 3 ? t : (t == 4 ? 1 : 0); }

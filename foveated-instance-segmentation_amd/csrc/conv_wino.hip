@@ -21,6 +21,7 @@
 #include "conv_split.h"
 #include "conv_kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -40,7 +41,16 @@ struct WinoArgs {
   unsigned src_bytes, ws_bytes, dst_bytes;
   unsigned magic_pp, magic_hv;
   float drop_scale; uint32_t drop_thresh, drop_key;
+#ifdef FS_WINO_TRACE
+  long long* dbg;                  // [workgroup][32] phase time stamps of wave 0 (tools/wino_trace.sh)
+#endif
 };
+
+#ifdef FS_WINO_TRACE
+#define WINO_STAMP(i) do { if (tid == 0) a.dbg[(long)blockIdx.x * 32 + (i)] = clock64(); } while (0)
+#else
+#define WINO_STAMP(i) do { } while (0)
+#endif
 
 // Weight pack: Up[g4 = ((chunk*3 + ky)*4 + c)*2 + s][plane][n][j] = plane-th term of U_c of filter row ky at
 // (k = 32*chunk + 16*s + j, n), scaled by 2^(14-Ew) in f16x2 (|U| <= 1.5 max|w| stays inside fp16), behind a HDR-byte header.
@@ -97,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: cp selects the wave's B stream through the SGPR offset operand
   const int cp = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
+  WINO_STAMP(0);
   const int nwg = a.nx * a.ny;
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
   const int qd = nwg >> 3, rm = nwg & 7;
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     int bb, yy;
     image_row(y0 + py, bb, yy);
     const bool live = p < npairs && yy < a.H && x0 + 2 * px < a.W;
-    rowpix[tid] = live ? ((bb * a.H + yy) * a.W + x0 + 2 * px) : -1;
+    rowpix[tid] = live ? ((bb * a.H + yy) * a.W + x0 + 2 * px) * a.Cd : -1;      // element offset of the pair's even pixel
   }
   if (tid < 2) amax_cell[tid] = 0u;
   const int q = tid & 7;
@@ -234,11 +245,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   load_b(1, fb[1]);
   load_halo(0);
   __syncthreads();                        // amax cells zeroed before the first atomic
+  WINO_STAMP(1);
   int g = 0;
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
     transform();
     if (P::SCALED) tile_amax(chunk & 1);
+    if (chunk < 4) WINO_STAMP(2 + 5 * chunk);
     __syncthreads();                      // amax complete; every wave has finished reading the previous image
+    if (chunk < 4) WINO_STAMP(3 + 5 * chunk);
     if (P::SCALED) {
       const int ec = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[chunk & 1]));
       if (ec > E) {
@@ -256,7 +270,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       if (tid == 0) amax_cell[(chunk + 1) & 1] = 0u;
     }
     store_halo(pow2f(14 - E));
+    if (chunk < 4) WINO_STAMP(4 + 5 * chunk);
     __syncthreads();
+    if (chunk < 4) WINO_STAMP(5 + 5 * chunk);
     if (chunk + 1 < a.nchunk) load_halo(chunk + 1);
     read_a(0, fa[0]);
 #pragma unroll
@@ -275,15 +291,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       ++g;
     }
+    if (chunk < 4) WINO_STAMP(6 + 5 * chunk);
   }
 
   // ---- epilogue: inverse transform across the two component-pair waves, then as conv_halo.hip ----
+  WINO_STAMP(22);
   __syncthreads();                        // the halo image is dead
-  float* xch = reinterpret_cast<float*>(smem);             // [wave][2 mi x 16 regs][64 lanes]  (32 KB)
+  WINO_STAMP(23);
+  f32x4* xch = reinterpret_cast<f32x4*>(smem);             // [wave][2 mi x 4 row groups][64 lanes] x 4 rows  (32 KB)
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) xch[(wave * 32 + mi * 16 + r) * 64 + lane] = cp == 0 ? acc[1][mi][r] : acc[0][mi][r];
+    for (int rg = 0; rg < 4; ++rg) {
+      f32x4 v;
+#pragma unroll
+      for (int ri = 0; ri < 4; ++ri) v[ri] = cp == 0 ? acc[1][mi][4 * rg + ri] : acc[0][mi][4 * rg + ri];
+      xch[(wave * 8 + mi * 4 + rg) * 64 + lane] = v;
+    }
   __syncthreads();
   float f1 = 1.f, f2 = 1.f;
   if (P::SCALED) {
@@ -298,19 +322,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int n = n0 + 32 * wn + l31;
   if (n < a.Cd) {
     const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
+    const int ncol = n + cp * a.Cd;                        // the {2,3} wave writes the odd pixel of the pair
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const i32x4 pix = *reinterpret_cast<const i32x4*>(&rowpix[32 * mi + 8 * rg + 4 * lh]);
+        const f32x4 other = xch[((wave ^ 2) * 8 + mi * 4 + rg) * 64 + lane];
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri) {
           const int r = 4 * rg + ri;
-          const float other = xch[((wave ^ 2) * 32 + mi * 16 + r) * 64 + lane];
           // even column (components 0,1 here, 2 received): m0 + m1 + m2;  odd column (2,3 here, 1 received): m1 - m2 - m3
-          const float m = cp == 0 ? (acc[0][mi][r] + acc[1][mi][r]) + other : (other - acc[0][mi][r]) - acc[1][mi][r];
+          const float m = cp == 0 ? (acc[0][mi][r] + acc[1][mi][r]) + other[ri] : (other[ri] - acc[0][mi][r]) - acc[1][mi][r];
           const bool live = pix[ri] >= 0;
-          const unsigned e = (unsigned)(pix[ri] + cp) * (unsigned)a.Cd + (unsigned)n;
+          const unsigned e = (unsigned)(pix[ri] + ncol);
           float v = P::SCALED ? fmaf(m * f2, f1, bv) : m + bv;
           if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
           v = live ? v : 0.f;
@@ -332,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       if (n0 + col < a.Cd) a.stats[((long)mt * a.Cd + n0 + col) * 2 + which] = v;
     }
   }
+  WINO_STAMP(24);
 }
 
 const bool g_wino = [] { const char* e = getenv("FS_WINOGRAD"); return !(e && e[0] == '0'); }();
@@ -366,8 +392,38 @@ int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int 
   constexpr int lds = P::NPL * PLANE * 2 + 64 * 4 + 16;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (attr != hipSuccess) return (int)attr;
+#ifdef FS_WINO_TRACE
+  static long long* dbg = nullptr;
+  const long nwg = (long)a.nx * a.ny;
+  if (dbg == nullptr && hipMalloc(&dbg, sizeof(long long) * 32 * 65536) != hipSuccess) return FS_ERR_ARG;
+  if (nwg > 65536) return FS_ERR_ARG;
+  a.dbg = dbg;
+  hipMemsetAsync(dbg, 0, sizeof(long long) * 32 * nwg, stream);
+#endif
   hipLaunchKernelGGL((conv3x3_wino_kernel<P>), dim3((unsigned)(a.nx * a.ny)), dim3(256), lds, stream, a);
   FS_LAUNCH_CHECK();
+#ifdef FS_WINO_TRACE
+  {
+    hipStreamSynchronize(stream);
+    static long long host[32 * 65536];
+    hipMemcpy(host, dbg, sizeof(long long) * 32 * nwg, hipMemcpyDeviceToHost);
+    double sum[32] = {0};
+    long long tmin = host[0], tmax = host[24];
+    for (long w = 0; w < nwg; ++w) {
+      for (int i = 1; i < 25; ++i) {
+        if (host[w * 32 + i] == 0) continue;
+        int prev = i - 1;
+        while (prev > 0 && host[w * 32 + prev] == 0) --prev;
+        sum[i] += (double)(host[w * 32 + i] - host[w * 32 + prev]);
+      }
+      if (host[w * 32] < tmin) tmin = host[w * 32];
+      if (host[w * 32 + 24] > tmax) tmax = host[w * 32 + 24];
+    }
+    fprintf(stderr, "wino trace B%d %dx%d %d->%d nchunk %d nwg %ld span %lld:", a.B, a.H, a.W, a.Cs, a.Cd, a.nchunk, nwg, tmax - tmin);
+    for (int i = 1; i < 25; ++i) if (sum[i] > 0) fprintf(stderr, " [%d]%.0f", i, sum[i] / nwg);
+    fprintf(stderr, "\n");
+  }
+#endif
   return FS_OK;
 }
 
