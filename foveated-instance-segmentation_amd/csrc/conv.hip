@@ -602,24 +602,21 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(AffArgs a) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       X4 p[NPL];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        T t[NPL];
-        P::split(P::SCALED ? ra[i][e] * sa : ra[i][e], t);
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) p[pl][e] = t[pl];
-      }
+      P::split4(P::SCALED ? ra[i] * sa : ra[i], p);
       const int o = (arow + 32 * i) * XLD + 4 * q;
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Ap[pl][o]) = p[pl];
     }
     X8 w[NPL];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      T t[NPL];
-      P::split(P::SCALED ? rb[j] * sb : rb[j], t);
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 v = {rb[4 * h], rb[4 * h + 1], rb[4 * h + 2], rb[4 * h + 3]};
+      X4 p[NPL];
+      P::split4(P::SCALED ? v * sb : v, p);
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) w[pl][j] = t[pl];
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[pl][4 * h + e] = p[pl][e];
     }
     const int o = bn * XLD + bk0;
 #pragma unroll

@@ -127,13 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(PwArgs a) {
       for (int i = 0; i < NITEM; ++i) {
         const int row = (tid >> 3) + 32 * i;
         X4 p[NPL];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          typename P::T t[NPL];
-          P::split(P::SCALED ? ra[cc][i][e] * sc : ra[cc][i][e], t);
-#pragma unroll
-          for (int pl = 0; pl < NPL; ++pl) p[pl][e] = t[pl];
-        }
+        P::split4(P::SCALED ? ra[cc][i] * sc : ra[cc][i], p);
         const int o = cc * IMG + row * XLD + 4 * q;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Ah[pl * RC * IMG + o]) = p[pl];

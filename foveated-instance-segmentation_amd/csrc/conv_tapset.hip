@@ -169,13 +169,7 @@ __global__ __launch_bounds__(256) void conv_tapset_kernel(TsArgs a) {
     for (int i = 0; i < NITEM; ++i) {
       const int slot = (tid >> 3) + 32 * i;
       X4 p[NPL];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        typename P::T t[NPL];
-        P::split(P::SCALED ? ra[i][e] * sc : ra[i][e], t);
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) p[pl][e] = t[pl];
-      }
+      P::split4(P::SCALED ? ra[i] * sc : ra[i], p);
       const int o = slot * XLD + 4 * q;
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Ah[pl * PLANE + o]) = p[pl];

@@ -193,26 +193,14 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void conv_wgrad_class_ke
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
       X4 p[NPL];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        typename P::T t[NPL];
-        P::split(P::SCALED ? rx[i][e] * sx : rx[i][e], t);
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) p[pl][e] = t[pl];
-      }
+      P::split4(P::SCALED ? rx[i] * sx : rx[i], p);
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Xl[xw + i * 1024 + pl * X_PLANE]) = p[pl];
     }
 #pragma unroll
     for (int i = 0; i < NYI; ++i) {
       X4 p[NPL];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        typename P::T t[NPL];
-        P::split(P::SCALED ? ry[i][e] * sy : ry[i][e], t);
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) p[pl][e] = t[pl];
-      }
+      P::split4(P::SCALED ? ry[i] * sy : ry[i], p);
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Yl[yw + i * 1024 + pl * Y_PLANE]) = p[pl];
     }
