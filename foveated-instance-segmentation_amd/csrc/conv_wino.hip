@@ -59,37 +59,47 @@ struct WinoArgs {
 template <class P>
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, unsigned char* __restrict__ ws, const unsigned* __restrict__ ew,
                                                         int Cin, int Cout, int transposed, int Ks, int Ns, int Npad, long total) {
+  // one thread per (chunk, ky, 8-k quarter, n): the 3 taps of 8 k are loaded once (24 independent loads, clamped addresses)
+  // and all 4 components are formed from them
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const float sc = P::SCALED ? pow2f(14 - exponent_of_bits(*ew)) : 1.f;
   typename P::T* wp = reinterpret_cast<typename P::T*>(ws + HDR);
   const int n = (int)(idx % Npad);
-  const int g4 = (int)(idx / Npad);
-  const int s = g4 & 1, c = (g4 >> 1) & 3, kyc = g4 >> 3;
+  const int qk = (int)(idx / Npad);
+  const int quarter = qk & 3, kyc = qk >> 2;                   // quarter = s * 2 + half of the 16-k fragment
   const int chunk = kyc / 3, ky = kyc - 3 * chunk;
-  const int k0 = chunk * 32 + s * 16;
-  typename P::x8 p[P::NPL][2];
+  const int k0 = chunk * 32 + quarter * 8;
+  const bool nok = n < Ns;
+  const int nc = nok ? n : 0;
+  float g[3][8];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int k = k0 + j;
-    float g[3] = {0.f, 0.f, 0.f};
-    if (n < Ns && k < Ks) {
+  for (int kx = 0; kx < 3; ++kx) {
+    const int tap = ky * 3 + kx;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int tap = ky * 3 + kx;
-        g[kx] = transposed ? w[((long)(8 - tap) * Cin + n) * Cout + k] : w[((long)tap * Cin + k) * Cout + n];
-      }
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      const bool ok = nok && k < Ks;
+      const int kc = ok ? k : 0;
+      const float v = transposed ? w[((long)(8 - tap) * Cin + nc) * Cout + kc] : w[((long)tap * Cin + kc) * Cout + nc];
+      g[kx][j] = ok ? v * sc : 0.f;
     }
-    const float u = c == 0 ? g[0] : (c == 3 ? g[2] : (c == 1 ? 0.5f * ((g[0] + g[2]) + g[1]) : 0.5f * ((g[0] + g[2]) - g[1])));
-    typename P::T t[P::NPL];
-    P::split(u * sc, t);
-#pragma unroll
-    for (int pl = 0; pl < P::NPL; ++pl) p[pl][j >> 3][j & 7] = t[pl];
   }
 #pragma unroll
-  for (int pl = 0; pl < P::NPL; ++pl) {
-    typename P::x8* o = reinterpret_cast<typename P::x8*>(wp + (((long)g4 * P::NPL + pl) * Npad + n) * 16);
-    o[0] = p[pl][0]; o[1] = p[pl][1];
+  for (int c = 0; c < 4; ++c) {
+    typename P::x8 p[P::NPL];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float u = c == 0 ? g[0][j] : (c == 3 ? g[2][j] : (c == 1 ? 0.5f * ((g[0][j] + g[2][j]) + g[1][j]) : 0.5f * ((g[0][j] + g[2][j]) - g[1][j])));
+      typename P::T t[P::NPL];
+      P::split(u, t);
+#pragma unroll
+      for (int pl = 0; pl < P::NPL; ++pl) p[pl][j] = t[pl];
+    }
+    const int g4 = (kyc * 4 + c) * 2 + (quarter >> 1);
+#pragma unroll
+    for (int pl = 0; pl < P::NPL; ++pl)
+      *reinterpret_cast<typename P::x8*>(wp + (((long)g4 * P::NPL + pl) * Npad + n) * 16 + 8 * (quarter & 1)) = p[pl];
   }
 }
 
@@ -385,7 +395,7 @@ int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int 
   int e = FS_OK;
   a.ew = P::SCALED ? fs_f16_weight_amax(w, (long)9 * Cin * Cout, ws, w_amax, stream, &e) : nullptr;
   if (e != FS_OK) return e;
-  const long total = (long)a.nchunk * 24 * a.Npad;
+  const long total = (long)a.nchunk * 12 * a.Npad;
   hipLaunchKernelGGL((wino_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws),
                      a.ew, Cin, Cout, transposed, a.Cs, a.Cd, a.Npad, total);
   FS_LAUNCH_CHECK();
