@@ -59,12 +59,12 @@ def _profiled_traffic(kernel):
     return None
 
 
-def _profiled_mfma_busy(mode):
+def _profiled_mfma_busy(mode, kernel):
     """MFMA-pipe busy fraction and sustained clock of the dominant kernel from the committed SQ-counter passes
-    (profiles/r02/pmc/sq_<mode>_conv3x3_halo_kernel_fwd_shape0.txt: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)), or None."""
+    (profiles/r02/pmc/sq_<mode>_<kernel>_fwd_shape0.txt: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)), or None."""
     import ast
     import re
-    rel = f"profiles/r02/pmc/sq_{mode}_conv3x3_halo_kernel_fwd_shape0.txt"
+    rel = f"profiles/r02/pmc/sq_{mode}_{kernel}_fwd_shape0.txt"
     try:
         vals = {}
         for line in open(os.path.join(ROOT, rel)):
@@ -363,10 +363,22 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
                 "share_of_serial_step": round(kk["total_ms"] / (1000.0 * serial_elapsed), 3)}
 
     if tag is not None and "conv3x3" in summ:
+        # every 3x3 stride-1 layer of this workload has an even width: in bf16x3 all of them take the F(2,3) row kernel, in f16x2 those
+        # with >= 128 source channels do (csrc/conv_wino.hip: fs_wino_eligible) and the rest the plain halo kernel
+        wino = os.environ.get("FS_WINOGRAD", "1") != "0"
+        kname = "conv3x3_wino_kernel" if wino else "conv3x3_halo_kernel"
+        what = (f"conv3x3_wino_kernel<{tag}> (3x3 stride-1 forward + bwd-data, halo-tiled implicit GEMM with F(2,3) minimal filtering along the "
+                "row: 12 of the direct form's 18 MFMA steps per pixel pair are executed"
+                + ("; layers below 128 source channels run conv3x3_halo_kernel, the direct form" if mode == "f16x2" else "") + f"; {how}; ")
+        if not wino:
+            what = f"conv3x3_halo_kernel<{tag}> (3x3 stride-1 forward + bwd-data, halo-tiled implicit GEMM; {how}; "
         out["roofline"] = entry(
             summ["conv3x3"],
-            f"conv3x3_halo_kernel<{tag}> (3x3 stride-1 forward + bwd-data, halo-tiled implicit GEMM; {how}; achieved = algorithmic fp32 FLOP/s "
-            "over the C-ABI call incl. its weight pack pre-kernel, peak = dense 16-bit MFMA peak / MFMAs per product)", "conv3x3_halo_kernel")
+            what + "achieved = ALGORITHMIC FLOP/s of the direct convolution (2*B*H*W*Cout*9*Cin per launch) over the C-ABI call incl. its weight "
+            "pack pre-kernel, peak = dense 16-bit MFMA peak / MFMAs per product)", kname)
+        out["roofline"]["executed_mfma_fraction"] = round(2.0 / 3.0, 4) if (wino and mode == "bf16x3") else None
+        out["roofline"]["note"] = ("frac prices the direct-convolution FLOPs against the dense peak; the matrix cores execute executed_mfma_fraction of them "
+                                   "(frac * executed_mfma_fraction = share of the peak the MFMA pipe actually delivers)") if (wino and mode == "bf16x3") else None
         if "wgrad3x3" in summ:
             out["roofline_wgrad"] = entry(summ["wgrad3x3"], f"conv_wgrad_class_kernel<{tag},3,3> (3x3 stride-1 bwd-weight, 9 taps per workgroup)",
                                           f"conv_wgrad_class_kernel<fs_split::{tag}, 3, 3")
@@ -379,7 +391,8 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
         if "conv_wgrad" in summ:
             out["roofline_wgrad"] = entry(summ["conv_wgrad"], "conv_wgrad_taps_kernel<3|9> + conv_wgrad_kernel (bwd-weight, fp32 MFMA)", "conv_wgrad_taps_kernel")
     if "roofline" in out:
-        out["roofline"]["mfma_utilisation"] = _profiled_mfma_busy(mode)       # offline SQ counters of the same kernel (rocprofv3 --pmc)
+        dominant = "conv3x3_wino_kernel" if (mode == "bf16x3" and os.environ.get("FS_WINOGRAD", "1") != "0") else "conv3x3_halo_kernel"
+        out["roofline"]["mfma_utilisation"] = _profiled_mfma_busy(mode, dominant)       # offline SQ counters of the same kernel (rocprofv3 --pmc)
         out["roofline"]["serial_ms_per_step"] = round(1000.0 * serial_elapsed / nsteps, 2)
         out["roofline"]["measured"] = "second pass of the same K steps with branch streams serialised, HIP events per launch on the launch stream"
     if "bn_fwd" in summ:

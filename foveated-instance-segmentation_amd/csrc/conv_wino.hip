@@ -30,7 +30,6 @@ using namespace fs_split;
 
 constexpr int XLD = 40;            // 16-bit elements per LDS slot (80 bytes)
 constexpr int WNS = 80;            // halo slots per component image: (Ph + 2) * PP <= WNS
-constexpr int NITEM = 3;           // (slot, channel quad) items per thread: 8 * WNS <= 256 * NITEM
 constexpr int CPLANE = WNS * XLD;  // elements per component image
 constexpr int PLANE = 4 * CPLANE;  // elements per precision plane
 
@@ -103,11 +102,16 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
   }
 }
 
-template <class P>
+// NJ = 32-column sub-tiles per wave.  NJ = 1: 64 pairs x 64 columns per workgroup (a wave holds 2 pair blocks x 1 sub-tile).
+// NJ = 2: 32 pairs x 128 columns (1 pair block x 2 sub-tiles): the halo image is transformed and split once for twice the
+// output channels -- that VALU work competes with the MFMAs for issue slots -- at twice the B-fragment traffic per MFMA.
+template <class P, int NJ>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   typedef typename P::x8 X8;
   typedef typename P::x4 X4;
   constexpr int NPL = P::NPL;
+  constexpr int MI = 2 / NJ;             // 32-pair blocks per wave
+  constexpr int NITEM = NJ == 1 ? 3 : 2; // (slot, channel quad) items per thread: 8 * slots <= 256 * NITEM
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typename P::T* Ah = reinterpret_cast<typename P::T*>(smem);                  // [NPL][4][WNS][XLD]
   int* rowpix = reinterpret_cast<int*>(smem + NPL * PLANE * 2);                // [64]
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int qd = nwg >> 3, rm = nwg & 7;
   const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
   const int mt = wg / a.ny;
-  const int n0 = (wg - mt * a.ny) * 64;
+  const int n0 = (wg - mt * a.ny) * 64 * NJ;
   const int ty = mt / a.tiles_x, tx = mt - ty * a.tiles_x;
   const int y0 = ty * a.Ph, x0 = tx * 2 * a.PP;
   const int nslots = (a.Ph + 2) * a.PP, npairs = a.Ph * a.PP;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     yy = in ? vy - bb * a.Hv : a.H;
   };
 
-  if (tid < 64) {
+  if (tid < 32 * MI) {
     const int p = (tid & ~31) + row_perm(tid & 31);
     const int py = div_small(p, a.magic_pp), px = p - py * a.PP;
     int bb, yy;
@@ -209,47 +213,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     }
   };
 
-  int rowbase[2][3];                     // [mi][filter row]: element offset of the wave's first component image
+  int rowbase[MI][3];                    // [mi][filter row]: element offset of the wave's first component image
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
     const int p = 32 * mi + row_perm(l31);
     const bool live = p < npairs;
     const int py = live ? div_small(p, a.magic_pp) : 0, px = live ? p - py * a.PP : 0;
 #pragma unroll
     for (int r = 0; r < 3; ++r) rowbase[mi][r] = 2 * cp * CPLANE + ((py + r) * a.PP + px) * XLD + 8 * lh;
   }
-  const int bvoff = HDR + ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2;
+  const int bvoff = HDR + ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2;      // sub-tile j: + j * 64 columns = j * 2048 bytes
   const int plane_bytes = a.Npad * 32;
   const int step_bytes = NPL * plane_bytes;
   const int G = a.nchunk * 12;           // B fragments this wave consumes
 
-  X8 fa[2][2][NPL];       // [buffer][mi][plane]
-  X8 fb[3][NPL];          // [ring slot][plane]: fragments run 2 steps ahead of the MFMAs
-  auto load_b = [&](int g, X8 (&dst)[NPL]) {
+  X8 fa[2][MI][NPL];      // [buffer][mi][plane]
+  X8 fb[3][NJ][NPL];      // [ring slot][sub-tile][plane]: fragments run 2 steps ahead of the MFMAs
+  auto load_b = [&](int g, X8 (&dst)[NJ][NPL]) {
     const int gg = g < G ? g : G - 1;
     const int g4 = (gg >> 2) * 8 + 4 * cp + (gg & 3);      // wave-uniform: goes in the scalar offset operand
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff, g4 * step_bytes + pl * plane_bytes, 0);
-      dst[pl] = __builtin_bit_cast(X8, v);
-    }
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff + j * 2048, g4 * step_bytes + pl * plane_bytes, 0);
+        dst[j][pl] = __builtin_bit_cast(X8, v);
+      }
   };
-  auto read_a = [&](int step, X8 (&dst)[2][NPL]) {
+  auto read_a = [&](int step, X8 (&dst)[MI][NPL]) {
     const int ky = step >> 2, ci = (step >> 1) & 1, s2 = step & 1;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl)
         dst[mi][pl] = *reinterpret_cast<const X8*>(&Ah[pl * PLANE + rowbase[mi][ky] + ci * CPLANE + 16 * s2]);
   };
 
-  f32x16 acc[2][2];       // [component of the pair][mi]
+  f32x16 acc[2][2];       // [component of the pair][block b = mi (NJ = 1) or sub-tile j (NJ = 2)]
 #pragma unroll
   for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ci][mi][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[ci][b][r] = 0.f;
   int E = EMIN;
   load_b(0, fb[0]);
   load_b(1, fb[1]);
@@ -271,9 +277,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
           for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc[ci][mi][r] *= f;
+              for (int r = 0; r < 16; ++r) acc[ci][b][r] *= f;
         }
         E = ec;
       }
@@ -290,13 +296,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       if (step + 1 < 12) read_a(step + 1, fa[(step + 1) & 1]);
       load_b(g + 2, fb[(step + 2) % 3]);
       __builtin_amdgcn_sched_barrier(0);
-      const X8(&A)[2][NPL] = fa[step & 1];
-      const X8(&Bf)[NPL] = fb[step % 3];
+      const X8(&A)[MI][NPL] = fa[step & 1];
+      const X8(&Bf)[NJ][NPL] = fb[step % 3];
       const int ci = (step >> 1) & 1;
 #pragma unroll
-      for (int t = 0; t < P::NTERM; ++t) {         // smallest terms first, the two pair blocks interleaved
-        acc[ci][0] = P::mfma(A[0][P::ta(t)], Bf[P::tb(t)], acc[ci][0]);
-        acc[ci][1] = P::mfma(A[1][P::ta(t)], Bf[P::tb(t)], acc[ci][1]);
+      for (int t = 0; t < P::NTERM; ++t) {         // smallest terms first, the two blocks interleaved
+        acc[ci][0] = P::mfma(A[0][P::ta(t)], Bf[0][P::tb(t)], acc[ci][0]);
+        acc[ci][1] = P::mfma(A[MI - 1][P::ta(t)], Bf[NJ - 1][P::tb(t)], acc[ci][1]);
       }
       __builtin_amdgcn_sched_barrier(0);
       ++g;
@@ -308,15 +314,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   WINO_STAMP(22);
   __syncthreads();                        // the halo image is dead
   WINO_STAMP(23);
-  f32x4* xch = reinterpret_cast<f32x4*>(smem);             // [wave][2 mi x 4 row groups][64 lanes] x 4 rows  (32 KB)
+  f32x4* xch = reinterpret_cast<f32x4*>(smem);             // [wave][2 blocks x 4 row groups][64 lanes] x 4 rows  (32 KB)
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int b = 0; b < 2; ++b)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       f32x4 v;
 #pragma unroll
-      for (int ri = 0; ri < 4; ++ri) v[ri] = cp == 0 ? acc[1][mi][4 * rg + ri] : acc[0][mi][4 * rg + ri];
-      xch[(wave * 8 + mi * 4 + rg) * 64 + lane] = v;
+      for (int ri = 0; ri < 4; ++ri) v[ri] = cp == 0 ? acc[1][b][4 * rg + ri] : acc[0][b][4 * rg + ri];
+      xch[(wave * 8 + b * 4 + rg) * 64 + lane] = v;
     }
   __syncthreads();
   float f1 = 1.f, f2 = 1.f;
@@ -328,42 +334,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     f2 = one ? 1.f : pow2f(Ew - 14);
   }
   const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
-  float csum = 0.f, csq = 0.f;
-  const int n = n0 + 32 * wn + l31;
-  if (n < a.Cd) {
+  float csum[NJ], csq[NJ];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int mi = NJ == 1 ? b : 0, j = NJ == 1 ? 0 : b;
+    if (mi == 0) { csum[j] = 0.f; csq[j] = 0.f; }
+    const int n = n0 + 64 * j + 32 * wn + l31;
+    if (n >= a.Cd) continue;
     const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
     const int ncol = n + cp * a.Cd;                        // the {2,3} wave writes the odd pixel of the pair
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int rg = 0; rg < 4; ++rg) {
+      const i32x4 pix = *reinterpret_cast<const i32x4*>(&rowpix[32 * mi + 8 * rg + 4 * lh]);
+      const f32x4 other = xch[((wave ^ 2) * 8 + b * 4 + rg) * 64 + lane];
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const i32x4 pix = *reinterpret_cast<const i32x4*>(&rowpix[32 * mi + 8 * rg + 4 * lh]);
-        const f32x4 other = xch[((wave ^ 2) * 8 + mi * 4 + rg) * 64 + lane];
-#pragma unroll
-        for (int ri = 0; ri < 4; ++ri) {
-          const int r = 4 * rg + ri;
-          // even column (components 0,1 here, 2 received): m0 + m1 + m2;  odd column (2,3 here, 1 received): m1 - m2 - m3
-          const float m = cp == 0 ? (acc[0][mi][r] + acc[1][mi][r]) + other[ri] : (other[ri] - acc[0][mi][r]) - acc[1][mi][r];
-          const bool live = pix[ri] >= 0;
-          const unsigned e = (unsigned)(pix[ri] + ncol);
-          float v = P::SCALED ? fmaf(m * f2, f1, bv) : m + bv;
-          if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-          v = live ? v : 0.f;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
-          csum += v; csq += v * v;
-        }
+      for (int ri = 0; ri < 4; ++ri) {
+        const int r = 4 * rg + ri;
+        // even column (components 0,1 here, 2 received): m0 + m1 + m2;  odd column (2,3 here, 1 received): m1 - m2 - m3
+        const float m = cp == 0 ? (acc[0][b][r] + acc[1][b][r]) + other[ri] : (other[ri] - acc[0][b][r]) - acc[1][b][r];
+        const bool live = pix[ri] >= 0;
+        const unsigned e = (unsigned)(pix[ri] + ncol);
+        float v = P::SCALED ? fmaf(m * f2, f1, bv) : m + bv;
+        if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+        v = live ? v : 0.f;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
+        csum[j] += v; csq[j] += v * v;
       }
     }
   }
   if (a.stats != nullptr) {
-    float* red = reinterpret_cast<float*>(smem + 32768);    // [wave][32 cols][2], behind the exchange buffer
-    const float s1 = csum + __shfl_xor(csum, 32, 64), s2 = csq + __shfl_xor(csq, 32, 64);
-    if (lh == 0) { red[(wave * 32 + l31) * 2] = s1; red[(wave * 32 + l31) * 2 + 1] = s2; }
+    float* red = reinterpret_cast<float*>(smem + 32768);    // [wave][NJ][32 cols][2], behind the exchange buffer
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float s1 = csum[j] + __shfl_xor(csum[j], 32, 64), s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
+      if (lh == 0) { red[((wave * NJ + j) * 32 + l31) * 2] = s1; red[((wave * NJ + j) * 32 + l31) * 2 + 1] = s2; }
+    }
     __syncthreads();
-    if (tid < 128) {
+    if (tid < 128 * NJ) {
       const int col = tid >> 1, which = tid & 1;
-      const int w0 = col >> 5, c31 = col & 31;            // waves w0 (even columns) and w0 + 2 (odd columns)
-      const float v = red[(w0 * 32 + c31) * 2 + which] + red[((w0 + 2) * 32 + c31) * 2 + which];
+      const int j = col >> 6, w0 = (col >> 5) & 1, c31 = col & 31;            // waves w0 (even columns) and w0 + 2 (odd columns)
+      const float v = red[((w0 * NJ + j) * 32 + c31) * 2 + which] + red[(((w0 + 2) * NJ + j) * 32 + c31) * 2 + which];
       if (n0 + col < a.Cd) a.stats[((long)mt * a.Cd + n0 + col) * 2 + which] = v;
     }
   }
@@ -372,16 +382,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 
 const bool g_wino = [] { const char* e = getenv("FS_WINOGRAD"); return !(e && e[0] == '0'); }();
 
-// Ph rows x PP pairs <= 64 pairs per workgroup, halo (Ph+2)*PP <= WNS; fewest tiles over the stacked batch, then smallest halo.
-void wino_plan(int B, int H, int W, int& Ph, int& PP, int& tiles_x, int& nx) {
+// 32-column sub-tiles per wave: layers with >= 128 output channels split the halo image once per 128 columns
+// (FS_WINO_NJ=1|2 forces one variant, for A/B measurements)
+const int g_wino_nj = [] { const char* e = getenv("FS_WINO_NJ"); return e ? atoi(e) : 0; }();
+int wino_nj(int Cd) { return (g_wino_nj == 1 || g_wino_nj == 2) ? (Cd >= 128 ? g_wino_nj : 1) : (Cd >= 128 ? 2 : 1); }
+
+// Ph rows x PP pairs <= 64 / NJ pairs per workgroup, halo (Ph+2)*PP <= WNS / NJ; fewest tiles over the stacked batch, then smallest halo.
+void wino_plan(int nj, int B, int H, int W, int& Ph, int& PP, int& tiles_x, int& nx) {
   const long rows = (long)B * (H + 1);
-  const int wp = W / 2;
+  const int wp = W / 2, maxpairs = 64 / nj, maxslots = WNS / nj;
   long best = -1;
-  Ph = 8; PP = 8;
+  Ph = 8 / nj; PP = 8;
   for (int pp = 2; pp <= 32 && pp <= wp; ++pp) {      // div_small needs a divisor >= 2
-    int ph = 64 / pp;
-    while (ph > 1 && (ph + 2) * pp > WNS) --ph;
-    if ((ph + 2) * pp > WNS) continue;
+    int ph = maxpairs / pp;
+    while (ph > 1 && (ph + 2) * pp > maxslots) --ph;
+    if (ph < 1 || (ph + 2) * pp > maxslots) continue;
     const long tiles = (long)cdiv(rows, ph) * cdiv(wp, pp);
     const long cost = tiles * 1000 + (ph + 2) * pp;
     if (best < 0 || cost < best) { best = cost; Ph = ph; PP = pp; }
@@ -390,7 +405,7 @@ void wino_plan(int B, int H, int W, int& Ph, int& PP, int& tiles_x, int& nx) {
   nx = cdiv(rows, Ph) * tiles_x;
 }
 
-template <class P>
+template <class P, int NJ>
 int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int Cin, int Cout, int transposed, hipStream_t stream) {
   int e = FS_OK;
   a.ew = P::SCALED ? fs_f16_weight_amax(w, (long)9 * Cin * Cout, ws, w_amax, stream, &e) : nullptr;
@@ -400,7 +415,7 @@ int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int 
                      a.ew, Cin, Cout, transposed, a.Cs, a.Cd, a.Npad, total);
   FS_LAUNCH_CHECK();
   constexpr int lds = P::NPL * PLANE * 2 + 64 * 4 + 16;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<P, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (attr != hipSuccess) return (int)attr;
 #ifdef FS_WINO_TRACE
   static long long* dbg = nullptr;
@@ -410,7 +425,7 @@ int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int 
   a.dbg = dbg;
   hipMemsetAsync(dbg, 0, sizeof(long long) * 32 * nwg, stream);
 #endif
-  hipLaunchKernelGGL((conv3x3_wino_kernel<P>), dim3((unsigned)(a.nx * a.ny)), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((conv3x3_wino_kernel<P, NJ>), dim3((unsigned)(a.nx * a.ny)), dim3(256), lds, stream, a);
   FS_LAUNCH_CHECK();
 #ifdef FS_WINO_TRACE
   {
@@ -448,13 +463,13 @@ bool fs_wino_eligible(int mode, int B, int H, int W, int Cs, int Cd) {
 
 long fs_wino_pack_bytes(int mode, int Cs, int Cd) {
   const int npl = mode == 2 ? 2 : 3;
-  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 63) / 64) * 64;
+  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 127) / 128) * 128;       // room for either column tiling
   return HDR + nchunk * 24 * npl * Npad * 16 * 2;
 }
 
-int fs_wino_stats_slabs(int B, int H, int W) {
+int fs_wino_stats_slabs(int B, int H, int W, int Cd) {
   int Ph, PP, tx, nx;
-  wino_plan(B, H, W, Ph, PP, tx, nx);
+  wino_plan(wino_nj(Cd), B, H, W, Ph, PP, tx, nx);
   return nx;
 }
 
@@ -464,10 +479,11 @@ int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bia
   WinoArgs a;
   a.src = src; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = dst; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cs = Cs; a.Cd = Cd;
-  a.Npad = ((Cd + 63) / 64) * 64;
+  const int nj = wino_nj(Cd);
+  a.Npad = ((Cd + 64 * nj - 1) / (64 * nj)) * 64 * nj;
   a.nchunk = (Cs + 31) / 32;
-  wino_plan(B, H, W, a.Ph, a.PP, a.tiles_x, a.nx);
-  a.ny = a.Npad / 64;
+  wino_plan(nj, B, H, W, a.Ph, a.PP, a.tiles_x, a.nx);
+  a.ny = a.Npad / (64 * nj);
   a.Hv = H + 1;
   a.magic_hv = div_magic(a.Hv);
   a.magic_pp = div_magic(a.PP);
@@ -479,6 +495,9 @@ int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bia
   a.dst_bytes = (unsigned)((size_t)B * H * W * Cd * 4);
   a.ws_bytes = (unsigned)pack_bytes;
   a.drop_scale = drop_scale; a.drop_thresh = drop_thresh; a.drop_key = drop_key;
-  return mode == 2 ? run_wino<PrecF16>(a, w, ws, w_amax, Cin, Cout, transposed, stream)
-                   : run_wino<PrecX3>(a, w, ws, w_amax, Cin, Cout, transposed, stream);
+  if (nj == 2)
+    return mode == 2 ? run_wino<PrecF16, 2>(a, w, ws, w_amax, Cin, Cout, transposed, stream)
+                     : run_wino<PrecX3, 2>(a, w, ws, w_amax, Cin, Cout, transposed, stream);
+  return mode == 2 ? run_wino<PrecF16, 1>(a, w, ws, w_amax, Cin, Cout, transposed, stream)
+                   : run_wino<PrecX3, 1>(a, w, ws, w_amax, Cin, Cout, transposed, stream);
 }

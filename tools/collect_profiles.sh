@@ -19,10 +19,14 @@ python3 $R/tools/traffic_summary.py $O/fetch $O/write $O/hbm_traffic_serial.json
 rm -rf $O/fetch $O/write
 cd $R
 export FS_CONV_PRECISION=bf16x3
-for spec in "fwd 0 conv3x3_halo_kernel" "fwd 3 conv3x3_halo_kernel" "wgrad 0 conv_wgrad_class_kernel" "fwd 5 conv_igemm_split_kernel"; do
+for spec in "fwd 0 conv3x3_wino_kernel" "fwd 3 conv3x3_wino_kernel" "wgrad 0 conv_wgrad_class_kernel" "fwd 5 conv1x1_gemm_kernel"; do
   set -- $spec
   bash tools/pmc_conv.sh $1 $2 $3 > $O/sq_bf16x3_$3_$1_shape$2.txt 2>&1
 done
+FS_WINOGRAD=0 bash tools/pmc_conv.sh fwd 0 conv3x3_halo_kernel > $O/sq_bf16x3_conv3x3_halo_kernel_fwd_shape0.txt 2>&1
+export FS_CONV_PRECISION=f16x2
+bash tools/pmc_conv.sh fwd 0 conv3x3_halo_kernel > $O/sq_f16x2_conv3x3_halo_kernel_fwd_shape0.txt 2>&1
+bash tools/pmc_conv.sh fwd 1 conv3x3_wino_kernel > $O/sq_f16x2_conv3x3_wino_kernel_fwd_shape1.txt 2>&1
 unset FS_CONV_PRECISION
 rm -rf $R/gpurun_out/pmc_1 $R/gpurun_out/pmc_2 $R/gpurun_out/pmc_3
 ls -la $O

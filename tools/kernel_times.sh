@@ -11,5 +11,5 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Name"]
         if "conv" in n or "pack" in n or "wino" in n:
-            print(sys.argv[2], n.split("(")[0][-70:], r["Calls"], round(float(r["AverageNs"]) / 1000, 1), "us")
+            print(sys.argv[2], n.replace("(anonymous namespace)::", "").replace("void ", "")[:60], r["Calls"], round(float(r["AverageNs"]) / 1000, 1), "us")
 PY
