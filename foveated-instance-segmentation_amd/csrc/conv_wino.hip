@@ -382,10 +382,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 
 const bool g_wino = [] { const char* e = getenv("FS_WINOGRAD"); return !(e && e[0] == '0'); }();
 
-// 32-column sub-tiles per wave: layers with >= 128 output channels split the halo image once per 128 columns
-// (FS_WINO_NJ=1|2 forces one variant, for A/B measurements)
-const int g_wino_nj = [] { const char* e = getenv("FS_WINO_NJ"); return e ? atoi(e) : 0; }();
-int wino_nj(int Cd) { return (g_wino_nj == 1 || g_wino_nj == 2) ? (Cd >= 128 ? g_wino_nj : 1) : (Cd >= 128 ? 2 : 1); }
+// 32-column sub-tiles per wave.  FS_WINO_NJ=2 makes layers with >= 128 output channels split their halo image once per 128
+// columns; measured and left off: the store phase shrinks by a third but the doubled B-fragment traffic lengthens the MFMA phase
+// (kernel time +-1 % in isolation, the training step 5 % slower: profiles/r02/winograd_column_tiling_ab.txt)
+const int g_wino_nj = [] { const char* e = getenv("FS_WINO_NJ"); return e ? atoi(e) : 1; }();
+int wino_nj(int Cd) { return (g_wino_nj == 2 && Cd >= 128) ? 2 : 1; }
 
 // Ph rows x PP pairs <= 64 / NJ pairs per workgroup, halo (Ph+2)*PP <= WNS / NJ; fewest tiles over the stacked batch, then smallest halo.
 void wino_plan(int nj, int B, int H, int W, int& Ph, int& PP, int& tiles_x, int& nx) {
