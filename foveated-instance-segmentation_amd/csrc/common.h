@@ -36,7 +36,7 @@ __device__ __forceinline__ bool fs_dropout_keep(uint32_t e, uint32_t key, uint32
 }
 
 __device__ __forceinline__ float fs_act(float v, int act) {
-  if (act == FS_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == FS_ACT_RELU) return v < 0.f ? 0.f : v;      // NaN propagates, as through torch.relu
   if (act == FS_ACT_RELU6) return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
   return v;
 }

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void hr_fuse_fwd_kernel(FuseArgs a) {
     }
     if (a.relu) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = acc[j] > 0.f ? acc[j] : 0.f;
+      for (int j = 0; j < 4; ++j) acc[j] = acc[j] < 0.f ? 0.f : acc[j];
     }
     *reinterpret_cast<f32x4*>(a.out + pix * a.C + c) = acc;
   }

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(1024) void compress_softmax_fwd_kernel(const float*
     float acc = 0.f;
     for (int c = 0; c < C; ++c) {
       const float v = sb[(long)p * C + c];
-      acc += (v > 0.f ? v : 0.f) * w[c];
+      acc += (v < 0.f ? 0.f : v) * w[c];
     }
     acc += bias[0];
     logit[p] = acc;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(1024) void compress_softmax_bwd_kernel(const float*
       if (c < C) {
         const float v = sb[(long)p * C + c];
         dsb[(long)p * C + c] = v > 0.f ? dl * w[c] : 0.f;
-        dwl[c] += dl * (v > 0.f ? v : 0.f);
+        dwl[c] += dl * (v < 0.f ? 0.f : v);
       }
     }
   }

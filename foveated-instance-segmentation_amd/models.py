@@ -6,6 +6,8 @@ with the same constructor/forward signatures, attribute names, return tuples, st
 (SURVEY.md Appendix A).  Branches the default run never takes raise NotImplementedError.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -158,8 +160,36 @@ class DeformSegmentationModule(nn.Module):
         create_grid; returns (pred_full (B,C,H,W), hole mask (B,H,W))."""
         return ops.unwarp_nearest(pred.contiguous(), grid, int(seg_size[0]), int(seg_size[1]))
 
+    # models/models.py:721 asserts `not torch.isnan(xs).any()` in the middle of the forward: a device->host read that drains the
+    # stream once per step (2-3 % of the training step on MI355X, profiles/r02/nan_check_ab.txt).  The same flag is taken on the
+    # device, copied to pinned host memory without blocking, and the AssertionError (same message) is raised when the flag is
+    # next looked at: at the end of train.train_step / train.eval_step, at the next forward, or by check_nan().
+    # FS_NAN_CHECK=sync restores the reference's in-place assert, FS_NAN_CHECK=0 drops the check.
+    _nan_mode = os.environ.get("FS_NAN_CHECK", "defer")
+
+    def _note_nan(self, xs):
+        if self._nan_mode == "0":
+            return
+        if self._nan_mode == "sync" or not xs.is_cuda:
+            assert not torch.isnan(xs).any(), "xs contains NaN values!"
+            return
+        st = self.__dict__.setdefault("_nan_state", {"host": torch.zeros(1, dtype=torch.bool).pin_memory(), "event": None})
+        st["host"].copy_(torch.isnan(xs).any().reshape(1), non_blocking=True)
+        st["event"] = torch.cuda.Event()
+        st["event"].record()
+
+    def check_nan(self):
+        """Raise the pending `xs contains NaN values!` assertion of the last forward, if any (see _note_nan)."""
+        st = self.__dict__.get("_nan_state")
+        if st is None or st["event"] is None:
+            return
+        st["event"].synchronize()
+        st["event"] = None
+        assert not bool(st["host"][0]), "xs contains NaN values!"
+
     def forward(self, feed_dict, *, writer=None, segSize=None, F_Xlr_acc_map=False, count=None, epoch=None,
                 feed_dict_info=None, feed_batch_count=None, cur_iter=None, is_inference=False, rank=None):
+        self.check_nan()
         if segSize is not None:
             raise NotImplementedError("segSize inference branch (models/models.py:621-631) is not on the default path")
         cfg = self.cfg
@@ -172,7 +202,7 @@ class DeformSegmentationModule(nn.Module):
         hs, ws = self.grid_size_x, self.grid_size_y
 
         xs, _ = self.saliency(x, focus)
-        assert not torch.isnan(xs).any(), "xs contains NaN values!"
+        self._note_nan(xs)
         grid = self.create_grid(xs)
 
         joint = cfg.TRAIN.deform_joint_loss

@@ -296,6 +296,8 @@ def train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=0):
             if not zoom:            # segmentation module frozen
                 continue
         opt.step()
+    if hasattr(module, "check_nan"):
+        module.check_nan()          # the forward's deferred NaN assertion (models.DeformSegmentationModule._note_nan)
     return out
 
 
@@ -304,7 +306,10 @@ def eval_step(module, batch):
     """eval.py:389-405 -- same forward with is_inference=True under no_grad (module.eval() by caller)."""
     X, Fp, Y, cls = batch
     feed = {"img_data": X[:, :3], "seg_label": Y, "focus_point": Fp, "cls_label": cls}
-    return module(feed, is_inference=True)
+    out = module(feed, is_inference=True)
+    if hasattr(module, "check_nan"):
+        module.check_nan()
+    return out
 
 
 def synthetic_batch(B, H, W, seed=1, device="cuda"):

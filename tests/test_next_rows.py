@@ -435,3 +435,31 @@ def test_checkpoint_of_the_real_module_on_gpu(tmp_path):
         assert abs(loss_resumed - loss_next) <= 1e-6 * max(1.0, abs(loss_next)), (loss_resumed, loss_next)
     finally:
         pass          # (round 1 reset a process-global here; the direct-gradient decision is per parameter now)
+
+
+@pytest.mark.gpu
+def test_nan_assertion_is_deferred_not_dropped():
+    """models/models.py:721 asserts `not torch.isnan(xs).any()` mid-forward (a host sync per step).  Here the flag travels to pinned
+    host memory without blocking and the same AssertionError surfaces at the end of train_step / eval_step, at the next forward, or
+    on check_nan() -- never silently."""
+    cfg = fovealseg.lvis50_cfg()
+    module, nets = train.build_module(cfg, device="cuda")
+    module.eval()
+    good = train.synthetic_batch(2, 256, 256, seed=3, device="cuda")
+    bad = tuple(t.clone() for t in good)
+    bad[0][0, 0, 5, 7] = float("nan")                    # one NaN pixel in the image -> NaN saliency logits -> NaN softmax
+    train.eval_step(module, good)                        # clean input: no assertion
+    with pytest.raises(AssertionError, match="xs contains NaN values!"):
+        train.eval_step(module, bad)
+    train.eval_step(module, good)                        # the flag does not stick
+    # direct forward calls: the assertion of call k is raised by check_nan() or at the start of call k + 1
+    X, Fp, Y, cls = bad
+    feed = {"img_data": X[:, :3], "seg_label": Y, "focus_point": Fp, "cls_label": cls}
+    with torch.no_grad():
+        module(dict(feed), is_inference=True)
+        with pytest.raises(AssertionError, match="xs contains NaN values!"):
+            module.check_nan()
+        module(dict(feed), is_inference=True)
+        Xg, Fg, Yg, cg = good
+        with pytest.raises(AssertionError, match="xs contains NaN values!"):
+            module({"img_data": Xg[:, :3], "seg_label": Yg, "focus_point": Fg, "cls_label": cg}, is_inference=True)

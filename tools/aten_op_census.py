@@ -34,6 +34,22 @@ def main():
     for e in rows[:40]:
         stack = " <- ".join(s.split("/")[-1] for s in e.stack[:4]) if e.stack else ""
         print(f"{e.count:6d} x {e.key:28s} cuda {e.device_time_total / 1e3:8.2f} ms   {stack[:150]}")
+    print("---- memory copies: the CPU op (and python frames) that issued each one")
+    cop = {}
+    for e in prof.events():
+        if "emcpy" in e.name or "copyBuffer" in e.name:
+            par, chain = e.cpu_parent, []
+            while par is not None and len(chain) < 4:
+                chain.append(par.name)
+                par = par.cpu_parent
+            key = (e.name[:40], " <- ".join(chain))
+            cop[key] = cop.get(key, 0) + 1
+    for k, v in sorted(cop.items(), key=lambda kv: -kv[1])[:12]:
+        print(f"{v:6d} x {k[0]:40s} {k[1][:160]}")
+    for e in ev:
+        if "copy" in e.key.lower() and e.count >= 50:
+            stack = " <- ".join(s.split("/")[-1] for s in e.stack[:5]) if e.stack else ""
+            print(f"{e.count:6d} x {e.key:28s} {stack[:200]}")
     print("---- device kernels / memcpy by name")
     agg = {}
     for e in prof.events():

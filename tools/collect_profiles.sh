@@ -28,5 +28,10 @@ export FS_CONV_PRECISION=f16x2
 bash tools/pmc_conv.sh fwd 0 conv3x3_halo_kernel > $O/sq_f16x2_conv3x3_halo_kernel_fwd_shape0.txt 2>&1
 bash tools/pmc_conv.sh fwd 1 conv3x3_wino_kernel > $O/sq_f16x2_conv3x3_wino_kernel_fwd_shape1.txt 2>&1
 unset FS_CONV_PRECISION
+# kernel-only durations of the 3x3 stride-1 forward on the four dominant shapes, direct (halo) form against the F(2,3) row kernel
+for m in bf16x3 f16x2; do for w in 0 1; do for s in 0 1 2 3; do
+  FS_CONV_PRECISION=$m FS_WINOGRAD=$w bash tools/kernel_times.sh fwd $s ${m}_winograd${w}_shape$s
+done; done; done > $O/winograd_kernel_times.txt 2>&1
+rm -rf $R/gpurun_out/kt_*
 rm -rf $R/gpurun_out/pmc_1 $R/gpurun_out/pmc_2 $R/gpurun_out/pmc_3
 ls -la $O
