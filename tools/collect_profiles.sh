@@ -33,5 +33,8 @@ for m in bf16x3 f16x2; do for w in 0 1; do for s in 0 1 2 3; do
   FS_CONV_PRECISION=$m FS_WINOGRAD=$w bash tools/kernel_times.sh fwd $s ${m}_winograd${w}_shape$s
 done; done; done > $O/winograd_kernel_times.txt 2>&1
 rm -rf $R/gpurun_out/kt_*
+# per-layer error against fp64 of the three modes, with the F(2,3) row kernel (default) and with the direct form only
+{ echo "# python tools/conv_accuracy.py  (FS_WINOGRAD=1, the default: 3x3 stride-1 layers on conv3x3_wino_kernel)"; python3 tools/conv_accuracy.py 2>&1 | grep -v amdgpu.ids;
+  echo "# FS_WINOGRAD=0 python tools/conv_accuracy.py  (direct form: conv3x3_halo_kernel)"; FS_WINOGRAD=0 python3 tools/conv_accuracy.py 2>&1 | grep -v amdgpu.ids; } > $O/conv_accuracy_winograd.txt
 rm -rf $R/gpurun_out/pmc_1 $R/gpurun_out/pmc_2 $R/gpurun_out/pmc_3
 ls -la $O
