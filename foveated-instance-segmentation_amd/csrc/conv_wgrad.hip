@@ -45,6 +45,7 @@ struct WgArgs {
   int Ph, Pw, tiles_y, tiles_x, npatch, patches_per_split;
   int tiles_ci, tiles_co;
   unsigned x_bytes, dy_bytes;
+  unsigned magic_wh, magic_pw;      // 2^32 / (Pw + NS - 1) + 1, 2^32 / Pw + 1: slot / pixel index -> (row, column) without integer division
 };
 
 // NG = patch streams ("groups" of 4 waves) per workgroup.  NG = 1: 256 threads, two workgroups per CU.  NG = 2: 512 threads, one
@@ -91,15 +92,22 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void conv_wgrad_class_ke
 #pragma unroll
   for (int i = 0; i < NXI; ++i) {
     const int slot = (tid >> 4) + 16 * i;
-    const int hy = slot / Wh, hx = slot - hy * Wh;
+    const int hy = div_small(slot, a.magic_wh), hx = slot - hy * Wh;
     xcode[i] = (slot < nslots && ci0 + 4 * cq < a.Cin) ? ((hy << 16) | hx) : -1;
   }
 #pragma unroll
   for (int i = 0; i < NYI; ++i) {
     const int p = (tid >> 4) + 16 * i;
-    const int py = p / a.Pw, px = p - py * a.Pw;
+    const int py = div_small(p, a.magic_pw), px = p - py * a.Pw;
     ycode[i] = (p < npix && co0 + 4 * cq < a.Cout) ? ((py << 16) | px) : -1;
   }
+  // byte offset of item i relative to the patch origin (the patch origin itself is wave-uniform: scalar arithmetic per patch, no
+  // per-item integer multiplies -- v_mul_lo_u32 is a quarter-rate instruction and there were 25 of them per patch)
+  int xdelta[NXI], ydelta[NYI];
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) xdelta[i] = ((a.sm * (xcode[i] >> 16) * a.Wx + a.sm * (xcode[i] & 0xffff)) * a.Cin + ci0 + 4 * cq) * 4;
+#pragma unroll
+  for (int i = 0; i < NYI; ++i) ydelta[i] = (((ycode[i] >> 16) * a.W + (ycode[i] & 0xffff)) * a.Cout + co0 + 4 * cq) * 4;
   const int xw = gx + (cq >> 3) * X_HALF + (tid >> 4) * 64 + (cq & 7) * 8;     // + i*1024 + plane*X_PLANE
   const int yw = gy + (cq >> 3) * Y_HALF + (tid >> 4) * 64 + (cq & 7) * 8;     // + i*1024 + plane*Y_PLANE
   const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.x, a.x_bytes);
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void conv_wgrad_class_ke
     for (int t = 0; t < 2; ++t) {
       int pidx = 16 * ks + 8 * lh + 4 * t + q;
       if (pidx >= npix) pidx = 0;             // padded k: dY is zero there, any valid X address will do
-      const int py = pidx / a.Pw, px = pidx - py * a.Pw;
+      const int py = div_small(pidx, a.magic_pw), px = pidx - py * a.Pw;
       xb[ks][t] = gx + wm * X_HALF + (py * Wh + px) * 64 + (cb + 4 * pp) * 2;
     }
   const int yb = gy + wn * Y_HALF + (8 * lh + q) * 64 + (cb + 4 * pp) * 2;      // + ks*1024 + t*256 + plane*Y_PLANE
@@ -133,32 +141,40 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void conv_wgrad_class_ke
   int E = 2 * EMIN - 1, par = 0;
 
   const int niter = (p_end - p_begin + NG - 1) / NG;
+  // (image, tile row, tile column) of the group's current patch, advanced by NG per round (wave-uniform: scalar adds and compares
+  // instead of two integer divisions per patch)
+  int pb_, pty, ptx;
+  {
+    const int first = (p_begin + grp < p_end) ? p_begin + grp : p_begin;
+    pb_ = first / tpi;
+    const int trem = first - pb_ * tpi;
+    pty = trem / a.tiles_x; ptx = trem - pty * a.tiles_x;
+  }
   for (int it = 0; it < niter; ++it) {
     // group g takes patches p_begin + g, + NG, ...; a group without a patch in the last round runs it on zeros (same barriers)
     const int patch_raw = p_begin + it * NG + grp;
     const bool pvalid = patch_raw < p_end;
-    const int patch = pvalid ? patch_raw : p_begin;
-    const int b = patch / tpi;
-    const int trem = patch - b * tpi;
-    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int b = pb_, ty = pty, tx = ptx;
     const int y0 = ty * a.Ph, x0 = tx * a.Pw;
+    ptx += NG;
+    while (ptx >= a.tiles_x) { ptx -= a.tiles_x; ++pty; }
+    while (pty >= a.tiles_y) { pty -= a.tiles_y; ++pb_; }
 
     f32x4 rx[NXI], ry[NYI];
+    const int iy0 = a.sm * y0 + a.cy, ix0 = a.sm * x0 + a.cx;                       // source pixel of halo slot (0, 0)
+    const int xbase = ((b * a.Hx + iy0) * a.Wx + ix0) * a.Cin * 4;                  // may be negative (padding); base + delta is not, where valid
+    const int ybase = ((b * a.H + y0) * a.W + x0) * a.Cout * 4;
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
-      const int hy = xcode[i] >> 16, hx = xcode[i] & 0xffff;
-      const int iy = a.sm * (y0 + hy) + a.cy, ix = a.sm * (x0 + hx) + a.cx;
+      const int iy = iy0 + a.sm * (xcode[i] >> 16), ix = ix0 + a.sm * (xcode[i] & 0xffff);
       const bool ok = pvalid && xcode[i] >= 0 && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx;
-      const unsigned off = (unsigned)(((b * a.Hx + iy) * a.Wx + ix) * a.Cin + ci0 + 4 * cq) * 4u;
-      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? (int)off : (int)OOB, 0, 0));
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? xbase + xdelta[i] : (int)OOB, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < NYI; ++i) {
-      const int py = ycode[i] >> 16, px = ycode[i] & 0xffff;
-      const int y = y0 + py, x = x0 + px;
+      const int y = y0 + (ycode[i] >> 16), x = x0 + (ycode[i] & 0xffff);
       const bool ok = pvalid && ycode[i] >= 0 && y < a.H && x < a.W;
-      const unsigned off = (unsigned)(((b * a.H + y) * a.W + x) * a.Cout + co0 + 4 * cq) * 4u;
-      ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, ok ? (int)off : (int)OOB, 0, 0));
+      ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, ok ? ybase + ydelta[i] : (int)OOB, 0, 0));
     }
     float sx = 1.f, sy = 1.f;
     if (P::SCALED) {   // tile maxima -> LDS cells of this patch's parity
@@ -298,6 +314,7 @@ template <class P, int NR, int NS>
 int launch_class(WgArgs a, int ntile, hipStream_t stream) {
   choose_wgrad_patch(a.H, a.W, NR, NS, a.Ph, a.Pw);
   a.tiles_y = cdiv(a.H, a.Ph); a.tiles_x = cdiv(a.W, a.Pw);
+  a.magic_wh = div_magic(a.Pw + NS - 1); a.magic_pw = div_magic(a.Pw);
   a.npatch = a.B * a.tiles_y * a.tiles_x;
   // 512 patch streams = 8 waves on every CU, never a short second round: 512 workgroups of one group (two per CU), or -- 9-tap
   // class with FS_WGRAD_GROUPS=2 -- 256 workgroups of two groups (half the split-K atomics).
