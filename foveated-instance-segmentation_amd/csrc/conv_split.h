@@ -28,6 +28,9 @@ __device__ __forceinline__ int exponent_of_bits(unsigned bits) {
 // n / d for 0 <= n < 65536 with m = 2^32 / d + 1 precomputed on the host (exact for d <= 65535): two VALU instead of ~25
 __device__ __forceinline__ int div_small(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }
 static inline unsigned div_magic(int d) { return (unsigned)(4294967296ULL / (unsigned)d + 1ULL); }
+// the same for divisors that may be 1 (magic 0 = identity)
+__device__ __forceinline__ int div_small1(int n, unsigned m) { return m == 0u ? n : (int)__umulhi((unsigned)n, m); }
+static inline unsigned div_magic1(int d) { return d == 1 ? 0u : div_magic(d); }
 // ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (per 32-lane half).  Map the 32 rows of
 // an MFMA tile to patch pixels so that each group reads 16 CONSECUTIVE pixels (conflict-free 80-byte rows).
 __device__ __forceinline__ int row_perm(int l) {

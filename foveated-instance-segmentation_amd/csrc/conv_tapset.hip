@@ -30,6 +30,7 @@ struct TsArgs {
   int Npad, nchunk, ttot;
   int Ph, Pw, tiles_y, tiles_x, nx, ny;
   unsigned src_bytes, wp_bytes, dst_bytes;
+  unsigned magic_pw, magic_wh[8];      // div_small1 magics of Pw and of the halo width Pw + nS - 1, nS = 1..8
   float drop_scale; uint32_t drop_thresh, drop_key;
 };
 
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_tapset_kernel(TsArgs a) {
   // output pixel of every tile row (MFMA row order), -1 = dead row
   if (tid < 128) {
     const int p = (tid & ~31) + row_perm(tid & 31);
-    const int py = p / a.Pw, px = p - py * a.Pw;
+    const int py = div_small1(p, a.magic_pw), px = p - py * a.Pw;
     const bool live = p < npix && y0 + py < a.Hq && x0 + px < a.Wq;
     rowpix[tid] = live ? ((b * a.Hd + (y0 + py) * a.os + a.oy0) * a.Wd + (x0 + px) * a.os + a.ox0) : -1;
   }
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_tapset_kernel(TsArgs a) {
   for (int mi = 0; mi < 2; ++mi) {
     const int p = 64 * wm + 32 * mi + row_perm(l31);
     const bool live = p < npix;
-    fpy[mi] = live ? p / a.Pw : 0;
+    fpy[mi] = live ? div_small1(p, a.magic_pw) : 0;
     fpx[mi] = live ? p - fpy[mi] * a.Pw : 0;
   }
 
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_tapset_kernel(TsArgs a) {
       const int slot = (tid >> 3) + 32 * i;
       goff[i] = -1;
       if (slot < nslots) {
-        const int hy = slot / Wh, hx = slot - hy * Wh;
+        const int hy = div_small1(slot, a.magic_wh[a.cls[c].nS - 1]), hx = slot - hy * Wh;
         const int sy = a.sm * (y0 + hy) + cy, sx = a.sm * (x0 + hx) + cx;
         if (sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws) goff[i] = ((b * a.Hs + sy) * a.Ws + sx) * a.Cs + 4 * q;
       }
@@ -389,6 +390,9 @@ int fs_tapset_conv(int mode, const FsTapsetProblem& p, hipStream_t stream) {
   fs_tapset_patch(p.Hq, p.Wq, maxR, maxS, &a.Ph, &a.Pw);
   if ((a.Ph + maxR - 1) * (a.Pw + maxS - 1) > NSMAX) return FS_ERR_ARG;
   a.tiles_y = cdiv(p.Hq, a.Ph); a.tiles_x = cdiv(p.Wq, a.Pw);
+  a.magic_pw = div_magic1(a.Pw);
+  if (maxS > 8) return FS_ERR_ARG;
+  for (int ns = 1; ns <= 8; ++ns) a.magic_wh[ns - 1] = div_magic1(a.Pw + ns - 1);
   a.nx = p.B * a.tiles_y * a.tiles_x;
   a.ny = a.Npad / 64;
   const long pack_bytes = fs_tapset_pack_bytes(mode, p.Cs, p.Cd, total_taps);
