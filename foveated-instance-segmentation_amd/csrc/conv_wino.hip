@@ -228,7 +228,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int G = a.nchunk * 12;           // B fragments this wave consumes
 
   X8 fa[2][MI][NPL];      // [buffer][mi][plane]
-  X8 fb[3][NJ][NPL];      // [ring slot][sub-tile][plane]: fragments run 2 steps ahead of the MFMAs
+#ifndef FS_WINO_RING
+#define FS_WINO_RING 3
+#endif
+  constexpr int RD = FS_WINO_RING;   // B-fragment ring: fragments run RD - 1 steps ahead of the MFMAs (12 % RD == 0: slots are compile-time)
+  static_assert(12 % RD == 0, "ring depth must divide the 12 steps of a chunk");
+  X8 fb[RD][NJ][NPL];     // [ring slot][sub-tile][plane]
   auto load_b = [&](int g, X8 (&dst)[NJ][NPL]) {
     const int gg = g < G ? g : G - 1;
     const int g4 = (gg >> 2) * 8 + 4 * cp + (gg & 3);      // wave-uniform: goes in the scalar offset operand
@@ -257,8 +262,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ci][b][r] = 0.f;
   int E = EMIN;
-  load_b(0, fb[0]);
-  load_b(1, fb[1]);
+#pragma unroll
+  for (int r = 0; r < RD - 1; ++r) load_b(r, fb[r]);
   load_halo(0);
   __syncthreads();                        // amax cells zeroed before the first atomic
   WINO_STAMP(1);
@@ -294,10 +299,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
     for (int step = 0; step < 12; ++step) {
       if (step + 1 < 12) read_a(step + 1, fa[(step + 1) & 1]);
-      load_b(g + 2, fb[(step + 2) % 3]);
+      load_b(g + RD - 1, fb[(step + RD - 1) % RD]);
       __builtin_amdgcn_sched_barrier(0);
       const X8(&A)[MI][NPL] = fa[step & 1];
-      const X8(&Bf)[NJ][NPL] = fb[step % 3];
+      const X8(&Bf)[NJ][NPL] = fb[step % RD];
       const int ci = (step >> 1) & 1;
 #pragma unroll
       for (int t = 0; t < P::NTERM; ++t) {         // smallest terms first, the two blocks interleaved
