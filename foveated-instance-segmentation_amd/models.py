@@ -5,9 +5,9 @@ with the same constructor/forward signatures, attribute names, return tuples, st
 `feed_dict['seg_label']` side effect (:951), under the effective LVIS-50 configuration
 (SURVEY.md Appendix A).  Branches the default run never takes raise NotImplementedError.
 """
-import numpy as np
 import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 
