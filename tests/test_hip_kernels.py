@@ -123,6 +123,7 @@ CONV_CASES = [
     (1, 13, 9, 16, 32, 1, 3, False),
     (5, 1, 1, 512, 51, 1, 1, True),        # FC as 1x1 conv, scalar path
     (1, 10, 10, 512, 512, 3, 1, False),
+    (2, 9, 11, 64, 96, 3, 1, True),        # odd width: the direct halo kernel (the F(2,3) row kernel needs pixel pairs), + bias
     (2, 10, 10, 64, 64, 3, 1, False, 2),    # dilation 2 (DeepLab layer3)
     (1, 10, 10, 128, 64, 3, 1, False, 12),  # ASPP rate 12: only the centre tap is in range
     (2, 23, 17, 3, 64, 7, 2, False),        # ResNet stem 7x7 stride 2 (generic kernel)
