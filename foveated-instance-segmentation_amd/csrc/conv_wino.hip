@@ -399,6 +399,13 @@ void wino_plan(int nj, int B, int H, int W, int& Ph, int& PP, int& tiles_x, int&
   const int wp = W / 2, maxpairs = 64 / nj, maxslots = WNS / nj;
   long best = -1;
   Ph = 8 / nj; PP = 8;
+  if (const char* e = getenv("FS_WINO_TILE")) {        // kernel experiments: "PhxPP"
+    int ph = 0, pp = 0;
+    if (sscanf(e, "%dx%d", &ph, &pp) == 2 && ph >= 1 && pp >= 2 && pp <= wp && ph * pp <= maxpairs && (ph + 2) * pp <= maxslots) {
+      Ph = ph; PP = pp; tiles_x = cdiv(wp, PP); nx = cdiv(rows, Ph) * tiles_x;
+      return;
+    }
+  }
   for (int pp = 2; pp <= 32 && pp <= wp; ++pp) {      // div_small needs a divisor >= 2
     int ph = maxpairs / pp;
     while (ph > 1 && (ph + 2) * pp > maxslots) --ph;
