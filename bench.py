@@ -288,33 +288,68 @@ def main():
                 module.train()
         fwd_only["what"] = "DeformSegmentationModule forward, is_inference=True, eval mode, no_grad; 152.29 GFLOP per image"
 
-    head = results[args.headline]
-    line = {
-        "metric": "images/sec fwd+bwd, 1024->80 foveated HRNetV2, batch 64",
-        "value": head["value"], "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": f"f32 ({args.headline}: {MODES[args.headline][3]})", "data": "synthetic", "conv_precision": args.headline,
-        "config": {"workload": f"BASELINE configs[1]: HRNetV2-nodownsp + C1, {args.size}x{args.size}->80x80, gaussian_radius 45, "
-                               f"batch {args.batch}/GPU, train mode (BN batch stats, Dropout 0.3), fwd+bwd+Adam x4",
-                   "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": head["loss"]},
-    }
     if rank == 0:
-        for k in ("roofline", "roofline_wgrad", "roofline_other_convs", "roofline_bn_fwd", "roofline_bn_bwd", "roofline_error", "frontend", "whole_step"):
-            if k in head:
-                line[k] = head[k]
-        line["modes"] = results
-        if fwd_only is not None:
-            line["forward_only"] = fwd_only
+        cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline()
+                cpu = cpu_baseline()
             except Exception as exc:
-                line["cpu_baseline"] = None
-                line["cpu_baseline_error"] = repr(exc)
-        print(json.dumps(line), flush=True)
+                cpu = {"error": repr(exc)}
+        line, detail = build_lines(args.headline, world, args.steps, args.warmup, args.batch, args.size, results, fwd_only, cpu)
+        write_detail(detail)
+        print(json.dumps(line), flush=True)          # the LAST thing on stdout, < 2 KB: the driver parses this line
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+MAX_LINE_BYTES = 2048
+
+
+def _short_roofline(r):
+    """The one roofline object of the JSON line: fixed keys, kernel name <= 80 characters."""
+    if not r:
+        return None
+    keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_us")
+    out = {"kernel": str(r.get("kernel", "")).split(" (")[0][:80]}
+    out.update({k: r.get(k) for k in keys})
+    return out
+
+
+def build_lines(headline, world, steps, warmup, batch, size, results, fwd_only, cpu):
+    """(line, detail): `line` is the ONE JSON object printed last on stdout (bench contract; kept under MAX_LINE_BYTES so
+    the driver's stdout tail always holds all of it), `detail` everything else (per-mode rooflines of every kernel class,
+    front-end table, forward-only rates, long descriptions) for bench_detail.json."""
+    head = results[headline]
+    line = {
+        "metric": "images/sec fwd+bwd, 1024->80 foveated HRNetV2, batch 64",
+        "value": head["value"], "unit": "img/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "conv_precision": headline,
+        "config": {"workload": f"configs[1]: HRNetV2-nodownsp+C1 {size}x{size}->80x80 r45 B={batch}/GPU train fwd+bwd+Adam",
+                   "global_batch": batch * world, "parallelism": f"dp{world}"},
+        "roofline": _short_roofline(head.get("roofline")),
+    }
+    if cpu is not None:
+        line["cpu_baseline"] = {k: (str(v)[:120] if k == "sample" else v) for k, v in cpu.items()
+                                if k in ("value", "unit", "cores", "kind", "sample", "error")}
+    line["modes"] = {m: {"value": r["value"], "ms_per_step": r["ms_per_step"],
+                         "frac": (r.get("roofline") or {}).get("frac")} for m, r in results.items()}
+    line["detail"] = "bench_detail.json"
+    detail = {"line": line, "modes": results, "forward_only": fwd_only, "cpu_baseline": cpu}
+    assert len(json.dumps(line)) < MAX_LINE_BYTES, "bench line grew past what the driver keeps"
+    return line, detail
+
+
+def write_detail(detail):
+    """Side file with everything the line leaves out (next to bench.py, and under gpurun_out/ so it travels back from the GPU box)."""
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    json.dump(detail, f, indent=1)
+        except OSError:
+            pass
 
 
 # Front-end / loss / optimiser kernels (HBM or gather-latency bound): timer kind -> description

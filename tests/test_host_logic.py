@@ -254,6 +254,54 @@ def test_bench_self_launch_command(monkeypatch):
     assert bench.mode_peak("bf16x3") == 2500.0 / 6 and bench.mode_peak("f16x2") == 2500.0 / 3 and bench.mode_peak("f32") == 157.3
 
 
+def test_bench_line_is_short_and_parseable(tmp_path, monkeypatch):
+    """VERDICT r2 #1 / ADVICE r2 (high): the final stdout line must stay under 2 KB whatever the per-kernel tables hold, parse as JSON,
+    and carry the headline mode's value, ONE roofline object and cpu_baseline; everything else goes to bench_detail.json."""
+    import importlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    # a fake KernelTimer summary with every kind roofline_entries knows, so the per-mode detail is as large as it gets
+    kinds = ["conv3x3", "wgrad3x3", "conv_affine", "conv_wgrad", "bn_fwd", "bn_bwd"] + list(bench.FRONTEND_KINDS)
+    summ = {k: {"flops": 3.9705e10 * 438 * 20, "total_ms": 71.0 * 20, "launches": 438 * 20} for k in kinds}
+    results = {}
+    for i, mode in enumerate(("bf16x3", "f16x2", "f32")):
+        res = {"value": 331.7 - 10 * i, "unit": "img/s", "ms_per_step": 192.9 + i, "operand_significand_bits": bench.MODES[mode][2],
+               "arithmetic": bench.MODES[mode][3], "loss": 1.234}
+        res.update(bench.roofline_entries(mode, summ, 20, 4.1))
+        results[mode] = res
+    fwd_only = {m: {"img_per_s": 1160.5, "ms_per_batch": 55.15, "algorithmic_tflops": 176.7} for m in results}
+    cpu = {"value": 1.6754, "unit": "img/s", "cores": 16, "kind": "port", "sample": "x" * 400, "forward_only": {"value": 4.979, "sample": "y" * 200}}
+    line, detail = bench.build_lines("bf16x3", 1, 20, 5, 64, 1024, results, fwd_only, cpu)
+    text = json.dumps(line)
+    assert len(text) < 2048 and "\n" not in text, len(text)
+    back = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline", "modes"):
+        assert key in back, key
+    assert back["value"] == 331.7 and back["conv_precision"] == "bf16x3" and back["config"]["workload"].startswith("configs[1]")
+    assert "model" not in back["config"]
+    r = back["roofline"]
+    assert set(r) == {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_us"}
+    assert len(r["kernel"]) <= 80 and r["kernel"].startswith("conv3x3_wino_kernel<PrecX3>") and r["bound"] == "mfma"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert set(back["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and back["cpu_baseline"]["kind"] == "port"
+    assert set(back["modes"]) == set(results) and set(back["modes"]["f32"]) == {"value", "ms_per_step", "frac"}
+    # the detail keeps what the line dropped, and lands in a side file
+    assert "frontend" in detail["modes"]["bf16x3"] and detail["forward_only"] is fwd_only
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.write_detail(detail)
+    assert json.load(open(tmp_path / "bench_detail.json"))["line"]["value"] == 331.7
+    # a multi-GPU line (no cpu_baseline on N>1) is just as short
+    line8, _ = bench.build_lines("bf16x3", 8, 20, 5, 64, 1024, results, None, None)
+    assert len(json.dumps(line8)) < 2048 and line8["n_gpus"] == 8 and line8["config"]["global_batch"] == 512
+    # nothing is printed after the JSON line
+    src = open(os.path.join(root, "bench.py")).read()
+    tail = src[src.index("print(json.dumps(line)"):src.index("MAX_LINE_BYTES = 2048")]
+    assert "print(" not in tail[len("print(json.dumps(line)"):]
+
+
 # ------------------------------------------------------------------------------------------------
 # pins captured from the reference itself (tests/golden/make_pins.py; VERDICT r1 "next" #8)
 # ------------------------------------------------------------------------------------------------
