@@ -48,28 +48,23 @@ struct WgArgs {
   unsigned magic_wh, magic_pw;      // 2^32 / (Pw + NS - 1) + 1, 2^32 / Pw + 1: slot / pixel index -> (row, column) without integer division
 };
 
-// NG = patch streams ("groups" of 4 waves) per workgroup.  NG = 1: 256 threads, two workgroups per CU.  NG = 2: 512 threads, one
-// workgroup per CU whose two groups take alternate patches of the workgroup's range and add their accumulators through LDS before
-// the split-K atomics: the same 8 waves per CU feed the matrix cores, but only half as many partial tiles reach the L2 atomic
-// units (256 x 147 KB instead of 512 x 147 KB per 3x3 launch; the atomics were a third of this kernel's time).
-template <class P, int NR, int NS, int NG>
-__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void conv_wgrad_class_kernel(WgArgs a) {
+// 256 threads, two workgroups per CU.  (Measured and rejected, profiles/r02/wgrad_groups_*.txt: a 512-thread workgroup of two patch
+// streams that add their accumulators through LDS before the atomics -- half the atomic traffic, 7 % faster alone in f16x2, +-0 in
+// bf16x3, 0.5-1.5 % slower in the training step where other streams' workgroups no longer fit beside it.)
+template <class P, int NR, int NS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
   typedef typename P::x8 X8;
   typedef typename P::x4 X4;
   constexpr int NT = NR * NS, NPL = P::NPL;
-  constexpr int GROUP_LDS = NPL * (X_PLANE + Y_PLANE);
-  constexpr int XCHG = NG == 2 ? NT * 4 * 16 * 64 * 4 : 0;                 // [tap][wave][reg][lane] floats of one group
-  constexpr int LDS_BYTES = NG * GROUP_LDS > XCHG ? NG * GROUP_LDS : XCHG;
+  constexpr int LDS_BYTES = NPL * (X_PLANE + Y_PLANE);
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-  __shared__ unsigned amax_cells[NG][2][2];      // [group][patch parity][X, dY]
+  __shared__ unsigned amax_cell[2][2];      // [patch parity][X, dY]
 
-  const int grp = NG == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // wave-uniform
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-  // the group's operand images start at byte gx (X planes) / gy (dY planes) of `lds`; folded into the precomputed offsets below
-  const int gx = grp * GROUP_LDS, gy = gx + NPL * X_PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the operand images start at byte gx (X planes) / gy (dY planes) of `lds`; folded into the precomputed offsets below
+  constexpr int gx = 0, gy = NPL * X_PLANE;
   unsigned char* const Xl = lds;
   unsigned char* const Yl = lds;
-  unsigned (*amax_cell)[2] = amax_cells[grp];
   const int wm = wave >> 1, wn = wave & 1;
   const int ntile = a.tiles_ci * a.tiles_co;
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous range so the
@@ -92,13 +87,13 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void conv_wgrad_class_ke
 #pragma unroll
   for (int i = 0; i < NXI; ++i) {
     const int slot = (tid >> 4) + 16 * i;
-    const int hy = div_small(slot, a.magic_wh), hx = slot - hy * Wh;
+    const int hy = div_small1(slot, a.magic_wh), hx = slot - hy * Wh;
     xcode[i] = (slot < nslots && ci0 + 4 * cq < a.Cin) ? ((hy << 16) | hx) : -1;
   }
 #pragma unroll
   for (int i = 0; i < NYI; ++i) {
     const int p = (tid >> 4) + 16 * i;
-    const int py = div_small(p, a.magic_pw), px = p - py * a.Pw;
+    const int py = div_small1(p, a.magic_pw), px = p - py * a.Pw;
     ycode[i] = (p < npix && co0 + 4 * cq < a.Cout) ? ((py << 16) | px) : -1;
   }
   // byte offset of item i relative to the patch origin (the patch origin itself is wave-uniform: scalar arithmetic per patch, no
@@ -122,7 +117,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void conv_wgrad_class_ke
     for (int t = 0; t < 2; ++t) {
       int pidx = 16 * ks + 8 * lh + 4 * t + q;
       if (pidx >= npix) pidx = 0;             // padded k: dY is zero there, any valid X address will do
-      const int py = div_small(pidx, a.magic_pw), px = pidx - py * a.Pw;
+      const int py = div_small1(pidx, a.magic_pw), px = pidx - py * a.Pw;
       xb[ks][t] = gx + wm * X_HALF + (py * Wh + px) * 64 + (cb + 4 * pp) * 2;
     }
   const int yb = gy + wn * Y_HALF + (8 * lh + q) * 64 + (cb + 4 * pp) * 2;      // + ks*1024 + t*256 + plane*Y_PLANE
@@ -140,25 +135,20 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void conv_wgrad_class_ke
   __syncthreads();
   int E = 2 * EMIN - 1, par = 0;
 
-  const int niter = (p_end - p_begin + NG - 1) / NG;
-  // (image, tile row, tile column) of the group's current patch, advanced by NG per round (wave-uniform: scalar adds and compares
-  // instead of two integer divisions per patch)
+  const int niter = p_end - p_begin;
+  // (image, tile row, tile column) of the current patch, advanced by one per round (wave-uniform: scalar adds and compares instead
+  // of two integer divisions per patch)
   int pb_, pty, ptx;
   {
-    const int first = (p_begin + grp < p_end) ? p_begin + grp : p_begin;
-    pb_ = first / tpi;
-    const int trem = first - pb_ * tpi;
+    pb_ = p_begin / tpi;
+    const int trem = p_begin - pb_ * tpi;
     pty = trem / a.tiles_x; ptx = trem - pty * a.tiles_x;
   }
   for (int it = 0; it < niter; ++it) {
-    // group g takes patches p_begin + g, + NG, ...; a group without a patch in the last round runs it on zeros (same barriers)
-    const int patch_raw = p_begin + it * NG + grp;
-    const bool pvalid = patch_raw < p_end;
+    constexpr bool pvalid = true;
     const int b = pb_, ty = pty, tx = ptx;
     const int y0 = ty * a.Ph, x0 = tx * a.Pw;
-    ptx += NG;
-    while (ptx >= a.tiles_x) { ptx -= a.tiles_x; ++pty; }
-    while (pty >= a.tiles_y) { pty -= a.tiles_y; ++pb_; }
+    if (++ptx >= a.tiles_x) { ptx = 0; if (++pty >= a.tiles_y) { pty = 0; ++pb_; } }
 
     f32x4 rx[NXI], ry[NYI];
     const int iy0 = a.sm * y0 + a.cy, ix0 = a.sm * x0 + a.cx;                       // source pixel of halo slot (0, 0)
@@ -252,20 +242,6 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void conv_wgrad_class_ke
   const int co = co0 + 32 * wn + (lane & 31);
   const int Eo = E - 28;                                   // two factors: the combined exponent can leave the float range
   const float fo1 = P::SCALED ? pow2f(Eo / 2) : 1.f, fo2 = P::SCALED ? pow2f(Eo - Eo / 2) : 1.f;
-  if (NG == 2) {
-    // group 1 hands its (already unscaled) accumulators to group 0 through LDS: [tap][wave][reg][lane], lane-contiguous
-    __syncthreads();                                       // every wave is done with the operand images
-    float* xw_ = reinterpret_cast<float*>(lds);
-    if (grp == 1) {
-#pragma unroll
-      for (int tap = 0; tap < NT; ++tap)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xw_[((tap * 4 + wave) * 16 + r) * 64 + lane] = acc[tap][r] * fo1 * fo2;
-    }
-    __syncthreads();
-    if (grp == 1) return;
-  }
-  const float* xch = reinterpret_cast<const float*>(lds);
   if (co < a.Cout && p_begin < p_end) {
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
@@ -274,8 +250,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void conv_wgrad_class_ke
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float v = acc[tap][r] * fo1 * fo2;
-        if (NG == 2) v += xch[((tap * 4 + wave) * 16 + r) * 64 + lane];
+        const float v = acc[tap][r] * fo1 * fo2;
         if (ci < a.Cin) atomicAdd(&a.dw[(ftap * a.Cin + ci) * a.Cout + co], v);
       }
     }
@@ -285,10 +260,6 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void conv_wgrad_class_ke
 // Patch choice: Ph*Pw <= 64 pixels (padded to a multiple of 16 for the k-steps), halo (Ph+2)(Pw+2) <= 112 slots;
 // minimise patches * (k-steps per patch + 1.5).
 void choose_wgrad_patch(int H, int W, int NR, int NS, int& Ph, int& Pw) {
-  if (const char* e = getenv("FS_WGRAD_PATCH")) {       // kernel experiments: "PhxPw"
-    int ph = 0, pw = 0;
-    if (sscanf(e, "%dx%d", &ph, &pw) == 2 && ph >= 1 && pw >= 1 && ph * pw <= YP && (ph + NR - 1) * (pw + NS - 1) <= XS) { Ph = ph; Pw = pw; return; }
-  }
   long best = -1;
   Ph = 8; Pw = 8;
   for (int pw = 2; pw <= 64 && pw <= W + 1; ++pw)
@@ -304,34 +275,21 @@ void choose_wgrad_patch(int H, int W, int NR, int NS, int& Ph, int& Pw) {
 }  // namespace
 
 namespace {
-// FS_WGRAD_GROUPS=2 selects the two-group variant for the 9-tap class.  Measured (profiles/r02/wgrad_groups_ab.txt): alone it is
-// 7 % faster in f16x2 (145 -> 134 us on 64->64 @ 80x80; half the atomic traffic) and +-0 in bf16x3, but in the training step it is
-// 0.5-1.5 % SLOWER in both modes (one 512-thread workgroup with 147 KB of LDS per CU leaves no room for the other streams'
-// workgroups to fill this kernel's load phases), so the default stays one group per workgroup.
-static const int g_wgrad_groups = [] { const char* e = getenv("FS_WGRAD_GROUPS"); return (e && e[0] == '2') ? 2 : 1; }();
-
 template <class P, int NR, int NS>
 int launch_class(WgArgs a, int ntile, hipStream_t stream) {
   choose_wgrad_patch(a.H, a.W, NR, NS, a.Ph, a.Pw);
   a.tiles_y = cdiv(a.H, a.Ph); a.tiles_x = cdiv(a.W, a.Pw);
-  a.magic_wh = div_magic(a.Pw + NS - 1); a.magic_pw = div_magic(a.Pw);
+  a.magic_wh = div_magic1(a.Pw + NS - 1); a.magic_pw = div_magic1(a.Pw);
   a.npatch = a.B * a.tiles_y * a.tiles_x;
-  // 512 patch streams = 8 waves on every CU, never a short second round: 512 workgroups of one group (two per CU), or -- 9-tap
-  // class with FS_WGRAD_GROUPS=2 -- 256 workgroups of two groups (half the split-K atomics).
+  // 512 patch streams = 8 waves on every CU, never a short second round: 512 workgroups (two per CU).
   // (A wave-specialised variant -- 4 producer + 4 consumer waves, double-buffered LDS, one workgroup per CU -- measured
   // +14 % on this kernel alone and -1 % on the training step, where kernels of other HRNet branches share the CUs.)
-  const int ng = (NR * NS == 9 && g_wgrad_groups == 2) ? 2 : 1;
-  int nsplit = (512 / ng) / ntile;
+  int nsplit = 512 / ntile;
   if (nsplit < 1) nsplit = 1;
-  if (nsplit > cdiv(a.npatch, ng)) nsplit = cdiv(a.npatch, ng);
+  if (nsplit > a.npatch) nsplit = a.npatch;
   a.patches_per_split = cdiv(a.npatch, nsplit);
   nsplit = cdiv(a.npatch, a.patches_per_split);
-  if (ng == 2) {
-    if constexpr (NR * NS == 9)
-      hipLaunchKernelGGL((conv_wgrad_class_kernel<P, NR, NS, 2>), dim3((unsigned)(ntile * nsplit)), dim3(512), 0, stream, a);
-  } else {
-    hipLaunchKernelGGL((conv_wgrad_class_kernel<P, NR, NS, 1>), dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
-  }
+  hipLaunchKernelGGL((conv_wgrad_class_kernel<P, NR, NS>), dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

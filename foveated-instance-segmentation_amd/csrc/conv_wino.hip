@@ -16,8 +16,12 @@
 //   LDS: NPL planes x 4 components x 80 halo slots x 80 B (32 k + 16 B pad), dynamic (76.8 KB in bf16x3, two workgroups per CU).
 //   The batch is tiled as ONE image of B*(H+1) rows (a zero row after every image: the vertical padding neighbours share).
 //   Weights are transformed and split ahead of time by a pack kernel into the order each wave consumes its B fragments.
-//   Epilogue: the two waves of a column half exchange one component through LDS; the {0,1} wave writes the even columns,
-//   the {2,3} wave the odd ones.  BatchNorm partial sums per (tile, column) as in conv_halo.hip.
+//   Workgroups are PERSISTENT: 2 per CU, each walks a strided list of tiles of its XCD's contiguous tile range; the first halo image
+//   and the first weight fragments of the next tile are requested while the current tile's rows are being stored (round 3: the
+//   first-load latency was 3.9 k of the 35 k cycles a 64-channel tile takes).
+//   Epilogue: every wave writes its two partial inverse-transform sums (even pixel / odd pixel) to LDS in accumulator order and the
+//   wave that owns a pixel parity reads them back as [pixel][4 channels] rows: 16-byte global stores (8 per wave instead of 64 dword
+//   stores; round 3), bias / dropout / BatchNorm partial sums on those rows.
 #include "conv_split.h"
 #include "conv_kernels.h"
 
@@ -38,7 +42,7 @@ struct WinoArgs {
   int B, H, W, Cs, Cd, Npad, nchunk;
   int Ph, PP, tiles_x, nx, ny, Hv;
   unsigned src_bytes, ws_bytes, dst_bytes;
-  unsigned magic_pp, magic_hv;
+  unsigned magic_pp, magic_hv, magic_ny, magic_tx;
   float drop_scale; uint32_t drop_thresh, drop_key;
 #ifdef FS_WINO_TRACE
   long long* dbg;                  // [workgroup][32] phase time stamps of wave 0 (tools/wino_trace.sh)
@@ -46,7 +50,7 @@ struct WinoArgs {
 };
 
 #ifdef FS_WINO_TRACE
-#define WINO_STAMP(i) do { if (tid == 0) a.dbg[(long)blockIdx.x * 32 + (i)] = clock64(); } while (0)
+#define WINO_STAMP(i) do { if (tid == 0 && first_tile) a.dbg[(long)blockIdx.x * 32 + (i)] = clock64(); } while (0)
 #else
 #define WINO_STAMP(i) do { } while (0)
 #endif
@@ -102,34 +106,47 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
   }
 }
 
-// NJ = 32-column sub-tiles per wave.  NJ = 1: 64 pairs x 64 columns per workgroup (a wave holds 2 pair blocks x 1 sub-tile).
-// NJ = 2: 32 pairs x 128 columns (1 pair block x 2 sub-tiles): the halo image is transformed and split once for twice the
-// output channels -- that VALU work competes with the MFMAs for issue slots -- at twice the B-fragment traffic per MFMA.
-template <class P, int NJ>
+constexpr int XCH_BYTES = 65536;   // epilogue exchange: [4 waves][2 parities][2 blocks][32 rows][32 columns] floats
+
+template <class P>
+constexpr int wino_lds_bytes() {
+  constexpr int img = P::NPL * PLANE * 2;
+  return (img > XCH_BYTES ? img : XCH_BYTES) + 4 * 32 * 2 * 4 /* stats */ + 2 * 64 * 4 /* rowpix x2 */ + 16 /* amax cells */;
+}
+
+template <class P>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   typedef typename P::x8 X8;
   typedef typename P::x4 X4;
   constexpr int NPL = P::NPL;
-  constexpr int MI = 2 / NJ;             // 32-pair blocks per wave
-  constexpr int NITEM = NJ == 1 ? 3 : 2; // (slot, channel quad) items per thread: 8 * slots <= 256 * NITEM
+  constexpr int MI = 2;                  // 32-pair blocks per wave
+  constexpr int NITEM = 3;               // (slot, channel quad) items per thread: 8 * slots <= 256 * NITEM
+  constexpr int IMG = NPL * PLANE * 2 > XCH_BYTES ? NPL * PLANE * 2 : XCH_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typename P::T* Ah = reinterpret_cast<typename P::T*>(smem);                  // [NPL][4][WNS][XLD]
-  int* rowpix = reinterpret_cast<int*>(smem + NPL * PLANE * 2);                // [64]
-  unsigned* amax_cell = reinterpret_cast<unsigned*>(rowpix + 64);              // [2]
+  float* red = reinterpret_cast<float*>(smem + IMG);                           // [4 waves][32 columns][2]
+  int* rowpix = reinterpret_cast<int*>(smem + IMG + 1024);                     // [2 tile parities][64]
+  unsigned* amax_cell = reinterpret_cast<unsigned*>(rowpix + 128);             // [2]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: cp selects the wave's B stream through the SGPR offset operand
   const int cp = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
+#ifdef FS_WINO_TRACE
+  bool first_tile = true;
+#endif
   WINO_STAMP(0);
-  const int nwg = a.nx * a.ny;
+  // ---- persistent schedule: XCD x owns a contiguous range of tiles (the column tiles of one pixel tile and neighbouring halos meet
+  // in one 4 MB L2); its workgroups (blockIdx & 7 == x under round-robin placement -- speed only) take every L-th tile of it ----
+  const int ntile = a.nx * a.ny;
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-  const int qd = nwg >> 3, rm = nwg & 7;
-  const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
-  const int mt = wg / a.ny;
-  const int n0 = (wg - mt * a.ny) * 64 * NJ;
-  const int ty = mt / a.tiles_x, tx = mt - ty * a.tiles_x;
-  const int y0 = ty * a.Ph, x0 = tx * 2 * a.PP;
+  const int qd = ntile >> 3, rm = ntile & 7;
+  const int t_first = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd);
+  const int t_end = t_first + qd + (xcd < rm ? 1 : 0);
+  const int L = ((int)gridDim.x + 7 - xcd) >> 3;
+  int wg = t_first + loc;
+  if (wg >= t_end) return;               // workgroup-uniform
+
   const int nslots = (a.Ph + 2) * a.PP, npairs = a.Ph * a.PP;
   // (image, row) of virtual row vy; gap rows and rows outside the stacked batch get row = H (invalid)
   auto image_row = [&](int vy, int& bb, int& yy) {
@@ -137,34 +154,51 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     bb = in ? div_small(vy, a.magic_hv) : 0;
     yy = in ? vy - bb * a.Hv : a.H;
   };
-
-  if (tid < 32 * MI) {
-    const int p = (tid & ~31) + row_perm(tid & 31);
-    const int py = div_small(p, a.magic_pp), px = p - py * a.PP;
-    int bb, yy;
-    image_row(y0 + py, bb, yy);
-    const bool live = p < npairs && yy < a.H && x0 + 2 * px < a.W;
-    rowpix[tid] = live ? ((bb * a.H + yy) * a.W + x0 + 2 * px) * a.Cd : -1;      // element offset of the pair's even pixel
-  }
-  if (tid < 2) amax_cell[tid] = 0u;
+  // tile index -> pixel tile mt, first column n0, tile origin (y0 in stacked rows, x0)
+  auto decode = [&](int w_, int& mt, int& n0, int& y0, int& x0) {
+    mt = div_small1(w_, a.magic_ny);
+    n0 = (w_ - mt * a.ny) * 64;
+    const int ty = div_small1(mt, a.magic_tx), tx = mt - ty * a.tiles_x;
+    y0 = ty * a.Ph; x0 = tx * 2 * a.PP;
+  };
+  // (the per-lane constants of the two set-up lambdas are recomputed per tile from an opaque copy of tid: hoisted out of the tile loop
+  // they would sit in -- and spill from -- registers the MFMA loop needs)
+  auto write_rowpix = [&](int par, int y0, int x0) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    if (t_ < 32 * MI) {
+      const int tid = t_;
+      const int p = (tid & ~31) + row_perm(tid & 31);
+      const int py = div_small(p, a.magic_pp), px = p - py * a.PP;
+      int bb, yy;
+      image_row(y0 + py, bb, yy);
+      const bool live = p < npairs && yy < a.H && x0 + 2 * px < a.W;
+      rowpix[par * 64 + tid] = live ? ((bb * a.H + yy) * a.W + x0 + 2 * px) * a.Cd : -1;      // element offset of the pair's even pixel
+    }
+  };
   const int q = tid & 7;
-  int goff[NITEM], gmask[NITEM];
+  int goff[NITEM], gmask = 0;            // gmask: 4 validity bits per item
+  auto setup_loader = [&](int y0, int x0) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
 #pragma unroll
-  for (int i = 0; i < NITEM; ++i) {
-    const int slot = (tid >> 3) + 32 * i;
-    const int hy = div_small(slot, a.magic_pp), pj = slot - hy * a.PP;
-    const int ix = x0 + 2 * pj - 1;
-    int bb, iy;
-    image_row(y0 + hy - 1, bb, iy);
-    const bool rowok = slot < nslots && iy < a.H;
-    int m = 0;
+    for (int i = 0; i < NITEM; ++i) {
+      const int slot = (t_ >> 3) + 32 * i;
+      const int hy = div_small(slot, a.magic_pp), pj = slot - hy * a.PP;
+      const int ix = x0 + 2 * pj - 1;
+      int bb, iy;
+      image_row(y0 + hy - 1, bb, iy);
+      const bool rowok = slot < nslots && iy < a.H;
+      int m = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) m |= (rowok && ix + e >= 0 && ix + e < a.W) ? (1 << e) : 0;
-    gmask[i] = m;
-    goff[i] = ((bb * a.H + (rowok ? iy : 0)) * a.W + ix) * a.Cs + 4 * q;
-  }
+      for (int e = 0; e < 4; ++e) m |= (rowok && ix + e >= 0 && ix + e < a.W) ? (1 << e) : 0;
+      gmask = i == 0 ? m : (gmask | (m << (4 * i)));
+      goff[i] = ((bb * a.H + (rowok ? iy : 0)) * a.W + ix) * a.Cs + 4 * (t_ & 7);
+    }
+  };
   const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(a.src, a.src_bytes);
   const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.ws, a.ws_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
 
   f32x4 ra[NITEM][4];
   auto load_halo = [&](int chunk) {
@@ -174,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     for (int i = 0; i < NITEM; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const bool ok = cok && ((gmask[i] >> e) & 1);
+        const bool ok = cok && ((gmask >> (4 * i + e)) & 1);
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? (int)((unsigned)(goff[i] + e * a.Cs + c0) * 4u) : (int)OOB, 0, 0);
         ra[i][e] = __builtin_bit_cast(f32x4, v);
       }
@@ -213,37 +247,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     }
   };
 
-  int rowbase[MI][3];                    // [mi][filter row]: element offset of the wave's first component image
+  int rowbase[MI];                       // [mi]: element offset of the wave's first component image, filter row 0 (tile-invariant)
+  const int rowstep = a.PP * XLD;        // elements per halo row (scalar)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int p = 32 * mi + row_perm(l31);
     const bool live = p < npairs;
     const int py = live ? div_small(p, a.magic_pp) : 0, px = live ? p - py * a.PP : 0;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) rowbase[mi][r] = 2 * cp * CPLANE + ((py + r) * a.PP + px) * XLD + 8 * lh;
+    rowbase[mi] = 2 * cp * CPLANE + (py * a.PP + px) * XLD + 8 * lh;
   }
-  const int bvoff = HDR + ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2;      // sub-tile j: + j * 64 columns = j * 2048 bytes
   const int plane_bytes = a.Npad * 32;
   const int step_bytes = NPL * plane_bytes;
-  const int G = a.nchunk * 12;           // B fragments this wave consumes
+  const int G = a.nchunk * 12;           // B fragments this wave consumes per tile
+  auto b_voff = [&](int n0) { return HDR + ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2; };
 
   X8 fa[2][MI][NPL];      // [buffer][mi][plane]
-#ifndef FS_WINO_RING
-#define FS_WINO_RING 3
-#endif
-  constexpr int RD = FS_WINO_RING;   // B-fragment ring: fragments run RD - 1 steps ahead of the MFMAs (12 % RD == 0: slots are compile-time)
-  static_assert(12 % RD == 0, "ring depth must divide the 12 steps of a chunk");
-  X8 fb[RD][NJ][NPL];     // [ring slot][sub-tile][plane]
-  auto load_b = [&](int g, X8 (&dst)[NJ][NPL]) {
-    const int gg = g < G ? g : G - 1;
+  constexpr int RD = 3;   // B-fragment ring: fragments run two steps ahead of the MFMAs (deeper rings measured +-0.5 %, profiles/r02)
+  X8 fb[RD][NPL];         // [ring slot][plane]
+  auto load_b = [&](int gg, int voff, X8 (&dst)[NPL]) {
     const int g4 = (gg >> 2) * 8 + 4 * cp + (gg & 3);      // wave-uniform: goes in the scalar offset operand
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff + j * 2048, g4 * step_bytes + pl * plane_bytes, 0);
-        dst[j][pl] = __builtin_bit_cast(X8, v);
-      }
+    for (int pl = 0; pl < NPL; ++pl) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff, g4 * step_bytes + pl * plane_bytes, 0);
+      dst[pl] = __builtin_bit_cast(X8, v);
+    }
   };
   auto read_a = [&](int step, X8 (&dst)[MI][NPL]) {
     const int ky = step >> 2, ci = (step >> 1) & 1, s2 = step & 1;
@@ -251,161 +278,197 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl)
-        dst[mi][pl] = *reinterpret_cast<const X8*>(&Ah[pl * PLANE + rowbase[mi][ky] + ci * CPLANE + 16 * s2]);
+        dst[mi][pl] = *reinterpret_cast<const X8*>(&Ah[pl * PLANE + rowbase[mi] + ky * rowstep + ci * CPLANE + 16 * s2]);
   };
 
-  f32x16 acc[2][2];       // [component of the pair][block b = mi (NJ = 1) or sub-tile j (NJ = 2)]
+  // ---- first tile ----
+  int mt, n0, y0, x0;
+  decode(wg, mt, n0, y0, x0);
+  setup_loader(y0, x0);
+  int par = 0;
+  write_rowpix(par, y0, x0);
+  if (tid < 2) amax_cell[tid] = 0u;
+  int bvoff = b_voff(n0);
 #pragma unroll
-  for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ci][b][r] = 0.f;
-  int E = EMIN;
-#pragma unroll
-  for (int r = 0; r < RD - 1; ++r) load_b(r, fb[r]);
+  for (int r = 0; r < RD - 1; ++r) load_b(r < G ? r : G - 1, bvoff, fb[r]);
   load_halo(0);
   __syncthreads();                        // amax cells zeroed before the first atomic
   WINO_STAMP(1);
-  int g = 0;
-  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-    transform();
-    if (P::SCALED) tile_amax(chunk & 1);
-    if (chunk < 4) WINO_STAMP(2 + 5 * chunk);
-    __syncthreads();                      // amax complete; every wave has finished reading the previous image
-    if (chunk < 4) WINO_STAMP(3 + 5 * chunk);
-    if (P::SCALED) {
-      const int ec = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[chunk & 1]));
-      if (ec > E) {
-        if (chunk > 0) {
-          const float f = pow2f(E - ec);
-#pragma unroll
-          for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) acc[ci][b][r] *= f;
-        }
-        E = ec;
-      }
-      if (tid == 0) amax_cell[(chunk + 1) & 1] = 0u;
-    }
-    store_halo(pow2f(14 - E));
-    if (chunk < 4) WINO_STAMP(4 + 5 * chunk);
-    __syncthreads();
-    if (chunk < 4) WINO_STAMP(5 + 5 * chunk);
-    if (chunk + 1 < a.nchunk) load_halo(chunk + 1);
-    read_a(0, fa[0]);
-#pragma unroll
-    for (int step = 0; step < 12; ++step) {
-      if (step + 1 < 12) read_a(step + 1, fa[(step + 1) & 1]);
-      load_b(g + RD - 1, fb[(step + RD - 1) % RD]);
-      __builtin_amdgcn_sched_barrier(0);
-      const X8(&A)[MI][NPL] = fa[step & 1];
-      const X8(&Bf)[NJ][NPL] = fb[step % RD];
-      const int ci = (step >> 1) & 1;
-#pragma unroll
-      for (int t = 0; t < P::NTERM; ++t) {         // smallest terms first, the two blocks interleaved
-        acc[ci][0] = P::mfma(A[0][P::ta(t)], Bf[0][P::tb(t)], acc[ci][0]);
-        acc[ci][1] = P::mfma(A[MI - 1][P::ta(t)], Bf[NJ - 1][P::tb(t)], acc[ci][1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      ++g;
-    }
-    if (chunk < 4) WINO_STAMP(6 + 5 * chunk);
-  }
+  int cc = 0;                             // chunks processed by this workgroup (parity of the f16x2 amax cell)
 
-  // ---- epilogue: inverse transform across the two component-pair waves, then as conv_halo.hip ----
-  WINO_STAMP(22);
-  __syncthreads();                        // the halo image is dead
-  WINO_STAMP(23);
-  f32x4* xch = reinterpret_cast<f32x4*>(smem);             // [wave][2 blocks x 4 row groups][64 lanes] x 4 rows  (32 KB)
+  for (;;) {
+    f32x16 acc[2][2];       // [component of the pair][pair block mi]
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+    for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      f32x4 v;
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int ri = 0; ri < 4; ++ri) v[ri] = cp == 0 ? acc[1][b][4 * rg + ri] : acc[0][b][4 * rg + ri];
-      xch[(wave * 8 + b * 4 + rg) * 64 + lane] = v;
+        for (int r = 0; r < 16; ++r) acc[ci][b][r] = 0.f;
+    int E = EMIN;
+    int g = 0;
+    const int wg_next = wg + L;
+    const bool has_next = wg_next < t_end;
+    int mt_n = 0, n0_n = 0, y0_n = 0, x0_n = 0, bvoff_n = bvoff;
+    if (has_next) {
+      decode(wg_next, mt_n, n0_n, y0_n, x0_n);
+      bvoff_n = b_voff(n0_n);
     }
-  __syncthreads();
-  float f1 = 1.f, f2 = 1.f;
-  if (P::SCALED) {
-    const int Ew = exponent_of_bits(*a.ew);
-    const int es = E + Ew - 28;
-    const bool one = es >= -126 && es <= 127;
-    f1 = one ? pow2f(es) : pow2f(E - 14);
-    f2 = one ? 1.f : pow2f(Ew - 14);
-  }
-  const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
-  float csum[NJ], csq[NJ];
+    for (int chunk = 0; chunk < a.nchunk; ++chunk, ++cc) {
+      transform();
+      if (P::SCALED) tile_amax(cc & 1);
+      if (chunk < 4) WINO_STAMP(2 + 5 * chunk);
+      __syncthreads();                      // amax complete; every wave has finished reading the previous image / exchange buffer
+      if (chunk < 4) WINO_STAMP(3 + 5 * chunk);
+      if (P::SCALED) {
+        const int ec = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[cc & 1]));
+        if (ec > E) {
+          if (chunk > 0) {
+            const float f = pow2f(E - ec);
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int mi = NJ == 1 ? b : 0, j = NJ == 1 ? 0 : b;
-    if (mi == 0) { csum[j] = 0.f; csq[j] = 0.f; }
-    const int n = n0 + 64 * j + 32 * wn + l31;
-    if (n >= a.Cd) continue;
-    const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
-    const int ncol = n + cp * a.Cd;                        // the {2,3} wave writes the odd pixel of the pair
+            for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const i32x4 pix = *reinterpret_cast<const i32x4*>(&rowpix[32 * mi + 8 * rg + 4 * lh]);
-      const f32x4 other = xch[((wave ^ 2) * 8 + b * 4 + rg) * 64 + lane];
+              for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int ri = 0; ri < 4; ++ri) {
-        const int r = 4 * rg + ri;
-        // even column (components 0,1 here, 2 received): m0 + m1 + m2;  odd column (2,3 here, 1 received): m1 - m2 - m3
-        const float m = cp == 0 ? (acc[0][b][r] + acc[1][b][r]) + other[ri] : (other[ri] - acc[0][b][r]) - acc[1][b][r];
-        const bool live = pix[ri] >= 0;
-        const unsigned e = (unsigned)(pix[ri] + ncol);
-        float v = P::SCALED ? fmaf(m * f2, f1, bv) : m + bv;
-        if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
-        v = live ? v : 0.f;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
-        csum[j] += v; csq[j] += v * v;
+                for (int r = 0; r < 16; ++r) acc[ci][b][r] *= f;
+          }
+          E = ec;
+        }
+        if (tid == 0) amax_cell[(cc + 1) & 1] = 0u;
       }
-    }
-  }
-  if (a.stats != nullptr) {
-    float* red = reinterpret_cast<float*>(smem + 32768);    // [wave][NJ][32 cols][2], behind the exchange buffer
+      store_halo(pow2f(14 - E));
+      if (chunk < 4) WINO_STAMP(4 + 5 * chunk);
+      __syncthreads();
+      if (chunk < 4) WINO_STAMP(5 + 5 * chunk);
+      if (chunk + 1 < a.nchunk) load_halo(chunk + 1);
+      read_a(0, fa[0]);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const float s1 = csum[j] + __shfl_xor(csum[j], 32, 64), s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
-      if (lh == 0) { red[((wave * NJ + j) * 32 + l31) * 2] = s1; red[((wave * NJ + j) * 32 + l31) * 2 + 1] = s2; }
+      for (int step = 0; step < 12; ++step) {
+        if (step + 1 < 12) read_a(step + 1, fa[(step + 1) & 1]);
+        {
+          const int gi = g + RD - 1;         // past this tile's last fragment: the next tile's first ones (or a repeat of the last)
+          const bool own = gi < G;
+          const int gn = gi - G < G ? gi - G : G - 1;
+          load_b(own ? gi : (has_next ? gn : G - 1), own ? bvoff : bvoff_n, fb[(step + RD - 1) % RD]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const X8(&A)[MI][NPL] = fa[step & 1];
+        const X8(&Bf)[NPL] = fb[step % RD];
+        const int ci = (step >> 1) & 1;
+#pragma unroll
+        for (int t = 0; t < P::NTERM; ++t) {         // smallest terms first, the two blocks interleaved
+          acc[ci][0] = P::mfma(A[0][P::ta(t)], Bf[P::tb(t)], acc[ci][0]);
+          acc[ci][1] = P::mfma(A[1][P::ta(t)], Bf[P::tb(t)], acc[ci][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ++g;
+      }
+      if (chunk < 4) WINO_STAMP(6 + 5 * chunk);
+    }
+
+    // ---- epilogue: inverse transform across the two component-pair waves through LDS, rows of [pixel][4 channels] out ----
+    WINO_STAMP(22);
+    __syncthreads();                        // the halo image is dead
+    WINO_STAMP(23);
+    {
+      // partial sums in accumulator order: parity 0 (even pixel) = m0 + m1 | m2, parity 1 (odd pixel) = m1 | -(m2 + m3)
+      int l_ = lane;
+      asm volatile("" : "+v"(l_));         // (epilogue lane constants are formed per tile, not kept across the MFMA loop)
+      float* xw = reinterpret_cast<float*>(smem) + wave * 4096 + (4 * (l_ >> 5)) * 32 + (l_ & 31);      // [parity][block][32 rows][32 columns]
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2);
+          const float ev = cp == 0 ? acc[0][b][r] + acc[1][b][r] : acc[0][b][r];
+          const float od = cp == 0 ? acc[1][b][r] : -(acc[0][b][r] + acc[1][b][r]);
+          xw[(b * 32 + row) * 32] = ev;
+          xw[2048 + (b * 32 + row) * 32] = od;
+        }
     }
     __syncthreads();
-    if (tid < 128 * NJ) {
-      const int col = tid >> 1, which = tid & 1;
-      const int j = col >> 6, w0 = (col >> 5) & 1, c31 = col & 31;            // waves w0 (even columns) and w0 + 2 (odd columns)
-      const float v = red[((w0 * NJ + j) * 32 + c31) * 2 + which] + red[(((w0 + 2) * NJ + j) * 32 + c31) * 2 + which];
-      if (n0 + col < a.Cd) a.stats[((long)mt * a.Cd + n0 + col) * 2 + which] = v;
+    if (has_next) {          // the accumulators are dead: the next tile's first halo image travels while this tile's rows are stored
+      setup_loader(y0_n, x0_n);
+      write_rowpix(par ^ 1, y0_n, x0_n);
+      load_halo(0);
     }
+    float f1 = 1.f, f2 = 1.f;
+    if (P::SCALED) {
+      const int Ew = exponent_of_bits(*a.ew);
+      const int es = E + Ew - 28;
+      const bool one = es >= -126 && es <= 127;
+      f1 = one ? pow2f(es) : pow2f(E - 14);
+      f2 = one ? 1.f : pow2f(Ew - 14);
+    }
+    {
+      // this wave stores pixel parity cp of its 32-column half: lane = (row within a group of 8, channel quad)
+      int l_ = lane;
+      asm volatile("" : "+v"(l_));
+      const int c4 = (l_ & 7) * 4, rsub = l_ >> 3;
+      const int n = n0 + 32 * wn + c4;
+      const bool nok = n < a.Cd;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias != nullptr && nok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = a.bias[n + j];
+      }
+      const float* mine = reinterpret_cast<const float*>(smem) + wave * 4096 + cp * 2048;
+      const float* theirs = reinterpret_cast<const float*>(smem) + (wave ^ 2) * 4096 + cp * 2048;
+      f32x4 csum = {0.f, 0.f, 0.f, 0.f}, csq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int row = b * 32 + 8 * k + rsub;
+          const int pix = rowpix[par * 64 + row];
+          const f32x4 m = *reinterpret_cast<const f32x4*>(mine + row * 32 + c4) + *reinterpret_cast<const f32x4*>(theirs + row * 32 + c4);
+          const bool live = pix >= 0 && nok;
+          const unsigned e = (unsigned)(pix + n + cp * a.Cd);                 // the {2,3} waves write the odd pixel of the pair
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x = P::SCALED ? fmaf(m[j] * f2, f1, bv[j]) : m[j] + bv[j];
+            if (a.drop_thresh != 0u) x = fs_dropout_keep((uint32_t)(e + j), a.drop_key, a.drop_thresh) ? x * a.drop_scale : 0.f;
+            v[j] = live ? x : 0.f;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
+          csum += v; csq += v * v;
+        }
+      if (a.stats != nullptr) {
+        // column sums over the wave's 64 rows: lanes with equal channel quad (lane & 7) hold different rows
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { csum[j] += __shfl_xor(csum[j], o, 64); csq[j] += __shfl_xor(csq[j], o, 64); }
+        if (l_ < 8) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { red[(wave * 32 + c4 + j) * 2] = csum[j]; red[(wave * 32 + c4 + j) * 2 + 1] = csq[j]; }
+        }
+        __syncthreads();
+        if (tid < 128) {
+          const int col = tid >> 1, which = tid & 1;
+          const int w0 = col >> 5, c31 = col & 31;                          // waves w0 (even pixels) and w0 + 2 (odd pixels)
+          const float v = red[(w0 * 32 + c31) * 2 + which] + red[((w0 + 2) * 32 + c31) * 2 + which];
+          if (n0 + col < a.Cd) a.stats[((long)mt * a.Cd + n0 + col) * 2 + which] = v;
+        }
+      }
+    }
+    WINO_STAMP(24);
+    if (!has_next) break;
+#ifdef FS_WINO_TRACE
+    first_tile = false;
+#endif
+    wg = wg_next; mt = mt_n; n0 = n0_n; bvoff = bvoff_n; par ^= 1;
   }
-  WINO_STAMP(24);
 }
 
 const bool g_wino = [] { const char* e = getenv("FS_WINOGRAD"); return !(e && e[0] == '0'); }();
 
-// 32-column sub-tiles per wave.  FS_WINO_NJ=2 makes layers with >= 128 output channels split their halo image once per 128
-// columns; measured and left off: the store phase shrinks by a third but the doubled B-fragment traffic lengthens the MFMA phase
-// (kernel time +-1 % in isolation, the training step 5 % slower: profiles/r02/winograd_column_tiling_ab.txt)
-const int g_wino_nj = [] { const char* e = getenv("FS_WINO_NJ"); return e ? atoi(e) : 1; }();
-int wino_nj(int Cd) { return (g_wino_nj == 2 && Cd >= 128) ? 2 : 1; }
-
-// Ph rows x PP pairs <= 64 / NJ pairs per workgroup, halo (Ph+2)*PP <= WNS / NJ; fewest tiles over the stacked batch, then smallest halo.
-void wino_plan(int nj, int B, int H, int W, int& Ph, int& PP, int& tiles_x, int& nx) {
+// Ph rows x PP pairs <= 64 pairs per workgroup, halo (Ph+2)*PP <= WNS; fewest tiles over the stacked batch, then smallest halo.
+void wino_plan(int B, int H, int W, int& Ph, int& PP, int& tiles_x, int& nx) {
   const long rows = (long)B * (H + 1);
-  const int wp = W / 2, maxpairs = 64 / nj, maxslots = WNS / nj;
+  const int wp = W / 2, maxpairs = 64, maxslots = WNS;
   long best = -1;
-  Ph = 8 / nj; PP = 8;
-  if (const char* e = getenv("FS_WINO_TILE")) {        // kernel experiments: "PhxPP"
-    int ph = 0, pp = 0;
-    if (sscanf(e, "%dx%d", &ph, &pp) == 2 && ph >= 1 && pp >= 2 && pp <= wp && ph * pp <= maxpairs && (ph + 2) * pp <= maxslots) {
-      Ph = ph; PP = pp; tiles_x = cdiv(wp, PP); nx = cdiv(rows, Ph) * tiles_x;
-      return;
-    }
-  }
+  Ph = 8; PP = 8;
   for (int pp = 2; pp <= 32 && pp <= wp; ++pp) {      // div_small needs a divisor >= 2
     int ph = maxpairs / pp;
     while (ph > 1 && (ph + 2) * pp > maxslots) --ph;
@@ -418,7 +481,20 @@ void wino_plan(int nj, int B, int H, int W, int& Ph, int& PP, int& tiles_x, int&
   nx = cdiv(rows, Ph) * tiles_x;
 }
 
-template <class P, int NJ>
+// persistent grid: two workgroups per CU of the current device (cached per device)
+int wino_grid_slots() {
+  static int slots[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 512;
+  if (slots[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    slots[dev] = 2 * cus;
+  }
+  return slots[dev];
+}
+
+template <class P>
 int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int Cin, int Cout, int transposed, hipStream_t stream) {
   int e = FS_OK;
   a.ew = P::SCALED ? fs_f16_weight_amax(w, (long)9 * Cin * Cout, ws, w_amax, stream, &e) : nullptr;
@@ -427,18 +503,29 @@ int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int 
   hipLaunchKernelGGL((wino_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws),
                      a.ew, Cin, Cout, transposed, a.Cs, a.Cd, a.Npad, total);
   FS_LAUNCH_CHECK();
-  constexpr int lds = P::NPL * PLANE * 2 + 64 * 4 + 16;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<P, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (attr != hipSuccess) return (int)attr;
+  constexpr int lds = wino_lds_bytes<P>();
+  {
+    // the dynamic-LDS opt-in (above the 64 KB default) is a per-device function attribute: set it once on every device used
+    static unsigned long long done = 0ull;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return FS_ERR_ARG;
+    if (dev < 0 || dev >= 64 || !((done >> dev) & 1ull)) {
+      const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (attr != hipSuccess) return (int)attr;
+      if (dev >= 0 && dev < 64) done |= 1ull << dev;
+    }
+  }
+  const long ntile = (long)a.nx * a.ny;
+  const int slots = wino_grid_slots();
+  const unsigned grid = (unsigned)(ntile < slots ? ntile : slots);
 #ifdef FS_WINO_TRACE
   static long long* dbg = nullptr;
-  const long nwg = (long)a.nx * a.ny;
+  const long nwg = grid;
   if (dbg == nullptr && hipMalloc(&dbg, sizeof(long long) * 32 * 65536) != hipSuccess) return FS_ERR_ARG;
-  if (nwg > 65536) return FS_ERR_ARG;
   a.dbg = dbg;
   hipMemsetAsync(dbg, 0, sizeof(long long) * 32 * nwg, stream);
 #endif
-  hipLaunchKernelGGL((conv3x3_wino_kernel<P, NJ>), dim3((unsigned)(a.nx * a.ny)), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((conv3x3_wino_kernel<P>), dim3(grid), dim3(256), lds, stream, a);
   FS_LAUNCH_CHECK();
 #ifdef FS_WINO_TRACE
   {
@@ -446,18 +533,14 @@ int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int 
     static long long host[32 * 65536];
     hipMemcpy(host, dbg, sizeof(long long) * 32 * nwg, hipMemcpyDeviceToHost);
     double sum[32] = {0};
-    long long tmin = host[0], tmax = host[24];
-    for (long w = 0; w < nwg; ++w) {
+    for (long w_ = 0; w_ < nwg; ++w_)
       for (int i = 1; i < 25; ++i) {
-        if (host[w * 32 + i] == 0) continue;
+        if (host[w_ * 32 + i] == 0) continue;
         int prev = i - 1;
-        while (prev > 0 && host[w * 32 + prev] == 0) --prev;
-        sum[i] += (double)(host[w * 32 + i] - host[w * 32 + prev]);
+        while (prev > 0 && host[w_ * 32 + prev] == 0) --prev;
+        sum[i] += (double)(host[w_ * 32 + i] - host[w_ * 32 + prev]);
       }
-      if (host[w * 32] < tmin) tmin = host[w * 32];
-      if (host[w * 32 + 24] > tmax) tmax = host[w * 32 + 24];
-    }
-    fprintf(stderr, "wino trace B%d %dx%d %d->%d nchunk %d nwg %ld span %lld:", a.B, a.H, a.W, a.Cs, a.Cd, a.nchunk, nwg, tmax - tmin);
+    fprintf(stderr, "wino trace (first tile of each workgroup) B%d %dx%d %d->%d nchunk %d tiles %ld grid %ld:", a.B, a.H, a.W, a.Cs, a.Cd, a.nchunk, ntile, nwg);
     for (int i = 1; i < 25; ++i) if (sum[i] > 0) fprintf(stderr, " [%d]%.0f", i, sum[i] / nwg);
     fprintf(stderr, "\n");
   }
@@ -476,13 +559,14 @@ bool fs_wino_eligible(int mode, int B, int H, int W, int Cs, int Cd) {
 
 long fs_wino_pack_bytes(int mode, int Cs, int Cd) {
   const int npl = mode == 2 ? 2 : 3;
-  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 127) / 128) * 128;       // room for either column tiling
+  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 63) / 64) * 64;
   return HDR + nchunk * 24 * npl * Npad * 16 * 2;
 }
 
 int fs_wino_stats_slabs(int B, int H, int W, int Cd) {
+  (void)Cd;
   int Ph, PP, tx, nx;
-  wino_plan(wino_nj(Cd), B, H, W, Ph, PP, tx, nx);
+  wino_plan(B, H, W, Ph, PP, tx, nx);
   return nx;
 }
 
@@ -492,25 +576,23 @@ int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bia
   WinoArgs a;
   a.src = src; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = dst; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cs = Cs; a.Cd = Cd;
-  const int nj = wino_nj(Cd);
-  a.Npad = ((Cd + 64 * nj - 1) / (64 * nj)) * 64 * nj;
+  a.Npad = ((Cd + 63) / 64) * 64;
   a.nchunk = (Cs + 31) / 32;
-  wino_plan(nj, B, H, W, a.Ph, a.PP, a.tiles_x, a.nx);
-  a.ny = a.Npad / (64 * nj);
+  wino_plan(B, H, W, a.Ph, a.PP, a.tiles_x, a.nx);
+  a.ny = a.Npad / 64;
   a.Hv = H + 1;
   a.magic_hv = div_magic(a.Hv);
   a.magic_pp = div_magic(a.PP);
+  a.magic_ny = div_magic1(a.ny);
+  a.magic_tx = div_magic1(a.tiles_x);
   const long pack_bytes = fs_wino_pack_bytes(mode, Cs, Cd);
   if (!fs_wino_eligible(mode, B, H, W, Cs, Cd) || pack_bytes >= 2147483647L || (size_t)B * H * W * Cs * 4 >= 4294967000UL ||
-      (size_t)B * H * W * Cd * 4 >= 4294967000UL)
+      (size_t)B * H * W * Cd * 4 >= 4294967000UL || (long)a.nx * a.ny >= 65536)
     return FS_ERR_ARG;
   a.src_bytes = (unsigned)((size_t)B * H * W * Cs * 4);
   a.dst_bytes = (unsigned)((size_t)B * H * W * Cd * 4);
   a.ws_bytes = (unsigned)pack_bytes;
   a.drop_scale = drop_scale; a.drop_thresh = drop_thresh; a.drop_key = drop_key;
-  if (nj == 2)
-    return mode == 2 ? run_wino<PrecF16, 2>(a, w, ws, w_amax, Cin, Cout, transposed, stream)
-                     : run_wino<PrecX3, 2>(a, w, ws, w_amax, Cin, Cout, transposed, stream);
-  return mode == 2 ? run_wino<PrecF16, 1>(a, w, ws, w_amax, Cin, Cout, transposed, stream)
-                   : run_wino<PrecX3, 1>(a, w, ws, w_amax, Cin, Cout, transposed, stream);
+  return mode == 2 ? run_wino<PrecF16>(a, w, ws, w_amax, Cin, Cout, transposed, stream)
+                   : run_wino<PrecX3>(a, w, ws, w_amax, Cin, Cout, transposed, stream);
 }

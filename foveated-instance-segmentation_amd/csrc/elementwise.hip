@@ -137,14 +137,52 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   }
 }
 
-// ---- BN backward pass 1: sum(g), sum(g*xhat), g = dz * act'(z) --------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
-                                                            const unsigned char* __restrict__ mask,
-                                                            const float* __restrict__ y, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, long M, int C, int ld,
-                                                            int Ctot, int rows_per_block, int act,
-                                                            double* __restrict__ sums) {
-  extern __shared__ double sm[];
+// ---- BN backward -------------------------------------------------------------------------------
+// Three stages, none of which touches the matrix cores, LDS beyond 8 KB or more than 48 VGPRs -- so that their workgroups fit NEXT TO
+// the convolution kernels of the other HRNet branches (two 230-VGPR waves per SIMD and 154 of the CU's 160 KB of LDS leave exactly
+// that much), instead of waiting for a CU to drain:
+//   partial : per-block column sums  S = sum(g), SX = sum(g * xhat),  g = dz * act'(z),  xhat = (y - mean) * invstd  -> slab[blk][C][2]
+//             (skipped when the kernel that PRODUCED dz already wrote the slab: add_n_bnsum_kernel below)
+//   finalize: slab -> dgamma, dbeta and the per-channel coefficients of the apply pass
+//   apply   : dy = ga * g - d * (y - mean) - bb   [x dropout mask],  dres = g
+//             with ga = gamma*invstd, d = ga * invstd * SX/M, bb = ga * S/M   (eval mode: d = bb = 0)
+// Algebra as F.batch_norm's backward: dy = ga * (g - mean(g) - xhat * mean(g * xhat)).
+struct BnMask {
+  // g = dz * act'(out): from the 1-byte mask of 4 channels when the forward wrote one, else from the activation output z
+  static __device__ __forceinline__ f32x4 apply(f32x4 g, const unsigned char* mask, const float* z, long o, int act) {
+    if (act == FS_ACT_NONE) return g;
+    if (mask != nullptr) {
+      const unsigned m = mask[o >> 2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = ((m >> j) & 1u) ? g[j] : 0.f;
+    } else {
+      const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] *= fs_act_mask(zz[j], act);
+    }
+    return g;
+  }
+};
+
+// column sums of one block's rows -> slab[blockIdx.x][C][2]; red = [C][2] floats of LDS (ds_add_f32 from the rpi row lanes)
+__device__ __forceinline__ void bn_slab_store(const RowWalk& w, f32x4 s, f32x4 sx, int C, int Ctot, float* __restrict__ slab, float* red) {
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  if (w.active()) {
+    const int c = 4 * w.col;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { atomicAdd(&red[2 * (c + j)], s[j]); atomicAdd(&red[2 * (c + j) + 1], sx[j]); }
+  }
+  __syncthreads();
+  float* dst = slab + (long)blockIdx.x * Ctot * 2;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) dst[i] = red[i];
+}
+
+__global__ __launch_bounds__(256)
+void bn_bwd_partial_kernel(const float* __restrict__ dz, const float* __restrict__ z, const unsigned char* __restrict__ mask,
+                           const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C,
+                           int ld, int rows_per_block, int act, float* __restrict__ slab) {
+  extern __shared__ float red[];
   RowWalk w(C);
   const int c = 4 * w.col;
   f32x4 s = {0, 0, 0, 0}, sx = {0, 0, 0, 0};
@@ -154,134 +192,102 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; is[j] = invstd[c + j]; }
     const long rb = (long)blockIdx.x * rows_per_block;
     long re = rb + rows_per_block; if (re > M) re = M;
-    long r = rb + w.r0;
-    if (act == FS_ACT_NONE || mask != nullptr) {
-      // four rows per trip: all loads of a trip are issued before the first use (a single row per trip keeps only
-      // 32 KB per CU in flight, about half of what the HBM latency needs)
-      const long step = w.rpi;
-      for (; r + 3 * step < re; r += 4 * step) {
-        f32x4 g[4], yy[4];
-        unsigned m[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const long o = (r + u * step) * ld + c;
-          g[u] = *reinterpret_cast<const f32x4*>(dz + o);
-          yy[u] = *reinterpret_cast<const f32x4*>(y + o);
-          m[u] = act != FS_ACT_NONE ? (unsigned)mask[o >> 2] : 0xFu;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) g[u][j] = ((m[u] >> j) & 1u) ? g[u][j] : 0.f;
-          s += g[u]; sx += g[u] * ((yy[u] - mu) * is);
-        }
-      }
+    for (long r = rb + w.r0; r < re; r += w.rpi) {
+      const long o = r * ld + c;
+      const f32x4 g = BnMask::apply(*reinterpret_cast<const f32x4*>(dz + o), mask, z, o, act);
+      s += g; sx += g * ((*reinterpret_cast<const f32x4*>(y + o) - mu) * is);
     }
-    for (; r < re; r += w.rpi) {
-      f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * ld + c);
-      if (act != FS_ACT_NONE) {
-        if (mask != nullptr) {
-          const unsigned m = mask[(r * ld + c) >> 2];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) g[j] = ((m >> j) & 1u) ? g[j] : 0.f;
-        } else {
-          const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * ld + c);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) g[j] *= fs_act_mask(zz[j], act);
-        }
-      }
-      const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + r * ld + c) - mu) * is;
-      s += g; sx += g * xh;
-    }
-    double* p = sm + ((long)w.r0 * C + c) * 2;
-    p[0] = s.x; p[1] = sx.x; p[2] = s.y; p[3] = sx.y; p[4] = s.z; p[5] = sx.z; p[6] = s.w; p[7] = sx.w;
   }
-  __syncthreads();
-  for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
-    double a = 0, b = 0;
-    for (int r = 0; r < w.rpi; ++r) { a += sm[((long)r * C + cc) * 2]; b += sm[((long)r * C + cc) * 2 + 1]; }
-    atomicAdd(&sums[cc], a);
-    atomicAdd(&sums[Ctot + cc], b);
-  }
+  bn_slab_store(w, s, sx, C, ld, slab, red);
 }
 
-// ---- BN backward pass 2: dy (conv-output gradient, dropout applied), dres, dgamma/dbeta -------
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z,
-                                                           const unsigned char* __restrict__ mask,
-                                                           const float* __restrict__ y, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           const double* __restrict__ sums, long M, int C, int ld, int Ctot,
-                                                           int c0, int rows_per_block, int act, int training,
-                                                           float drop_scale, uint32_t drop_thresh,
-                                                           uint32_t drop_key, float* __restrict__ dy, float* __restrict__ dres,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                                           int reverse) {
+// out = a + b [+ c [+ d]]  (the gradient sum at a tensor with several consumers; ops.FanOut) AND, because that tensor is the
+// output z of a conv + BatchNorm + activation layer, the layer's BatchNorm-backward column sums of the freshly formed gradient:
+// the sum is in registers here, so the BatchNorm backward's own reduction pass over (dz, y) -- two of its five tensor passes -- is
+// replaced by one extra read of y in this kernel.  Same row/column walk and slab layout as bn_bwd_partial_kernel.
+__global__ __launch_bounds__(256)
+void add_n_bnsum_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c_, const float* __restrict__ d,
+                        float* __restrict__ out, const unsigned char* __restrict__ mask, const float* __restrict__ y,
+                        const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C, int ld, int rows_per_block, int act,
+                        float* __restrict__ slab) {
+  extern __shared__ float red[];
   RowWalk w(C);
-  if (blockIdx.x == 0 && dgamma != nullptr)
-    for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
-      dbeta[cc] = (accumulate ? dbeta[cc] : 0.f) + (float)sums[cc];
-      dgamma[cc] = (accumulate ? dgamma[cc] : 0.f) + (float)sums[Ctot + cc];
+  const int c = 4 * w.col;
+  f32x4 s = {0, 0, 0, 0}, sx = {0, 0, 0, 0};
+  if (w.active()) {
+    f32x4 mu, is;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; is[j] = invstd[c + j]; }
+    const long rb = (long)blockIdx.x * rows_per_block;
+    long re = rb + rows_per_block; if (re > M) re = M;
+    for (long r = rb + w.r0; r < re; r += w.rpi) {
+      const long o = r * ld + c;
+      f32x4 v = *reinterpret_cast<const f32x4*>(a + o) + *reinterpret_cast<const f32x4*>(b + o);
+      const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+      if (c_ != nullptr) v += *reinterpret_cast<const f32x4*>(c_ + o);
+      if (d != nullptr) v += *reinterpret_cast<const f32x4*>(d + o);
+      *reinterpret_cast<f32x4*>(out + o) = v;
+      const f32x4 g = BnMask::apply(v, mask, nullptr, o, mask != nullptr ? act : FS_ACT_NONE);
+      s += g; sx += g * ((yy - mu) * is);
     }
+  }
+  bn_slab_store(w, s, sx, C, ld, slab, red);
+}
+
+// one block per channel: slab column -> S, SX (double tree) -> dbeta, dgamma and the apply coefficients coef[4][Ctot] = ga, d, mean, bb
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nslab, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd, long M,
+                                                              int C, int training, float* __restrict__ coef, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
+  __shared__ double red[16];
+  const int c = blockIdx.x;
+  double s = 0.0, sx = 0.0;
+  for (int i = threadIdx.x; i < nslab; i += blockDim.x) {
+    const float2 v = *reinterpret_cast<const float2*>(slab + ((long)i * C + c) * 2);
+    s += (double)v.x; sx += (double)v.y;
+  }
+  s = block_sum<double>(s, red);
+  sx = block_sum<double>(sx, red);
+  if (threadIdx.x != 0) return;
+  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sx;
+  const float is = invstd[c], ga = gamma[c] * is;
+  const float mg = training ? (float)(s / (double)M) : 0.f, mgx = training ? (float)(sx / (double)M) : 0.f;
+  coef[c] = ga;
+  coef[C + c] = ga * mgx * is;
+  coef[2 * C + c] = mean[c];
+  coef[3 * C + c] = ga * mg;
+}
+
+__global__ __launch_bounds__(256)
+void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ z, const unsigned char* __restrict__ mask,
+                         const float* __restrict__ y, const float* __restrict__ coef, long M, int C, int ld, int c0, int rows_per_block,
+                         int act, float drop_scale, uint32_t drop_thresh, uint32_t drop_key, float* __restrict__ dy,
+                         float* __restrict__ dres) {
+  RowWalk w(C);
   if (!w.active()) return;
   const int c = 4 * w.col;
-  f32x4 mu, is, ga, mg, mgx;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    mu[j] = mean[c + j]; is[j] = invstd[c + j]; ga[j] = gamma[c + j] * is[j];
-    mg[j] = training ? (float)(sums[c + j] / (double)M) : 0.f;
-    mgx[j] = training ? (float)(sums[Ctot + c + j] / (double)M) : 0.f;
-  }
-  // reverse = 1: workgroups are dispatched in blockIdx order, so the first ones take the LAST rows -- the rows the reduce pass
-  // read last and the 256 MB Infinity Cache most likely still holds (dz + y of a 64-channel 80x80 layer are 210 MB)
-  const long rb = (long)(reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rows_per_block;
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(coef + c0 + c), dd = *reinterpret_cast<const f32x4*>(coef + ld + c0 + c),
+              mu = *reinterpret_cast<const f32x4*>(coef + 2 * ld + c0 + c), bb = *reinterpret_cast<const f32x4*>(coef + 3 * ld + c0 + c);
+  // workgroups are dispatched in blockIdx order: the first ones take the LAST rows -- the rows the pass before read or wrote last and
+  // the 256 MB Infinity Cache most likely still holds (dz + y of a 64-channel 80x80 layer are 210 MB)
+  const long rb = (long)(gridDim.x - 1 - blockIdx.x) * rows_per_block;
   long re = rb + rows_per_block; if (re > M) re = M;
-  auto finish = [&](long r, f32x4 g, const f32x4 yy) {
-    if (dres != nullptr) *reinterpret_cast<f32x4*>(dres + r * ld + c) = g;
-    const f32x4 xh = (yy - mu) * is;
-    f32x4 d = ga * (g - mg - xh * mgx);
+  auto finish = [&](long o, f32x4 g, const f32x4 yy) {
+    if (dres != nullptr) *reinterpret_cast<f32x4*>(dres + o) = g;
+    f32x4 v = ga * g - dd * (yy - mu) - bb;
     if (drop_thresh != 0u) {
-      const uint32_t e = (uint32_t)(r * ld + c0 + c);
+      const uint32_t e = (uint32_t)(o + c0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[j] = fs_dropout_keep(e + j, drop_key, drop_thresh) ? d[j] * drop_scale : 0.f;
+      for (int j = 0; j < 4; ++j) v[j] = fs_dropout_keep(e + j, drop_key, drop_thresh) ? v[j] * drop_scale : 0.f;
     }
-    *reinterpret_cast<f32x4*>(dy + r * ld + c) = d;
+    *reinterpret_cast<f32x4*>(dy + o) = v;
   };
-  long r = rb + w.r0;
-  if (act == FS_ACT_NONE || mask != nullptr) {
-    // two rows per trip, all loads issued before the first use (as in the reduce pass): more bytes in flight per CU
-    const long step = w.rpi;
-    for (; r + step < re; r += 2 * step) {
-      f32x4 g[2], yy[2];
-      unsigned m[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const long o = (r + u * step) * ld + c;
-        g[u] = *reinterpret_cast<const f32x4*>(dz + o);
-        yy[u] = *reinterpret_cast<const f32x4*>(y + o);
-        m[u] = act != FS_ACT_NONE ? (unsigned)mask[o >> 2] : 0xFu;
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) g[u][j] = ((m[u] >> j) & 1u) ? g[u][j] : 0.f;
-        finish(r + u * step, g[u], yy[u]);
-      }
-    }
-  }
-  for (; r < re; r += w.rpi) {
-    f32x4 g = *reinterpret_cast<const f32x4*>(dz + r * ld + c);
-    if (act != FS_ACT_NONE) {
-      if (mask != nullptr) {
-        const unsigned m = mask[(r * ld + c) >> 2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = ((m >> j) & 1u) ? g[j] : 0.f;
-      } else {
-        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * ld + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] *= fs_act_mask(zz[j], act);
-      }
-    }
-    finish(r, g, *reinterpret_cast<const f32x4*>(y + r * ld + c));
+  // one row per trip: 48 VGPRs keep eight of these waves per SIMD (as many bytes in flight as two rows at six) and let a workgroup
+  // fit beside two 230-VGPR convolution waves
+  for (long r = rb + w.r0; r < re; r += w.rpi) {
+    const long o = r * ld + c;
+    finish(o, BnMask::apply(*reinterpret_cast<const f32x4*>(dz + o), mask, z, o, act), *reinterpret_cast<const f32x4*>(y + o));
   }
 }
 
@@ -606,29 +612,72 @@ int fs_bn_act_fwd(const float* y, const float* mean, const float* invstd, const 
   return FS_OK;
 }
 
-// Backward of out = act(bn(y) + res).  training=1: batch statistics (sum terms); 0: running stats.
-// dy = gradient w.r.t. the (dropped-out) conv output, multiplied by the dropout mask when
-// drop_p > 0; dres (nullable) = gradient w.r.t. res; dgamma/dbeta overwritten.
-static const int g_bn_reverse = [] { const char* e = getenv("FS_BN_REVERSE"); return (e && e[0] == '0') ? 0 : 1; }();
+// ---- Backward of out = act(bn(y) + res): partial sums -> finalize -> apply (kernels above) ------------------------------------------
+// Number of slab rows ([.][C][2] floats each) fs_bn_bwd_partial / fs_add_n_bnsum write for an (M, C) activation.
+int fs_bn_bwd_slabs(long M, int C) {
+  if (M <= 0 || C <= 0 || C % 4) return 0;
+  int n = 0;
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    const int Cc = C - c0 < 1024 ? C - c0 : 1024;
+    const int k = cdiv(M, rows_per_block_for(M, Cc));
+    n = k > n ? k : n;
+  }
+  return n;
+}
 
-int fs_bn_act_bwd(const float* dz, const float* z, const unsigned char* mask, const float* y, const float* mean, const float* invstd,
-                  const float* gamma, long M, int C, int act, int training, float drop_p, uint32_t drop_key, float* dy,
-                  float* dres, float* dgamma, float* dbeta, double* sums, int accumulate_affine, hipStream_t stream) {
-  FS_REQUIRE(dz && y && mean && invstd && gamma && dy && dgamma && dbeta && sums && M > 0 && C % 4 == 0);
+int fs_bn_bwd_partial(const float* dz, const float* z, const unsigned char* mask, const float* y, const float* mean, const float* invstd,
+                      long M, int C, int act, float* slab, hipStream_t stream) {
+  FS_REQUIRE(dz && y && mean && invstd && slab && M > 0 && C > 0 && C % 4 == 0);
   FS_REQUIRE(act == FS_ACT_NONE || z != nullptr || mask != nullptr);
-  hipError_t e = hipMemsetAsync(sums, 0, 2 * C * sizeof(double), stream);
-  if (e != hipSuccess) return (int)e;
+  const int nslab = fs_bn_bwd_slabs(M, C);
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    const int Cc = C - c0 < 1024 ? C - c0 : 1024;
+    const int rpb = rows_per_block_for(M, Cc);
+    // every launch writes all nslab rows of its channel window (blocks past the last row write zeros)
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nslab), dim3(256), 2 * Cc * sizeof(float), stream, dz + c0, z ? z + c0 : nullptr,
+                       mask ? mask + c0 / 4 : nullptr, y + c0, mean + c0, invstd + c0, M, Cc, C, rpb, act, slab + 2 * c0);
+    FS_LAUNCH_CHECK();
+  }
+  return FS_OK;
+}
+
+int fs_add_n_bnsum(const float* a, const float* b, const float* c, const float* d, float* out, const unsigned char* mask, const float* y,
+                   const float* mean, const float* invstd, long M, int C, int act, float* slab, hipStream_t stream) {
+  FS_REQUIRE(a && b && out && y && mean && invstd && slab && M > 0 && C > 0 && C % 4 == 0 && (d == nullptr || c != nullptr));
+  FS_REQUIRE(act == FS_ACT_NONE || mask != nullptr);
+  const int nslab = fs_bn_bwd_slabs(M, C);
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    const int Cc = C - c0 < 1024 ? C - c0 : 1024;
+    const int rpb = rows_per_block_for(M, Cc);
+    hipLaunchKernelGGL(add_n_bnsum_kernel, dim3(nslab), dim3(256), 2 * Cc * sizeof(float), stream, a + c0, b + c0, c ? c + c0 : nullptr,
+                       d ? d + c0 : nullptr, out + c0, mask ? mask + c0 / 4 : nullptr, y + c0, mean + c0, invstd + c0, M, Cc, C, rpb, act,
+                       slab + 2 * c0);
+    FS_LAUNCH_CHECK();
+  }
+  return FS_OK;
+}
+
+int fs_bn_bwd_finalize(const float* slab, int nslab, const float* gamma, const float* mean, const float* invstd, long M, int C,
+                       int training, float* coef, float* dgamma, float* dbeta, int accumulate_affine, hipStream_t stream) {
+  FS_REQUIRE(slab && nslab > 0 && gamma && mean && invstd && coef && dgamma && dbeta && M > 0 && C > 0);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, stream, slab, nslab, gamma, mean, invstd, M, C, training, coef, dgamma,
+                     dbeta, accumulate_affine);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_bn_bwd_apply(const float* dz, const float* z, const unsigned char* mask, const float* y, const float* coef, long M, int C, int act,
+                    float drop_p, uint32_t drop_key, float* dy, float* dres, hipStream_t stream) {
+  FS_REQUIRE(dz && y && coef && dy && M > 0 && C > 0 && C % 4 == 0);
+  FS_REQUIRE(act == FS_ACT_NONE || z != nullptr || mask != nullptr);
   float scale = 1.f; uint32_t thresh = 0u;
   if (drop_p > 0.f) { scale = 1.0f / (float)(1.0 - (double)drop_p); thresh = (uint32_t)((double)drop_p * 4294967296.0); }
   for (int c0 = 0; c0 < C; c0 += 1024) {
     const int Cc = C - c0 < 1024 ? C - c0 : 1024;
     const int rpb = rows_per_block_for(M, Cc);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(M, rpb)), dim3(256), stats_smem(Cc), stream, dz + c0, z ? z + c0 : nullptr,
-                       mask ? mask + c0 / 4 : nullptr, y + c0, mean + c0, invstd + c0, M, Cc, C, C, rpb, act, sums + c0);
-    FS_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, stream, dz + c0, z ? z + c0 : nullptr,
-                       mask ? mask + c0 / 4 : nullptr, y + c0, mean + c0, invstd + c0, gamma + c0, sums + c0, M, Cc, C, C, c0, rpb, act, training, scale, thresh, drop_key,
-                       dy + c0, dres ? dres + c0 : nullptr, dgamma + c0, dbeta + c0, accumulate_affine, g_bn_reverse);
+                       mask ? mask + c0 / 4 : nullptr, y + c0, coef, M, Cc, C, c0, rpb, act, scale, thresh, drop_key, dy + c0,
+                       dres ? dres + c0 : nullptr);
     FS_LAUNCH_CHECK();
   }
   return FS_OK;

@@ -43,7 +43,10 @@ SIGNATURES = {
     "fs_bn_finalize_slab": "piliffpppp",
     "fs_bn_eval_prepare": "ppifpp",
     "fs_bn_act_fwd": "pppppppplii",
-    "fs_bn_act_bwd": "pppppppliiifupppppi",
+    "fs_bn_bwd_partial": "ppppppliip",
+    "fs_add_n_bnsum": "pppppppppliip",
+    "fs_bn_bwd_finalize": "pippplii" + "pppi",
+    "fs_bn_bwd_apply": "ppppp" + "lii" + "fu" + "pp",
     "fs_hr_fuse_fwd": "pppipiiiii",
     "fs_relu_bwd": "pppl",
     "fs_add_n": "pppppl",
@@ -76,7 +79,8 @@ _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 
 _lib = None
 # declared in the header, host-side only (no stream argument)
-HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice")
+HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice",
+             "fs_bn_bwd_slabs")
 
 
 class HipLibraryError(RuntimeError):
@@ -107,8 +111,22 @@ def load():
     lib.fs_conv2d_stats_slabs.argtypes = [_I] * 12 + [_L]
     lib.fs_conv2d_kernel_choice.restype = _I
     lib.fs_conv2d_kernel_choice.argtypes = [_I] * 13 + [_L]
+    lib.fs_bn_bwd_slabs.restype = _I
+    lib.fs_bn_bwd_slabs.argtypes = [_L, _I]
     _lib = lib
+    global _default_mode
+    _default_mode = ("f32", "bf16x3", "f16x2")[lib.fs_get_conv_precision()]
     return lib
+
+
+_default_mode = None
+
+
+def default_conv_precision() -> str:
+    """The mode the library came up in: 'bf16x3' (24-bit operands, the reference's fp32 operand width) unless FS_CONV_PRECISION
+    named another one before the library was loaded."""
+    load()
+    return _default_mode
 
 
 def set_conv_precision(mode: str) -> None:
@@ -138,6 +156,15 @@ def conv_stats_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_byte
     v = _ws_cache.get(key)
     if v is None:
         v = _ws_cache[key] = int(load().fs_conv2d_stats_slabs(*key[1:]))
+    return v
+
+
+def bn_bwd_slabs(M, C):
+    """Rows of the [.][C][2] partial-sum slab the BatchNorm-backward producers write for an (M, C) activation (cached)."""
+    key = ("bnslab", M, C)
+    v = _ws_cache.get(key)
+    if v is None:
+        v = _ws_cache[key] = int(load().fs_bn_bwd_slabs(M, C))
     return v
 
 

@@ -164,6 +164,7 @@ def _conv_workspace(device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, tra
 
 
 FUSE_BN_STATS = True     # BatchNorm batch statistics come out of the conv epilogue (fs_conv2d_fwd_stats)
+FUSE_BN_BWD_SUMS = True  # BatchNorm-backward column sums come out of the kernel that produces the gradient, where one does (FanOut)
 
 
 def conv2d_fwd_stats(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1, w_amax=None):
@@ -200,12 +201,26 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1, w_amax=None):
 # no process-wide mode: a parameter outside any arena, or whose `.grad` was re-pointed (module.zero_grad() -> None -> a fresh
 # tensor), takes the ordinary autograd path.  The arena is zeroed once per step (optimizer.zero_grad), so repeated backwards
 # accumulate exactly like `.grad`.  DIRECT_GRAD = False (or FS_DIRECT_GRAD=0) switches the direct path off altogether.
+#
+# torch's DistributedDataParallel (the reference's call site, train_deform_semantic.py:395) learns that a gradient is ready from a
+# hook on the parameter's AccumulateGrad node, which a kernel that adds straight into the arena never fires.  A forward that runs
+# inside a DDP wrapper therefore suspends the direct path for itself and its backward (models.DeformSegmentationModule.forward
+# -> under_torch_ddp): gradients are returned to autograd, AccumulateGrad adds them into the same arena views in place, the
+# reducer sees every one of them.
 DIRECT_GRAD = os.environ.get("FS_DIRECT_GRAD", "1") != "0"
+DDP_ACTIVE = False       # set per forward by models.DeformSegmentationModule.forward
+
+
+def under_torch_ddp(module) -> bool:
+    """True while `module.forward` is being run by a torch DistributedDataParallel wrapper around `module`."""
+    ddp_cls = torch.nn.parallel.DistributedDataParallel
+    active = getattr(ddp_cls, "_active_ddp_module", None)
+    return active is not None and getattr(active, "module", None) is module
 
 
 def _direct_grad_target(p):
     home = getattr(p, "_fs_grad_home", None)
-    if not DIRECT_GRAD or home is None or not p.is_leaf:
+    if not DIRECT_GRAD or DDP_ACTIVE or home is None or not p.is_leaf:
         return None
     g = p.grad
     if g is not None and g.is_cuda and g.data_ptr() == home[0].data_ptr() + 4 * home[1] and g.shape == p.shape and g.stride() == p.stride():
@@ -276,12 +291,21 @@ def pad_in_channels(x, w):
 FANOUT = os.environ.get("FS_FANOUT", "1") != "0"
 
 
+# BatchNorm-backward column sums that the PRODUCER of a gradient tensor already formed (FanOut.backward below):
+# dz.data_ptr() -> (slab, nslab, dz).  The entry keeps dz alive, so its address cannot be reused while the entry exists;
+# ConvBnAct.backward pops it.  Cleared at the start of every module forward.
+BN_SLABS = {}
+
+
 class FanOut(Function):
     """x -> n aliases of x, one per consumer.  Backward: ONE n-ary HIP add of the consumers' gradients (fs_add_n, up to four at a
-    time) instead of the n - 1 binary ATen adds the autograd engine would issue -- the last ATen compute kernel inside the step."""
+    time) instead of the n - 1 binary ATen adds the autograd engine would issue -- the last ATen compute kernel inside the step.
+    When x is the output of a conv + BatchNorm + activation layer (ConvBnAct tags it with `_fs_bn`), the last add also forms that
+    layer's BatchNorm-backward column sums (fs_add_n_bnsum): the layer's own reduction pass over (dz, y) is then skipped."""
 
     @staticmethod
     def forward(ctx, x, n):
+        ctx.bn = getattr(x, "_fs_bn", None)
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
@@ -295,11 +319,23 @@ class FanOut(Function):
             for g in rest:
                 acc = acc + g
             return acc, None
+        bn = ctx.bn if FUSE_BN_BWD_SUMS else None
         while rest:
             take, rest = rest[:3], rest[3:]
             out = torch.empty_like(acc)
-            hip.call("fs_add_n", hip.ptr(acc), hip.ptr(take[0]), hip.ptr(take[1]) if len(take) > 1 else None,
-                     hip.ptr(take[2]) if len(take) > 2 else None, hip.ptr(out), acc.numel())
+            if bn is not None and not rest and acc.dim() == 4 and acc.shape[-1] % 4 == 0 and acc.shape == bn[0].shape:
+                y, amask, mean, invstd, act = bn
+                C = acc.shape[-1]
+                M = acc.numel() // C
+                nslab = hip.bn_bwd_slabs(M, C)
+                slab = torch.empty(nslab * C * 2, device=acc.device, dtype=torch.float32)
+                hip.call("fs_add_n_bnsum", hip.ptr(acc), hip.ptr(take[0]), hip.ptr(take[1]) if len(take) > 1 else None,
+                         hip.ptr(take[2]) if len(take) > 2 else None, hip.ptr(out), hip.ptr(amask), hip.ptr(y), hip.ptr(mean),
+                         hip.ptr(invstd), M, C, act if amask is not None else ACT_NONE, hip.ptr(slab))
+                BN_SLABS[out.data_ptr()] = (slab, nslab, out)
+            else:
+                hip.call("fs_add_n", hip.ptr(acc), hip.ptr(take[0]), hip.ptr(take[1]) if len(take) > 1 else None,
+                         hip.ptr(take[2]) if len(take) > 2 else None, hip.ptr(out), acc.numel())
             acc = out
         return acc, None
 
@@ -334,6 +370,11 @@ class FanOutSubsample(Function):
         if g_sub is not None:
             g_full[:, ::s, ::s, :].add_(g_sub)
         return g_full, None
+
+
+def act_has_bwd(act, amask):
+    """The activation derivative is available to another kernel: no activation, or the 1-byte masks were written."""
+    return act == ACT_NONE or amask is not None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -384,6 +425,8 @@ class ConvBnAct(Function):
         ctx.save_for_backward(x, w, gamma, y, z if amask is None else None, mean, invstd, amask)
         ctx.beta_ref = beta
         ctx.w_amax = wa          # the weights do not change between this forward and its backward
+        if act_has_bwd(meta["act"], amask):
+            z._fs_bn = (y, amask, mean, invstd, meta["act"])     # for the producer of dz (FanOut.backward): this layer's BN-backward operands
         return z
 
     @staticmethod
@@ -399,11 +442,23 @@ class ConvBnAct(Function):
         direct_affine = tg is not None and tb is not None
         dgamma = tg if direct_affine else torch.empty(C, device=y.device, dtype=torch.float32)
         dbeta = tb if direct_affine else torch.empty(C, device=y.device, dtype=torch.float32)
-        sums = torch.empty(2 * C, device=y.device, dtype=torch.float64)
+        # BatchNorm backward = column sums (unless the kernel that produced dz already formed them) -> finalize -> apply
+        pre = BN_SLABS.pop(dz.data_ptr(), None)
+        if pre is not None and pre[2].shape == dz.shape:
+            slab, nslab = pre[0], pre[1]
+            slab.record_stream(torch.cuda.current_stream())
+        else:
+            nslab = hip.bn_bwd_slabs(M, C)
+            slab = torch.empty(nslab * C * 2, device=y.device, dtype=torch.float32)
+            _launch("bn_bwd", 0.0, "fs_bn_bwd_partial", hip.ptr(dz), hip.ptr(z), hip.ptr(amask), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd),
+                    M, C, m["act"], hip.ptr(slab))
+        coef = torch.empty(4 * C, device=y.device, dtype=torch.float32)
+        _launch("bn_bwd", 0.0, "fs_bn_bwd_finalize", hip.ptr(slab), nslab, hip.ptr(gamma), hip.ptr(mean), hip.ptr(invstd), M, C,
+                1 if m["training"] else 0, hip.ptr(coef), hip.ptr(dgamma), hip.ptr(dbeta), 1 if direct_affine else 0)
+        # timer "work" of the three launches together = algorithmic bytes: dz, y and the mask read once, dy [and dres] written once
         _launch("bn_bwd", 4.0 * M * C * (3 + m["has_res"]) + (M * C // 4 if amask is not None else 0),
-                "fs_bn_act_bwd", hip.ptr(dz), hip.ptr(z), hip.ptr(amask), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), M, C,
-                m["act"], 1 if m["training"] else 0, float(m["drop_p"]), int(m["drop_key"]), hip.ptr(dy), hip.ptr(dres),
-                hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums), 1 if direct_affine else 0)
+                "fs_bn_bwd_apply", hip.ptr(dz), hip.ptr(z), hip.ptr(amask), hip.ptr(y), hip.ptr(coef), M, C, m["act"], float(m["drop_p"]),
+                int(m["drop_key"]), hip.ptr(dy), hip.ptr(dres))
         tgt = _direct_grad_target(w)
         if not WGRAD_FIRST:
             dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax) if ctx.needs_input_grad[0] else None

@@ -203,9 +203,19 @@ def ddp_setup(backend=None):
     return rank, local_rank, world
 
 
+def _collectives_on():
+    """A process group is up.  A group of ONE rank still runs its collectives (they are cheap no-op exchanges): the same
+    code path -- device binding, RCCL's stream hand-off behind the side-stream backward -- is then exercised on a single GPU."""
+    return dist.is_available() and dist.is_initialized()
+
+
+def _is_torch_ddp(module):
+    return module is not None and isinstance(module, torch.nn.parallel.DistributedDataParallel)
+
+
 def broadcast_parameters(optimizers, module=None, src=0):
     """DDP construction-time broadcast (train_deform_semantic.py:395): one collective per arena."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return
     for opt in optimizers:
         dist.broadcast(opt.flat.data, src=src)
@@ -238,7 +248,7 @@ def broadcast_buffers(module, src=0):
     """DDP(broadcast_buffers=True) semantics (train_deform_semantic.py:395; torch DDP syncs module buffers from rank 0 at the start of
     every training forward): after this call every rank holds rank 0's BatchNorm running statistics.  One collective over the
     module's flat buffer arena (built on first use)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return
     flat = getattr(module, "_fs_flat_buffers", None)
     if flat is None:
@@ -247,9 +257,11 @@ def broadcast_buffers(module, src=0):
     dist.broadcast(flat.data, src=src)
 
 
-def allreduce_gradients(optimizers):
-    """Gradient average across ranks: one SUM all-reduce per arena; the 1/world is folded into Adam."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def allreduce_gradients(optimizers, module=None):
+    """Gradient average across ranks: one SUM all-reduce per arena; the 1/world is folded into Adam.
+    `module` wrapped by torch's DistributedDataParallel (the reference's call site, train_deform_semantic.py:395): its reducer has
+    already averaged the gradients into the arena views during backward, so nothing is exchanged here."""
+    if not _collectives_on() or _is_torch_ddp(module):
         for opt in optimizers:
             opt.grad_scale = 1.0
         return
@@ -281,11 +293,19 @@ def train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=0):
         opt.zero_grad()
     adjust_learning_rate(optimizers, cur_iter, cfg, epoch=epoch)
     DropoutState.step += 1
-    broadcast_buffers(module)          # no-op on one rank; DDP syncs buffers from rank 0 before every training forward
+    ddp = _is_torch_ddp(module)
+    inner = module.module if ddp else module
+    if not ddp:
+        broadcast_buffers(module)      # no-op without a process group; torch DDP syncs buffers from rank 0 itself before every forward
     out = module(feed, epoch=epoch, cur_iter=cur_iter)
     loss = out[0]
     loss.mean().backward()
-    allreduce_gradients(optimizers)
+    # models/models.py:721 asserts on NaN saliency in the middle of the forward, i.e. BEFORE any update; the deferred flag is read
+    # here, after backward (the saliency forward finished long ago: no stall) and before the gradient exchange and the optimiser
+    # steps, so a caller that catches the AssertionError still holds the parameters and Adam moments of the previous step
+    if hasattr(inner, "check_nan"):
+        inner.check_nan()
+    allreduce_gradients(optimizers, module)
     T = cfg.TRAIN
     for opt in optimizers:          # train_deform_semantic.py:112-120: which optimisers step in this epoch
         zoom = opt.param_groups[0]["zoom"]
@@ -296,8 +316,6 @@ def train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=0):
             if not zoom:            # segmentation module frozen
                 continue
         opt.step()
-    if hasattr(module, "check_nan"):
-        module.check_nan()          # the forward's deferred NaN assertion (models.DeformSegmentationModule._note_nan)
     return out
 
 

@@ -147,11 +147,20 @@ int fs_bn_eval_prepare(const float* running_mean, const float* running_var, int 
  * backward passes read one byte instead of four floats of `out`.  models/hrnetv2_nodownsp.py:51-52,56-62. */
 int fs_bn_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* res,
                   float* out, unsigned char* mask, long M, int C, int act, fs_stream_t stream);
-/* Backward of the above; the activation derivative comes from `mask` when given, else from z (= out).
- * accumulate_affine != 0: dgamma / dbeta are ADDED to (gradient-arena targets, like fs_conv2d_bwd_weight's accumulate), else overwritten. */
-int fs_bn_act_bwd(const float* dz, const float* z, const unsigned char* mask, const float* y, const float* mean, const float* invstd, const float* gamma,
-                  long M, int C, int act, int training, float drop_p, uint32_t drop_key, float* dy, float* dres, float* dgamma,
-                  float* dbeta, double* sums, int accumulate_affine, fs_stream_t stream);
+/* Backward of the above (F.batch_norm backward + activation + dropout mask of the conv output; models/hrnetv2_nodownsp.py:46-62,
+ * lib/nn/modules/batchnorm.py:56-61) in three stages; the activation derivative comes from `mask` when given, else from z (= out):
+ *   fs_bn_bwd_partial : column sums sum(g), sum(g * xhat) of g = dz * act'(z) per block of rows -> slab[fs_bn_bwd_slabs(M, C)][C][2].
+ *                       Skipped when the kernel that produced dz wrote the slab itself (fs_add_n_bnsum).
+ *   fs_bn_bwd_finalize: slab -> dgamma, dbeta (accumulate_affine != 0: ADDED to gradient-arena targets, else overwritten) and the
+ *                       per-channel coefficients coef[4][C] of the apply pass (training = 0: running statistics, no mean terms).
+ *   fs_bn_bwd_apply   : dy = gradient w.r.t. the (dropped-out) conv output, dres (nullable) = gradient w.r.t. the residual input. */
+int fs_bn_bwd_slabs(long M, int C);      /* host only */
+int fs_bn_bwd_partial(const float* dz, const float* z, const unsigned char* mask, const float* y, const float* mean, const float* invstd,
+                      long M, int C, int act, float* slab, fs_stream_t stream);
+int fs_bn_bwd_finalize(const float* slab, int nslab, const float* gamma, const float* mean, const float* invstd, long M, int C,
+                       int training, float* coef, float* dgamma, float* dbeta, int accumulate_affine, fs_stream_t stream);
+int fs_bn_bwd_apply(const float* dz, const float* z, const unsigned char* mask, const float* y, const float* coef, long M, int C, int act,
+                    float drop_p, uint32_t drop_key, float* dy, float* dres, fs_stream_t stream);
 
 /* ---- HRNet multi-resolution fuse / concat ------------------------------------------------------ */
 /* out = [relu](sum_t up(terms[t])), terms at (th[t],tw[t]) bilinearly up-sampled (align_corners=False).
@@ -163,6 +172,11 @@ int fs_relu_bwd(const float* dout, const float* out, float* g, long n, fs_stream
  * with several consumers -- the block input of models/hrnetv2_nodownsp.py:46-64 (conv path + residual), the branch outputs every
  * fuse row reads (:228-252) -- which the autograd engine would otherwise form with ATen's binary add, one launch per extra consumer. */
 int fs_add_n(const float* a, const float* b, const float* c, const float* d, float* out, long n, fs_stream_t stream);
+/* The same sum where `out` is the gradient of a conv + BatchNorm + activation layer's output (autograd's add at the BasicBlock
+ * output, models/hrnetv2_nodownsp.py:59-62): also writes that layer's BatchNorm-backward partial sums (fs_bn_bwd_partial's slab),
+ * so the layer's own reduction pass is skipped.  mask / y / mean / invstd: the layer's forward record; M rows of C channels. */
+int fs_add_n_bnsum(const float* a, const float* b, const float* c, const float* d, float* out, const unsigned char* mask, const float* y,
+                   const float* mean, const float* invstd, long M, int C, int act, float* slab, fs_stream_t stream);
 /* dst[..., coff:coff+C] = up(src); models/hrnetv2_nodownsp.py:434-442 (interpolate + cat). */
 int fs_upsample_slice_fwd(const float* src, int B, int th, int tw, int C, float* dst, int Ho, int Wo, int Cdst, int coff,
                           fs_stream_t stream);

@@ -206,3 +206,123 @@ def test_two_rank_train_step_on_gpu():
         assert all(m > 0 for m in r["moved"][:2])                       # encoder and decoder parameters stepped
     assert a["digest"] == b["digest"]                                    # replicas stay bit-identical after the step
     assert a["loss_own"] != b["loss_own"]                                # different shards per rank
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The reference's own wrapper line (train_deform_semantic.py:395): DistributedDataParallel(module, device_ids=[rank],
+# find_unused_parameters=True).  torch's reducer hooks AccumulateGrad, so a forward that runs inside the wrapper routes weight
+# and BatchNorm-affine gradients through autograd instead of adding them into the arena directly (ops.DDP_ACTIVE); the reducer
+# must then average EVERY parameter's gradient into the same arena views that `allreduce_gradients` produces on its own.
+# ----------------------------------------------------------------------------------------------------------------
+def _gpu_torch_ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import fovealseg
+    from fovealseg import ops
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    train.ddp_setup(backend="gloo")
+    dev = torch.device("cuda", 0)
+    cfg = fovealseg.lvis50_cfg()
+    torch.manual_seed(5 + rank)
+    module, nets = train.build_module(cfg, device=dev, init="random" if rank else "name_keyed")     # rank 1 starts elsewhere
+    module.train()
+    optimizers = train.create_optimizers(nets, cfg)
+    train.broadcast_parameters(optimizers, module)
+    batch = train.synthetic_batch(2, 256, 256, seed=11 + rank, device=dev)
+    X, Fp, Y, cls = batch
+
+    def fwd_bwd(m):
+        for opt in optimizers:
+            opt.zero_grad()
+        ops.DropoutState.seed, ops.DropoutState.step = 77 + rank, 1
+        feed = {"img_data": X[:, :3], "seg_label": Y, "focus_point": Fp, "cls_label": cls}
+        loss = m(feed, epoch=1, cur_iter=0)[0]
+        loss.mean().backward()
+        return float(loss)
+    # (a) this repo's explicit exchange on the bare module
+    loss_a = fwd_bwd(module)
+    assert ops.DDP_ACTIVE is False
+    train.allreduce_gradients(optimizers)
+    want = [o.flat.grad * o.grad_scale for o in optimizers]
+    # (b) the reference's line, unchanged (device_ids=[rank] on a one-GPU-per-rank node; both ranks share cuda:0 here)
+    ddp = DDP(module, device_ids=[0], find_unused_parameters=True)
+    loss_b = fwd_bwd(ddp)
+    assert ops.DDP_ACTIVE is True                 # the forward saw the wrapper
+    torch.cuda.synchronize()
+    errs = []
+    for o, w in zip(optimizers, want):
+        o.check_grads_in_arena()                  # the reducer wrote INTO the arena views, .grad was never re-pointed
+        errs.append(float((o.flat.grad - w).norm() / w.norm().clamp_min(1e-30)))
+    # a whole train_step through the wrapper: no second exchange, Adam sees grad_scale 1, replicas stay identical
+    ops.DropoutState.step = 0
+    p_before = [o.flat.data.clone() for o in optimizers]
+    train.train_step(ddp, optimizers, batch, cfg, epoch=1, cur_iter=0)
+    torch.cuda.synchronize()
+    moved = [float((o.flat.data - p0).abs().max()) for o, p0 in zip(optimizers, p_before)]
+    out[rank] = dict(errs=errs, loss_a=loss_a, loss_b=loss_b, scales=[o.grad_scale for o in optimizers], moved=moved,
+                     digest=[float(o.flat.data.double().sum()) for o in optimizers])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_reference_ddp_wrapper_line_on_gpu():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gpu_torch_ddp_worker, args=(world, port, out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    for r in (a, b):
+        assert max(r["errs"]) <= 1e-5, r["errs"]             # reducer average == explicit arena all-reduce x 1/world (float atomics: 1e-5)
+        assert abs(r["loss_a"] - r["loss_b"]) <= 1e-5 * max(1.0, abs(r["loss_a"]))
+        assert r["scales"] == [1.0] * 4                      # DDP already averaged: nothing folded into Adam
+        assert all(m > 0 for m in r["moved"][:2])
+    assert a["digest"] == b["digest"]                        # replicas bit-identical after the optimiser step
+
+
+@pytest.mark.gpu
+def test_train_step_through_one_rank_rccl_group():
+    """VERDICT r2 #6b: with a process group of ONE rank on the nccl (= RCCL) backend the step takes the same code path as N > 1 --
+    communicator bound to the device (`device_id`), buffer broadcast before the forward, one all-reduce per arena after a
+    backward that ran on four side streams -- and must give the step it gives without a group."""
+    import fovealseg
+    from fovealseg import ops
+    assert not dist.is_initialized()
+    dev = torch.device("cuda", 0)
+    cfg = fovealseg.lvis50_cfg()
+    batch = train.synthetic_batch(4, 256, 256, seed=3, device=dev)
+
+    def run(group):
+        module, nets = train.build_module(cfg, device=dev)
+        module.train()
+        optimizers = train.create_optimizers(nets, cfg)
+        if group:
+            train.broadcast_parameters(optimizers, module)
+            assert getattr(module, "_fs_flat_buffers", None) is not None      # the buffer arena exists: the broadcast really ran
+        ops.DropoutState.seed, ops.DropoutState.step = 9, 0
+        losses = []
+        for it in range(2):
+            o = train.train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=it)
+            losses.append(float(o[0]))
+        torch.cuda.synchronize()
+        return losses, [op.flat.data.clone() for op in optimizers], [op.grad_scale for op in optimizers]
+    base_losses, base_params, _ = run(group=False)
+    saved = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    try:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+        assert train._collectives_on() and dist.get_backend() == "nccl"
+        losses, params, scales = run(group=True)
+        dist.barrier()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert scales == [1.0] * 4
+    for a, b in zip(base_losses, losses):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (base_losses, losses)       # bwd-weight float atomics reorder: not bit-identical
+    for p0, p1 in zip(base_params, params):
+        assert float((p0 - p1).abs().max()) <= 1e-4 * float(p0.abs().max())

@@ -101,7 +101,7 @@ class traced:
 def prec(request):
     fovealseg.hip.set_conv_precision(request.param)
     yield request.param
-    fovealseg.hip.set_conv_precision("f16x2")
+    fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -245,7 +245,7 @@ def test_split_precision_range_properties(mode, shape):
         yn = ops.conv2d_fwd(xn, wd, None, s, 1)
         assert not torch.isfinite(yn[0]).all() and torch.isfinite(yn[1:]).all()
     finally:
-        fovealseg.hip.set_conv_precision("f16x2")
+        fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
 
 
 def test_maxpool_and_dropout():
@@ -994,7 +994,7 @@ def test_full_depth_b64_modes(hipmod, oracle, mode, hw):
         assert err_logit <= FULL_DEPTH_LOGIT_TOL, err_logit
         assert worst[0][1] <= FULL_DEPTH_GRAD_TOL, worst
     finally:
-        fovealseg.hip.set_conv_precision("f16x2")
+        fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
         _set_drop(hipmod, 0.3)
         hipmod.zero_grad(set_to_none=True)
         _restore(hipmod)
@@ -1526,7 +1526,7 @@ def test_config2_hrnet_640_per_gpu_shape():
         finally:
             pass          # (round 1 reset a process-global here; the direct-gradient decision is per parameter now)
     finally:
-        fovealseg.hip.set_conv_precision("f16x2")
+        fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
 
 
 def test_dice_known_answers_unpinned_toolbelt():
@@ -1626,4 +1626,60 @@ def test_winograd_row_kernel(case):
         if mode == "bf16x3":
             assert torch.equal(ops.conv2d_bwd_data(dyd * 2.0 ** 20, wd, xd.shape, 1, 1), dx * 2.0 ** 20)
     finally:
-        fovealseg.hip.set_conv_precision("f16x2")
+        fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
+
+
+@pytest.mark.parametrize("C,hw,act_last", [(64, 20, True), (24, 9, False), (256, 6, True)])
+def test_bn_backward_sums_from_the_gradient_producer(C, hw, act_last):
+    """Round 3: where the gradient of a conv + BatchNorm + activation output is formed by ops.FanOut's n-ary add, that add also writes
+    the layer's BatchNorm-backward column sums (fs_add_n_bnsum) and the layer's own reduction pass (fs_bn_bwd_partial) is skipped.
+    Both routes must give the same gradients: two residual blocks back to back (block output -> FanOut -> next conv + residual),
+    train mode, dropout on; the unfused route is the one test_conv_bn_act / G7 pin to the reference."""
+    from fovealseg import modules as Mods
+    torch.manual_seed(C + hw)
+    blocks = [Mods.BasicBlock(C).to(DEV) for _ in range(2)]
+    for i, b in enumerate(blocks):
+        b._path = f"t.{i}"
+        b.train()
+        with torch.no_grad():
+            for bn in (b.bn1, b.bn2):
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.normal_(0.0, 0.3)
+    x0 = torch.randn(3, hw, hw, C, device=DEV)
+    cot = torch.randn(3, hw, hw, C, device=DEV)
+    ops.DropoutState.seed, ops.DropoutState.step = 11, 3
+
+    def run(fused):
+        ops.FUSE_BN_BWD_SUMS = fused
+        ops.BN_SLABS.clear()
+        for b in blocks:
+            b.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        h = blocks[0](x)
+        xa, xb = ops.fan_out(blocks[1](h), 2)                   # the LAST block's output feeds two consumers as well
+        out = (xa * cot).sum() + (xb * xb).sum() * 0.5
+        calls = []
+        orig = fovealseg.hip.call
+
+        def spy(name, *a):
+            calls.append(name)
+            return orig(name, *a)
+        fovealseg.hip.call = spy
+        try:
+            out.backward()
+        finally:
+            fovealseg.hip.call = orig
+        grads = [x.grad.clone()] + [p.grad.clone() for b in blocks for p in b.parameters()]
+        return grads, calls
+    try:
+        g_fused, calls_fused = run(True)
+        g_plain, calls_plain = run(False)
+    finally:
+        ops.FUSE_BN_BWD_SUMS = True
+    # 4 BatchNorm layers; bn2 of both blocks receives its gradient from a FanOut add -> 2 fused sums, 2 reduction passes left
+    assert calls_plain.count("fs_bn_bwd_partial") == 4 and calls_plain.count("fs_add_n_bnsum") == 0
+    assert calls_fused.count("fs_add_n_bnsum") == 2 and calls_fused.count("fs_bn_bwd_partial") == 2
+    assert not ops.BN_SLABS                                         # every slab was consumed
+    for a, b in zip(g_fused, g_plain):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-5 * scale          # same sums, different summation order (and bwd-weight atomics)

@@ -377,7 +377,7 @@ def test_train_step_skips_frozen_optimisers(monkeypatch):
 
         def backward(self):
             pass
-    monkeypatch.setattr(train, "allreduce_gradients", lambda opts: None)
+    monkeypatch.setattr(train, "allreduce_gradients", lambda opts, module=None: None)
     opts = [Opt(False), Opt(False), Opt(True), Opt(True)]
     module = lambda feed, epoch=None, cur_iter=None: (Loss(), None, None)       # noqa: E731
     batch = (torch.zeros(1, 4, 2, 2), None, None, None)

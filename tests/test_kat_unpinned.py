@@ -156,7 +156,7 @@ def test_deeplab_hip_known_answers_unpinned():
         try:
             got = ops.conv2d_fwd(xd, wd, None, 1, 2, dil=2)[0, :, :, 2].cpu().numpy()
         finally:
-            fovealseg.hip.set_conv_precision("f16x2")
+            fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
         assert np.abs(got - want).max() == 0.0, mode                # small integers: exact in every mode
     m = D.deeplab().to("cuda").eval()
     pool = m.deeplab.classifier[0].convs[4]

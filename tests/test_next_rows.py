@@ -452,6 +452,22 @@ def test_nan_assertion_is_deferred_not_dropped():
     with pytest.raises(AssertionError, match="xs contains NaN values!"):
         train.eval_step(module, bad)
     train.eval_step(module, good)                        # the flag does not stick
+    # a training step on the bad batch raises BEFORE the gradient exchange and the optimiser steps (the reference asserts mid-forward,
+    # models/models.py:721): parameters, Adam moments and step counts are those of the previous step
+    module.train()
+    opts = train.create_optimizers(nets, cfg)
+    train.train_step(module, opts, good, cfg, epoch=1, cur_iter=0)
+    torch.cuda.synchronize()
+    before = [(o.flat.data.clone(), o.m.clone(), o.v.clone(), o.t) for o in opts]
+    with pytest.raises(AssertionError, match="xs contains NaN values!"):
+        train.train_step(module, opts, bad, cfg, epoch=1, cur_iter=1)
+    torch.cuda.synchronize()
+    for o, (d, m, v, t) in zip(opts, before):
+        assert torch.equal(o.flat.data, d) and torch.equal(o.m, m) and torch.equal(o.v, v) and o.t == t
+        assert torch.isfinite(o.flat.data).all()
+    train.train_step(module, opts, good, cfg, epoch=1, cur_iter=1)          # and the run continues
+    assert all(bool(torch.isfinite(o.flat.data).all()) for o in opts)
+    module.eval()
     # direct forward calls: the assertion of call k is raised by check_nan() or at the start of call k + 1
     X, Fp, Y, cls = bad
     feed = {"img_data": X[:, :3], "seg_label": Y, "focus_point": Fp, "cls_label": cls}
@@ -467,16 +483,17 @@ def test_nan_assertion_is_deferred_not_dropped():
 
 @pytest.mark.gpu
 def test_training_trajectory_same_in_every_conv_mode():
-    """30 optimisation steps on one fixed batch (train mode, dropout replayed by the step counter): the loss falls by more than a quarter
-    in every conv mode, and the split-precision trajectories (F(2,3) row kernel included) stay within 8 % of the fp32-MFMA mode's at
-    every step.  The bound is set by the noise floor, not by the kernels: two runs of the SAME fp32 mode already differ by 1.3 % after 20
-    steps (bwd-weight float atomics change the last bits of a gradient, Adam's g / sqrt(v) turns that into +-lr on near-zero gradients;
-    tools/trajectory_probe.py prints the curves: f32 vs f32 1.3e-2, bf16x3 1.8e-2, f16x2 0.9e-2).  A wrong gradient anywhere in the conv
-    engine separates the curves by far more, or stops the descent."""
+    """40 optimisation steps on one fixed batch (train mode, dropout replayed by the step counter): the loss falls by more than a third
+    in every conv mode, and the split-precision trajectories (F(2,3) row kernel included) stay as close to the fp32-MFMA mode's as a
+    second run of the fp32-MFMA mode itself does.  The bound is derived from that noise, measured inside the test: the f32
+    mode runs TWICE (bwd-weight float atomics change the last bits of a gradient, Adam's g / sqrt(v) turns that into +-lr on near-zero
+    gradients: 1.3e-2 after 20 steps in tools/trajectory_probe.py), and every other mode must stay within 3 x max(that spread, 1.5e-2)
+    of the first f32 curve at every step.  A wrong gradient anywhere in the conv engine (a wrong scale on one tap class, say) separates
+    the curves by far more, or stops the descent."""
     cfg = fovealseg.lvis50_cfg()
     curves = {}
     try:
-        for mode in ("f32", "bf16x3", "f16x2"):
+        for name, mode in (("f32", "f32"), ("f32_again", "f32"), ("bf16x3", "bf16x3"), ("f16x2", "f16x2")):
             fovealseg.hip.set_conv_precision(mode)
             module, nets = train.build_module(cfg, device="cuda")
             module.train()
@@ -484,16 +501,18 @@ def test_training_trajectory_same_in_every_conv_mode():
             batch = train.synthetic_batch(4, 256, 256, seed=11, device="cuda")
             fovealseg.ops.DropoutState.seed, fovealseg.ops.DropoutState.step = 5, 0
             losses = []
-            for it in range(30):
+            for it in range(40):
                 out = train.train_step(module, opts, batch, cfg, epoch=1, cur_iter=it)
                 losses.append(out[0].detach().reshape(-1)[0])
-            curves[mode] = torch.stack(losses).double().cpu()
+            curves[name] = torch.stack(losses).double().cpu()
             del module, nets, opts
     finally:
-        fovealseg.hip.set_conv_precision("f16x2")
+        fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
     ref = curves["f32"]
-    for mode, c in curves.items():
-        assert torch.isfinite(c).all() and float(c[-3:].mean()) < 0.75 * float(c[:3].mean()), (mode, c)
-        assert abs(float(c[0]) - float(ref[0])) <= 1e-4 * float(ref[0]), (mode, float(c[0]), float(ref[0]))      # same forward before any update
+    spread = float(((curves["f32_again"] - ref).abs() / ref.abs()).max())
+    bound = 3.0 * max(spread, 1.5e-2)
+    for name, c in curves.items():
+        assert torch.isfinite(c).all() and float(c[-3:].mean()) < (2.0 / 3.0) * float(c[:3].mean()), (name, c)
+        assert abs(float(c[0]) - float(ref[0])) <= 1e-4 * float(ref[0]), (name, float(c[0]), float(ref[0]))      # same forward before any update
         rel = float(((c - ref).abs() / ref.abs()).max())
-        assert rel <= 8e-2, (mode, rel, c, ref)
+        assert rel <= bound, (name, rel, spread, bound, c, ref)

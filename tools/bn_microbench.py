@@ -38,15 +38,20 @@ def main():
         mean = y.mean(0).contiguous(); invstd = (1.0 / y.std(0)).contiguous()
         gamma = torch.rand(C, device=dev) + 0.5; beta = torch.randn(C, device=dev)
         dgamma = torch.empty(C, device=dev); dbeta = torch.empty(C, device=dev)
-        sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
+        nslab = hip.bn_bwd_slabs(M, C)
+        slab = torch.empty(nslab * C * 2, device=dev); coef = torch.empty(4 * C, device=dev)
         out = []
         for has_res in (False, True):
             r = res if has_res else None
             dr = dres if has_res else None
             tf = timed(lambda: hip.call("fs_bn_act_fwd", hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(beta), hip.ptr(r),
                                         hip.ptr(z), hip.ptr(mask), M, C, 1), reps)
-            tb = timed(lambda: hip.call("fs_bn_act_bwd", hip.ptr(dz), None, hip.ptr(mask), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma),
-                                        M, C, 1, 1, 0.3, 77, hip.ptr(dy), hip.ptr(dr), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(sums), 0), reps)
+            def bwd():
+                hip.call("fs_bn_bwd_partial", hip.ptr(dz), None, hip.ptr(mask), hip.ptr(y), hip.ptr(mean), hip.ptr(invstd), M, C, 1, hip.ptr(slab))
+                hip.call("fs_bn_bwd_finalize", hip.ptr(slab), nslab, hip.ptr(gamma), hip.ptr(mean), hip.ptr(invstd), M, C, 1, hip.ptr(coef),
+                         hip.ptr(dgamma), hip.ptr(dbeta), 0)
+                hip.call("fs_bn_bwd_apply", hip.ptr(dz), None, hip.ptr(mask), hip.ptr(y), hip.ptr(coef), M, C, 1, 0.3, 77, hip.ptr(dy), hip.ptr(dr))
+            tb = timed(bwd, reps)
             bf = 4.0 * M * C * (2 + has_res) + M * C / 4
             bb = 4.0 * M * C * (5 + has_res) + 2 * M * C / 4
             out.append(f"res={int(has_res)} fwd {tf:6.1f} us {bf / tf / 1e3:6.0f} GB/s | bwd {tb:6.1f} us {bb / tb / 1e3:6.0f} GB/s")
