@@ -1197,7 +1197,7 @@ int fs_conv2d_stats_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout
   const long need = fs_conv2d_workspace_bytes(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0);
   if (need > 0 && ws_bytes >= need) {
     const bool halo = H == Ho && W == Wo && fs_halo_eligible(H, W, Cin, Cout, R, S, stride, pad, dil);
-    if (halo && fs_wino_eligible(g_conv_precision, B, Ho, Wo, Cin, Cout)) return fs_wino_stats_slabs(B, Ho, Wo, Cout);
+    if (halo && fs_wino_eligible(g_conv_precision, B, Ho, Wo, Cin, Cout)) return fs_wino_stats_slabs(g_conv_precision, B, Ho, Wo, Cin, Cout);
     if (halo) return fs_halo_stats_slabs(B, Ho, Wo);
     if (tapset_shape_ok(Cin, Cout, R, S, stride, dil)) return fs_tapset_slabs(B, Ho, Wo, (R + stride - 1) / stride, (S + stride - 1) / stride);
     if (halo) return fs_halo_stats_slabs(B, Ho, Wo);

@@ -25,7 +25,7 @@ int fs_weight_amax_segments_impl(const float* arena, const long* offsets, const 
 // Even W >= 4, B*(H+1) < 65536, channel counts multiples of 4, K >= 32 (K >= 128 in f16x2); FS_WINOGRAD=0 switches it off.
 bool fs_wino_eligible(int mode, int B, int H, int W, int Cs, int Cd);
 long fs_wino_pack_bytes(int mode, int Cs, int Cd);
-int fs_wino_stats_slabs(int B, int H, int W, int Cd);
+int fs_wino_stats_slabs(int mode, int B, int H, int W, int Cs, int Cd);
 int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
                     int B, int H, int W, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh,
                     uint32_t drop_key, hipStream_t stream);

@@ -339,11 +339,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       if (chunk < 4) WINO_STAMP(4 + 5 * chunk);
       __syncthreads();
       if (chunk < 4) WINO_STAMP(5 + 5 * chunk);
-      if (chunk + 1 < a.nchunk) load_halo(chunk + 1);
       read_a(0, fa[0]);
 #pragma unroll
       for (int step = 0; step < 12; ++step) {
         if (step + 1 < 12) read_a(step + 1, fa[(step + 1) & 1]);
+        if (step == 0 && chunk + 1 < a.nchunk) load_halo(chunk + 1);     // (at step 10, behind the chunk's last own fragment: +-0 on the step)
         {
           const int gi = g + RD - 1;         // past this tile's last fragment: the next tile's first ones (or a repeat of the last)
           const bool own = gi < G;
@@ -461,6 +461,333 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   }
 }
 
+// ---- eight-wave variant with the split work INSIDE the MFMA phase (bf16x3, round 3) ----------------------------------------------
+// What the phase stamps of the kernel above say (tools/wino_trace.sh, profiles/r03/wino_phase_stamps.txt): its two co-resident
+// workgroups run in lockstep -- both split and store a halo image at the same time (about 3 k cycles without one MFMA on the CU),
+// then both multiply at the same time (2 x 144 MFMAs in 9.5 k cycles: the pipe is ~95 % busy in THAT phase).  Holding the two
+// workgroups one phase apart (a ping-pong of two 4-wave halves behind one barrier, measured and rejected) does not help: a wave
+// multiplying alone needs 7.6 k cycles for its 144 MFMAs, because every vector-memory instruction in its stream (36 weight-fragment
+// loads + 12 halo loads per chunk) costs ~60 issue cycles the pipe sits idle unless a partner wave multiplies meanwhile.
+// So here both waves of a SIMD stay in the MFMA phase all the time and the split/store work of the NEXT chunk is a block of VALU
+// code inside the CURRENT chunk's MFMA phase, placed at a different step for waves 0-3 than for waves 4-7 (SIMD partners are waves
+// w and w + 4): while one wave of a SIMD splits, its partner multiplies.  That needs the halo image double-buffered in LDS
+// (2 x 76.8 KB), i.e. ONE workgroup of eight waves per CU sharing it: 64 pairs x 128 columns, waves = 2 component pairs x 4 column
+// groups, so the split work per MFMA is halved as well.
+// (A 64-column form -- 2 x 2 waves x the two 16-channel halves of every chunk, added in the epilogue -- was 19 % slower than the
+// 4-wave kernel on 64 -> 64 @ 80x80 and is not kept; which layers come here: wino_use8 below.)
+// One barrier per chunk.  Halo loads for chunk j + 2 are issued right behind the split of chunk j + 1 into the registers it freed
+// (a whole chunk period of cover).  Tile loop persistent as above; BatchNorm partial sums: one slab row per (pixel tile, pixel
+// parity) -- no exchange between waves.
+template <class P>
+__global__ __launch_bounds__(512, 1) void conv3x3_wino8_kernel(WinoArgs a) {
+  static_assert(!P::SCALED, "no slot for the f16x2 tile-maximum exchange in this schedule");
+  typedef typename P::x8 X8;
+  typedef typename P::x4 X4;
+  constexpr int NPL = P::NPL;
+  constexpr int MI = 2;                    // 32-pair blocks per wave
+  constexpr int NITEM = 2;                 // (slot, channel quad) items per thread: 8 * slots <= 512 * NITEM
+  constexpr int IMG = NPL * PLANE * 2;     // bytes of one halo image
+  constexpr int NCOL = 128;                // columns per workgroup
+  constexpr int NSTEP = 12;                // MFMA steps of a chunk
+  constexpr int S_EARLY = 2, S_LATE = 8;   // steps behind which waves 0-3 / 4-7 split the next chunk
+  static_assert(IMG >= XCH_BYTES, "an exchange round (one pair block of all 8 waves) lives in one image buffer");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* rowpix = reinterpret_cast<int*>(smem + 2 * IMG);                        // [2 tile parities][64]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int hw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cp = hw >> 2;                                                      // component pair {0,1} / {2,3}; also the stagger group
+  const int wn = hw & 3;                                                       // 32-column group
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // ---- persistent schedule (as above, one workgroup per CU) ----
+  const int ntile = a.nx * a.ny;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd = ntile >> 3, rm = ntile & 7;
+  const int t_first = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd);
+  const int t_end = t_first + qd + (xcd < rm ? 1 : 0);
+  const int L = ((int)gridDim.x + 7 - xcd) >> 3;
+  if (t_first + loc >= t_end) return;                                          // workgroup-uniform
+  const int ntw = (t_end - t_first - loc + L - 1) / L;                         // tiles this workgroup walks: t_first + loc + k L
+  const int nch = a.nchunk;
+  const int nslots = (a.Ph + 2) * a.PP, npairs = a.Ph * a.PP;
+
+  auto image_row = [&](int vy, int& bb, int& yy) {
+    const bool in = vy >= 0 && vy < a.B * a.Hv;
+    bb = in ? div_small(vy, a.magic_hv) : 0;
+    yy = in ? vy - bb * a.Hv : a.H;
+  };
+  auto decode = [&](int w_, int& mt, int& n0, int& y0, int& x0) {
+    mt = div_small1(w_, a.magic_ny);
+    n0 = (w_ - mt * a.ny) * NCOL;
+    const int ty = div_small1(mt, a.magic_tx), tx = mt - ty * a.tiles_x;
+    y0 = ty * a.Ph; x0 = tx * 2 * a.PP;
+  };
+  auto write_rowpix = [&](int par, int y0, int x0) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    if (t_ < 32 * MI) {
+      const int p = (t_ & ~31) + row_perm(t_ & 31);
+      const int py = div_small(p, a.magic_pp), px = p - py * a.PP;
+      int bb, yy;
+      image_row(y0 + py, bb, yy);
+      const bool live = p < npairs && yy < a.H && x0 + 2 * px < a.W;
+      rowpix[par * 64 + t_] = live ? ((bb * a.H + yy) * a.W + x0 + 2 * px) * a.Cd : -1;
+    }
+  };
+  // halo loader: item i of a thread = (slot (tid >> 3) + 64 i, channel quad tid & 7); item 1 exists for slots 64..79 (waves 0, 1)
+  int goff[NITEM], gmask = 0;
+  auto setup_loader = [&](int y0, int x0) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+      const int slot = (t_ >> 3) + 64 * i;
+      const int hy = div_small(slot, a.magic_pp), pj = slot - hy * a.PP;
+      const int ix = x0 + 2 * pj - 1;
+      int bb, iy;
+      image_row(y0 + hy - 1, bb, iy);
+      const bool rowok = slot < nslots && iy < a.H;
+      int m = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m |= (rowok && ix + e >= 0 && ix + e < a.W) ? (1 << e) : 0;
+      gmask = i == 0 ? m : (gmask | (m << (4 * i)));
+      goff[i] = ((bb * a.H + (rowok ? iy : 0)) * a.W + ix) * a.Cs + 4 * (t_ & 7);
+    }
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(a.src, a.src_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.ws, a.ws_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
+  const int q = tid & 7;
+  const bool item1 = (tid >> 3) + 64 < nslots;                                 // wave-uniform in groups of 8 lanes; false for waves >= 2
+
+  f32x4 ra[NITEM][4];
+  auto load_halo = [&](int chunk) {
+    const int c0 = chunk * 32;
+    const bool cok = c0 + 4 * q < a.Cs;
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+      if (i == 1 && hw >= 2) continue;                                         // waves 2..7 own no second item (wave-uniform)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = cok && ((gmask >> (4 * i + e)) & 1);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? (int)((unsigned)(goff[i] + e * a.Cs + c0) * 4u) : (int)OOB, 0, 0);
+        ra[i][e] = __builtin_bit_cast(f32x4, v);
+      }
+    }
+  };
+  auto store_halo = [&](int buf) {         // d0..d3 -> T0..T3 -> planes -> image `buf`
+    typename P::T* Aw = reinterpret_cast<typename P::T*>(smem + buf * IMG);
+#pragma unroll
+    for (int i = 0; i < NITEM; ++i) {
+      if (i == 1 && hw >= 2) continue;
+      const int slot = (tid >> 3) + 64 * i;
+      if (slot >= nslots) continue;
+      const f32x4 d0 = ra[i][0], d1 = ra[i][1], d2 = ra[i][2], d3 = ra[i][3];
+      const f32x4 T[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        X4 p[NPL];
+        P::split4(T[c], p);
+        const int o = (c * WNS + slot) * XLD + 4 * q;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Aw[pl * PLANE + o]) = p[pl];
+      }
+    }
+  };
+  (void)item1;
+
+  int rowbase[MI];
+  const int rowstep = a.PP * XLD;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int p = 32 * mi + row_perm(l31);
+    const bool live = p < npairs;
+    const int py = live ? div_small(p, a.magic_pp) : 0, px = live ? p - py * a.PP : 0;
+    rowbase[mi] = 2 * cp * CPLANE + (py * a.PP + px) * XLD + 8 * lh;
+  }
+  const int plane_bytes = a.Npad * 32;
+  const int step_bytes = NPL * plane_bytes;
+  const int G = nch * NSTEP;               // B fragments this wave consumes per tile
+  auto b_voff = [&](int n0) { return HDR + ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2; };
+
+  X8 fa[2][MI][NPL];
+  constexpr int RD = 3;
+  X8 fb[RD][NPL];
+  auto load_b = [&](int gg, int voff, X8 (&dst)[NPL]) {
+    const int g4 = (gg >> 2) * 8 + 4 * cp + (gg & 3);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff, g4 * step_bytes + pl * plane_bytes, 0);
+      dst[pl] = __builtin_bit_cast(X8, v);
+    }
+  };
+  auto read_a = [&](int buf, int step, X8 (&dst)[MI][NPL]) {
+    const int ky = step >> 2, ci = (step >> 1) & 1, s2 = step & 1;
+    const typename P::T* Ar = reinterpret_cast<const typename P::T*>(smem + buf * IMG);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+        dst[mi][pl] = *reinterpret_cast<const X8*>(&Ar[pl * PLANE + rowbase[mi] + ky * rowstep + ci * CPLANE + 16 * s2]);
+  };
+
+  // ---- cursors: the halo loader runs up to two chunks ahead of the MFMAs, across tile boundaries ----
+  int lk = 0, lc = 0;                      // (tile number, chunk) of the next halo load
+  auto loader_advance = [&]() {            // after a load: move on; entering a new tile re-aims the loader
+    if (++lc == nch) {
+      lc = 0; ++lk;
+      if (lk < ntw) {
+        int mt_, n0_, y0_, x0_;
+        decode(t_first + loc + lk * L, mt_, n0_, y0_, x0_);
+        setup_loader(y0_, x0_);
+      }
+    }
+  };
+  int mt, n0, y0, x0;
+  decode(t_first + loc, mt, n0, y0, x0);
+  setup_loader(y0, x0);
+  write_rowpix(0, y0, x0);
+  int bvoff = b_voff(n0);
+#pragma unroll
+  for (int r = 0; r < RD - 1; ++r) load_b(r, bvoff, fb[r]);
+  load_halo(0);
+  loader_advance();
+  store_halo(0);                           // chunk 0 of the first tile (exposed once per workgroup)
+  if (lk < ntw) { load_halo(lc); loader_advance(); }
+  __syncthreads();
+
+  int J = 0;                               // chunks multiplied so far: image buffer of the current chunk = J & 1
+  const int total_chunks = ntw * nch;
+  for (int k = 0; k < ntw; ++k) {
+    const bool has_next = k + 1 < ntw;
+    int mt_n = 0, n0_n = 0, y0_n = 0, x0_n = 0, bvoff_n = bvoff;
+    if (has_next) {
+      decode(t_first + loc + (k + 1) * L, mt_n, n0_n, y0_n, x0_n);
+      bvoff_n = b_voff(n0_n);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ci][b][r] = 0.f;
+    int g = 0;
+    for (int chunk = 0; chunk < nch; ++chunk, ++J) {
+      const int buf = J & 1;
+      const bool split_next = J + 1 < total_chunks;          // ra holds the halo of chunk J + 1 (this tile's next chunk or the next tile's first)
+      read_a(buf, 0, fa[0]);
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) read_a(buf, st + 1, fa[(st + 1) & 1]);
+        {
+          const int gi = g + RD - 1;
+          const bool own = gi < G;
+          const int gn = gi - G < G ? gi - G : G - 1;
+          load_b(own ? gi : (has_next ? gn : G - 1), own ? bvoff : bvoff_n, fb[(st + RD - 1) % RD]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const X8(&A)[MI][NPL] = fa[st & 1];
+        const X8(&Bf)[NPL] = fb[st % RD];
+        const int ci = (st >> 1) & 1;
+        if (ci == 0) {
+#pragma unroll
+          for (int t = 0; t < P::NTERM; ++t) {
+            acc[0][0] = P::mfma(A[0][P::ta(t)], Bf[P::tb(t)], acc[0][0]);
+            acc[0][1] = P::mfma(A[1][P::ta(t)], Bf[P::tb(t)], acc[0][1]);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < P::NTERM; ++t) {
+            acc[1][0] = P::mfma(A[0][P::ta(t)], Bf[P::tb(t)], acc[1][0]);
+            acc[1][1] = P::mfma(A[1][P::ta(t)], Bf[P::tb(t)], acc[1][1]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ++g;
+        // the NEXT chunk's split / store, at a different step for the two waves of a SIMD (w and w + 4, i.e. cp = 0 / 1)
+        if ((st == S_EARLY || st == S_LATE) && split_next && (st == S_EARLY) == (cp == 0)) {
+          store_halo(buf ^ 1);
+          if (lk < ntw) { load_halo(lc); loader_advance(); }    // chunk J + 2 into the registers just freed
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- epilogue: two exchange rounds (pair block 0, then 1) through the image buffer the last chunk was read from ----
+    unsigned char* const xbuf = smem + ((J - 1) & 1) * IMG;
+    const int par = k & 1;
+    const int n = n0 + 32 * wn + (lane & 7) * 4;
+    const bool nok = n < a.Cd;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr && nok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = a.bias[n + j];
+    }
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f}, csq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      {
+        // partial sums in accumulator order: parity 0 (even pixel) = m0 + m1 | m2, parity 1 (odd pixel) = m1 | -(m2 + m3)
+        int l_ = lane;
+        asm volatile("" : "+v"(l_));
+        float* xw = reinterpret_cast<float*>(xbuf) + hw * 2048 + (4 * (l_ >> 5)) * 32 + (l_ & 31);      // [wave][parity][32 rows][32 columns]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2);
+          const float ev = cp == 0 ? acc[0][b][r] + acc[1][b][r] : acc[0][b][r];
+          const float od = cp == 0 ? acc[1][b][r] : -(acc[0][b][r] + acc[1][b][r]);
+          xw[row * 32] = ev;
+          xw[1024 + row * 32] = od;
+        }
+      }
+      __syncthreads();
+      // this wave stores pixel parity cp of its column group
+      {
+        int l_ = lane;
+        asm volatile("" : "+v"(l_));
+        const int c4 = (l_ & 7) * 4, rsub = l_ >> 3;
+        // source waves: both component pairs (hw and hw ^ 4)
+        const float* s0 = reinterpret_cast<const float*>(xbuf) + hw * 2048 + cp * 1024;
+        const float* s1 = reinterpret_cast<const float*>(xbuf) + (hw ^ 4) * 2048 + cp * 1024;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int row = 8 * kk + rsub;
+          const int pix = rowpix[par * 64 + b * 32 + row];
+          const f32x4 m = *reinterpret_cast<const f32x4*>(s0 + row * 32 + c4) + *reinterpret_cast<const f32x4*>(s1 + row * 32 + c4);
+          const bool live = pix >= 0 && nok;
+          const unsigned e = (unsigned)(pix + n + cp * a.Cd);                 // the {2,3} waves write the odd pixel of the pair
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x = m[j] + bv[j];
+            if (a.drop_thresh != 0u) x = fs_dropout_keep((uint32_t)(e + j), a.drop_key, a.drop_thresh) ? x * a.drop_scale : 0.f;
+            v[j] = live ? x : 0.f;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
+          csum += v; csq += v * v;
+        }
+      }
+      __syncthreads();
+    }
+    if (a.stats != nullptr) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { csum[j] += __shfl_xor(csum[j], o, 64); csq[j] += __shfl_xor(csq[j], o, 64); }
+      if (lane < 8 && nok) {               // slab row = (pixel tile, pixel parity): [2 nx][Cd][2]
+        float* dst = a.stats + ((long)(2 * mt + cp) * a.Cd + n) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dst[2 * j] = csum[j]; dst[2 * j + 1] = csq[j]; }
+      }
+    }
+    if (!has_next) break;
+    mt = mt_n; n0 = n0_n; bvoff = bvoff_n;
+    write_rowpix((k + 1) & 1, y0_n, x0_n);
+  }
+}
+
 const bool g_wino = [] { const char* e = getenv("FS_WINOGRAD"); return !(e && e[0] == '0'); }();
 
 // Ph rows x PP pairs <= 64 pairs per workgroup, halo (Ph+2)*PP <= WNS; fewest tiles over the stacked batch, then smallest halo.
@@ -494,6 +821,16 @@ int wino_grid_slots() {
   return slots[dev];
 }
 
+// Which 3x3 layers take the eight-wave kernel: bf16x3, more than 64 output channels (128-column workgroups) and at least 8 channel
+// chunks -- measured in one gpurun call against the persistent 4-wave kernel: 256 -> 256 @ 20x20 139 vs 150 us, 512 -> 512 @ 10x10
+// 150 vs 165 us, 960 -> 240 @ 80x80 5.81 vs 5.92 ms; 128 -> 128 @ 40x40 the same; its 64-column form (k-halves) 19 % slower on
+// 64 -> 64 @ 80x80 and not kept.  FS_WINO8=0 / 2: never / every layer above 64 output channels (kernel experiments; read once).
+bool wino_use8(int mode, int Cs, int Cd) {
+  static const int pol = [] { const char* e = getenv("FS_WINO8"); return e ? atoi(e) : 1; }();
+  if (mode != 1 || Cd <= 64 || pol == 0) return false;
+  return pol == 2 || Cs >= 256;
+}
+
 template <class P>
 int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int Cin, int Cout, int transposed, hipStream_t stream) {
   int e = FS_OK;
@@ -503,35 +840,47 @@ int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int 
   hipLaunchKernelGGL((wino_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws),
                      a.ew, Cin, Cout, transposed, a.Cs, a.Cd, a.Npad, total);
   FS_LAUNCH_CHECK();
+  const long ntile = (long)a.nx * a.ny;
+  const int slots = wino_grid_slots();
+  // the dynamic-LDS opt-in (above the 64 KB default) is a per-device function attribute: set it once on every device used
   constexpr int lds = wino_lds_bytes<P>();
+  constexpr int lds8 = 2 * P::NPL * PLANE * 2 + 2 * 64 * 4;
   {
-    // the dynamic-LDS opt-in (above the 64 KB default) is a per-device function attribute: set it once on every device used
-    static unsigned long long done = 0ull;
+    static unsigned long long done = 0ull;            // one mask per precision (template instance)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return FS_ERR_ARG;
     if (dev < 0 || dev >= 64 || !((done >> dev) & 1ull)) {
-      const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (attr != hipSuccess) return (int)attr;
+      if constexpr (!P::SCALED) {
+        attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino8_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8);
+        if (attr != hipSuccess) return (int)attr;
+      }
       if (dev >= 0 && dev < 64) done |= 1ull << dev;
     }
   }
-  const long ntile = (long)a.nx * a.ny;
-  const int slots = wino_grid_slots();
+  if constexpr (!P::SCALED) {
+    if (a.ny * 128 == a.Npad && wino_use8(1, a.Cs, a.Cd)) {       // planned for 128-column workgroups (fs_wino_conv3x3)
+      const unsigned grid8 = (unsigned)(ntile < slots / 2 ? ntile : slots / 2);
+      hipLaunchKernelGGL((conv3x3_wino8_kernel<P>), dim3(grid8), dim3(512), lds8, stream, a);
+      FS_LAUNCH_CHECK();
+      return FS_OK;
+    }
+  }
   const unsigned grid = (unsigned)(ntile < slots ? ntile : slots);
 #ifdef FS_WINO_TRACE
   static long long* dbg = nullptr;
   const long nwg = grid;
   if (dbg == nullptr && hipMalloc(&dbg, sizeof(long long) * 32 * 65536) != hipSuccess) return FS_ERR_ARG;
   a.dbg = dbg;
-  hipMemsetAsync(dbg, 0, sizeof(long long) * 32 * nwg, stream);
+  if (hipMemsetAsync(dbg, 0, sizeof(long long) * 32 * nwg, stream) != hipSuccess) return FS_ERR_ARG;
 #endif
   hipLaunchKernelGGL((conv3x3_wino_kernel<P>), dim3(grid), dim3(256), lds, stream, a);
   FS_LAUNCH_CHECK();
 #ifdef FS_WINO_TRACE
   {
-    hipStreamSynchronize(stream);
     static long long host[32 * 65536];
-    hipMemcpy(host, dbg, sizeof(long long) * 32 * nwg, hipMemcpyDeviceToHost);
+    if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(host, dbg, sizeof(long long) * 32 * nwg, hipMemcpyDeviceToHost) != hipSuccess) return FS_ERR_ARG;
     double sum[32] = {0};
     for (long w_ = 0; w_ < nwg; ++w_)
       for (int i = 1; i < 25; ++i) {
@@ -559,15 +908,14 @@ bool fs_wino_eligible(int mode, int B, int H, int W, int Cs, int Cd) {
 
 long fs_wino_pack_bytes(int mode, int Cs, int Cd) {
   const int npl = mode == 2 ? 2 : 3;
-  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 63) / 64) * 64;
+  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 127) / 128) * 128;       // room for either column tiling
   return HDR + nchunk * 24 * npl * Npad * 16 * 2;
 }
 
-int fs_wino_stats_slabs(int B, int H, int W, int Cd) {
-  (void)Cd;
+int fs_wino_stats_slabs(int mode, int B, int H, int W, int Cs, int Cd) {
   int Ph, PP, tx, nx;
   wino_plan(B, H, W, Ph, PP, tx, nx);
-  return nx;
+  return wino_use8(mode, Cs, Cd) ? 2 * nx : nx;        // the eight-wave kernel writes one row per (pixel tile, pixel parity)
 }
 
 int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
@@ -576,10 +924,11 @@ int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bia
   WinoArgs a;
   a.src = src; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = dst; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cs = Cs; a.Cd = Cd;
-  a.Npad = ((Cd + 63) / 64) * 64;
+  const int ncol = wino_use8(mode, Cs, Cd) ? 128 : 64;      // columns per workgroup
+  a.Npad = ((Cd + ncol - 1) / ncol) * ncol;
   a.nchunk = (Cs + 31) / 32;
   wino_plan(B, H, W, a.Ph, a.PP, a.tiles_x, a.nx);
-  a.ny = a.Npad / 64;
+  a.ny = a.Npad / ncol;
   a.Hv = H + 1;
   a.magic_hv = div_magic(a.Hv);
   a.magic_pp = div_magic(a.PP);

@@ -324,5 +324,9 @@ def test_train_step_through_one_rank_rccl_group():
     assert scales == [1.0] * 4
     for a, b in zip(base_losses, losses):
         assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (base_losses, losses)       # bwd-weight float atomics reorder: not bit-identical
+    # Adam moves an element by at most lr (= 1e-4 here) per step whatever the size of its gradient, so where a gradient is within the
+    # atomics' rounding of zero the two runs can step in opposite directions: the worst element differs by <= 2 steps x 2 lr, while the
+    # arena as a whole stays at the rounding level
     for p0, p1 in zip(base_params, params):
-        assert float((p0 - p1).abs().max()) <= 1e-4 * float(p0.abs().max())
+        d = (p0 - p1).abs()
+        assert float(d.max()) <= 4.1e-4 and float(d.mean()) <= 2e-6, (float(d.max()), float(d.mean()))

@@ -37,9 +37,11 @@ def main():
         x = torch.randn(B, H, W, Ci, device=dev)
         w = ops.new_rsck_weight(Co, Ci, k, k, device=dev)
         w.normal_()
+        if os.environ.get("MB_ZEROS") == "1":          # DVFS probe: same instruction stream on all-zero operands (MI355X_MICROARCH.md, give-back (1))
+            x.zero_(); w.zero_()
         pad = k // 2
         y = ops.conv2d_fwd(x, w, None, s, pad)
-        dy = torch.randn_like(y)
+        dy = torch.zeros_like(y) if os.environ.get("MB_ZEROS") == "1" else torch.randn_like(y)
         flops = 2.0 * y.numel() * Ci * k * k
         fns = {"fwd": lambda: ops.conv2d_fwd(x, w, None, s, pad),
                "bwd_data": lambda: ops.conv2d_bwd_data(dy, w, x.shape, s, pad),
