@@ -329,4 +329,4 @@ def test_train_step_through_one_rank_rccl_group():
     # arena as a whole stays at the rounding level
     for p0, p1 in zip(base_params, params):
         d = (p0 - p1).abs()
-        assert float(d.max()) <= 4.1e-4 and float(d.mean()) <= 2e-6, (float(d.max()), float(d.mean()))
+        assert float(d.max()) <= 4.1e-4 and float(d.mean()) <= 1e-5, (float(d.max()), float(d.mean()))
