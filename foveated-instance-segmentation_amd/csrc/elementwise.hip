@@ -766,10 +766,13 @@ int fs_dropout(const float* x, float* out, long n, float drop_p, uint32_t drop_k
   return FS_OK;
 }
 
-int fs_colsum(const float* x, long M, int C, float* out, hipStream_t stream) {
+// accumulate != 0: the column sums are ADDED to out (a gradient-arena target: no memset), else out is overwritten
+int fs_colsum(const float* x, long M, int C, float* out, int accumulate, hipStream_t stream) {
   FS_REQUIRE(x && out && M > 0 && C > 0);
-  hipError_t e = hipMemsetAsync(out, 0, C * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, C * sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+  }
   if (C % 4 == 0 && C <= 1024 && ((size_t)x & 15) == 0) {
     const int rpb = rows_per_block_for(M, C);
     const int cw = C / 4;

@@ -126,64 +126,127 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------
 // depthwise 3x3 conv, stride 1, pad 1, NHWC; weights logical (C,1,3,3) = [c][9]
 // flip = 0: y = sum_t w[c][t] x[p + t] (+ bias);  flip = 1: input gradient (taps mirrored, no bias)
+// HBM-bound (one read of x, one write of y).  Round 2's kernel issued 9 neighbour loads per output through L1 and ran at a fifth
+// of the roof; here a thread owns 4 channels x DW_RY output rows and WALKS along the row with a 3-column register window: 6 new
+// loads per 4 outputs.  Consecutive lanes = consecutive channel quads (1 KB per pixel row of a wave).
 // ------------------------------------------------------------------------------------------
+constexpr int DW_RY = 4;       // output rows per thread
+constexpr int DW_SEG = 16;     // output columns per thread
+
 __global__ __launch_bounds__(256) void dwconv3_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
                                                       int C, int flip) {
-  // the 9 x C weights transposed to [tap][channel] in LDS (taps already mirrored for the input gradient): one 16-byte LDS read per
-  // tap and channel quad instead of four scalar global loads -- 36 of the 45 loads a thread issued per output were weight scalars
-  extern __shared__ float wt[];    // [9][C]
-  for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) {
-    const int c = i / 9, t = i - 9 * c;
-    wt[(flip ? 8 - t : t) * C + c] = w[i];
-  }
-  __syncthreads();
   const int cw = C >> 2;
-  const long total = (long)B * H * W * cw;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = 4 * (int)(i % cw);
-    const long pix = i / cw;
-    const int px = (int)(pix % W), py = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
-    f32x4 acc = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0, 0, 0, 0};
+  const int rg = (H + DW_RY - 1) / DW_RY, sg = (W + DW_SEG - 1) / DW_SEG;
+  const long items = (long)B * rg * sg;
+  const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cq = (int)(gt % cw);
+  const long item = gt / cw;
+  if (item >= items) return;
+  const int c = 4 * cq;
+  const int s_ = (int)(item % sg), r_ = (int)((item / sg) % rg), b = (int)(item / ((long)sg * rg));
+  const int y0 = r_ * DW_RY, x0 = s_ * DW_SEG;
+  const int x1 = x0 + DW_SEG < W ? x0 + DW_SEG : W;
+  f32x4 wv[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int dy = t / 3 - 1, dxx = t % 3 - 1;
-      const int iy = py + dy, ix = px + dxx;
-      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (((long)b * H + iy) * W + ix) * C + c);
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(&wt[t * C + c]);
-      acc += xv * wv;
+  for (int t = 0; t < 9; ++t) {
+    const int tt = flip ? 8 - t : t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wv[t][e] = w[(c + e) * 9 + tt];
+  }
+  const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0, 0, 0, 0};
+  const float* xb = x + (long)b * H * W * C + c;
+  auto col = [&](int ix, f32x4 (&v)[DW_RY + 2]) {
+#pragma unroll
+    for (int r = 0; r < DW_RY + 2; ++r) {
+      const int iy = y0 - 1 + r;
+      const bool ok = ix >= 0 && ix < W && iy >= 0 && iy < H;
+      v[r] = ok ? *reinterpret_cast<const f32x4*>(xb + ((long)iy * W + ix) * C) : f32x4{0, 0, 0, 0};
     }
-    *reinterpret_cast<f32x4*>(y + pix * C + c) = acc;
+  };
+  f32x4 v0[DW_RY + 2], v1[DW_RY + 2], v2[DW_RY + 2];
+  col(x0 - 1, v0);
+  col(x0, v1);
+  for (int ix = x0; ix < x1; ++ix) {
+    col(ix + 1, v2);
+#pragma unroll
+    for (int r = 0; r < DW_RY; ++r) {
+      if (y0 + r >= H) break;
+      f32x4 acc = bv;
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) acc += v0[r + ty] * wv[3 * ty] + v1[r + ty] * wv[3 * ty + 1] + v2[r + ty] * wv[3 * ty + 2];
+      *reinterpret_cast<f32x4*>(y + (((long)b * H + y0 + r) * W + ix) * C + c) = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < DW_RY + 2; ++r) { v0[r] = v1[r]; v1[r] = v2[r]; }
   }
 }
-// dw[c][t] = sum_pix x[pix + t][c] * dy[pix][c]; thread = (channel quad), block = chunk of pixels, atomics at the end
-__global__ __launch_bounds__(1024) void dwconv3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            float* __restrict__ dw, int B, int H, int W, int C, int pix_per_block) {
+
+// dw[c][t] = sum_pix x[pix + t][c] * dy[pix][c].  Same walk (10 loads per 4 pixels instead of 40); a thread loops over the items
+// item0, item0 + nitem_lanes, ... and writes its 9 x 4 partial sums to slab[item lane][9][C] (coalesced, no atomics, no memset);
+// dwconv3_wgrad_reduce_kernel adds the slab rows into dw.
+__global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ slab, int B, int H, int W, int C, int nlanes) {
   const int cw = C >> 2;
-  const int cg = threadIdx.x % cw, pl = threadIdx.x / cw, npl = blockDim.x / cw;
-  if (pl >= npl) return;
-  const int c = 4 * cg;
-  const long P = (long)B * H * W;
-  const long p0 = (long)blockIdx.x * pix_per_block;
-  long p1 = p0 + pix_per_block; if (p1 > P) p1 = P;
+  const int rg = (H + DW_RY - 1) / DW_RY, sg = (W + DW_SEG - 1) / DW_SEG;
+  const long items = (long)B * rg * sg;
+  const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cq = (int)(gt % cw);
+  const long lane0 = gt / cw;
+  if (lane0 >= nlanes) return;
+  const int c = 4 * cq;
   f32x4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = f32x4{0, 0, 0, 0};
-  for (long p = p0 + pl; p < p1; p += npl) {
-    const int px = (int)(p % W), py = (int)((p / W) % H), b = (int)(p / ((long)W * H));
-    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + p * C + c);
+  for (long item = lane0; item < items; item += nlanes) {
+    const int s_ = (int)(item % sg), r_ = (int)((item / sg) % rg), b = (int)(item / ((long)sg * rg));
+    const int y0 = r_ * DW_RY, x0 = s_ * DW_SEG;
+    const int x1 = x0 + DW_SEG < W ? x0 + DW_SEG : W;
+    const float* xb = x + (long)b * H * W * C + c;
+    const float* gb = dy + (long)b * H * W * C + c;
+    auto col = [&](int ix, f32x4 (&v)[DW_RY + 2]) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int iy = py + t / 3 - 1, ix = px + t % 3 - 1;
-      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-      acc[t] += g * *reinterpret_cast<const f32x4*>(x + (((long)b * H + iy) * W + ix) * C + c);
+      for (int r = 0; r < DW_RY + 2; ++r) {
+        const int iy = y0 - 1 + r;
+        const bool ok = ix >= 0 && ix < W && iy >= 0 && iy < H;
+        v[r] = ok ? *reinterpret_cast<const f32x4*>(xb + ((long)iy * W + ix) * C) : f32x4{0, 0, 0, 0};
+      }
+    };
+    f32x4 v0[DW_RY + 2], v1[DW_RY + 2], v2[DW_RY + 2];
+    col(x0 - 1, v0);
+    col(x0, v1);
+    for (int ix = x0; ix < x1; ++ix) {
+      col(ix + 1, v2);
+#pragma unroll
+      for (int r = 0; r < DW_RY; ++r) {
+        const bool ok = y0 + r < H;
+        const f32x4 g = ok ? *reinterpret_cast<const f32x4*>(gb + ((long)(y0 + r) * W + ix) * C) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+          acc[3 * ty] += g * v0[r + ty];
+          acc[3 * ty + 1] += g * v1[r + ty];
+          acc[3 * ty + 2] += g * v2[r + ty];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < DW_RY + 2; ++r) { v0[r] = v1[r]; v1[r] = v2[r]; }
     }
   }
+  float* dst = slab + (long)lane0 * 9 * C + c;
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(&dw[(c + e) * 9 + t], acc[t][e]);
+  for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(dst + (long)t * C) = acc[t];
+}
+
+// dw[c][t] (+)= sum over slab rows of slab[row][t][c]
+__global__ __launch_bounds__(256) void dwconv3_wgrad_reduce_kernel(const float* __restrict__ slab, int nlanes, int C, float* __restrict__ dw,
+                                                                  int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // i = t * C + c: coalesced over c
+  if (i >= 9 * C) return;
+  const int t = i / C, c = i - t * C;
+  float s = 0.f;
+  for (int r = 0; r < nlanes; ++r) s += slab[(long)r * 9 * C + i];
+  float* d = dw + c * 9 + t;
+  *d = (accumulate ? *d : 0.f) + s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -571,14 +634,16 @@ int fs_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
   return FS_OK;
 }
 
-// dgamma / dbeta are overwritten
+// accumulate != 0: dgamma / dbeta are ADDED to (gradient-arena targets: no memset), else overwritten
 int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
-                     float* dgamma, float* dbeta, long M, int C, hipStream_t stream) {
+                     float* dgamma, float* dbeta, long M, int C, int accumulate, hipStream_t stream) {
   FS_REQUIRE(g && x && gamma && mean && rstd && dx && dgamma && dbeta && M > 0 && C > 0 && C % 4 == 0 && C <= 2048);
-  hipError_t e = hipMemsetAsync(dgamma, 0, C * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(dbeta, 0, C * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(dgamma, 0, C * sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(dbeta, 0, C * sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+  }
   int rpb = (int)((M + 1023) / 1024); if (rpb < 4) rpb = 4;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 2 * C * sizeof(float), stream, g, x, gamma, mean, rstd,
                      dx, dgamma, dbeta, M, C, rpb);
@@ -605,28 +670,33 @@ int fs_gelu_bwd(const float* g, const float* x, float* dx, long n, hipStream_t s
 int fs_dwconv3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int flip,
                    hipStream_t stream) {
   FS_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
-  FS_REQUIRE(C <= 4096);                                        // 9 x C weights staged in LDS (<= 144 KB)
-  int blocks = cdiv((long)B * H * W * (C / 4), 256); if (blocks > 8192) blocks = 8192;
-  const int smem = 9 * C * (int)sizeof(float);
-  static int attr_bytes = 0;
-  if (smem > 65536 && smem > attr_bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)dwconv3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    attr_bytes = smem;
-  }
-  hipLaunchKernelGGL(dwconv3_kernel, dim3(blocks), dim3(256), smem, stream, x, w, bias, y, B, H, W, C, flip);
+  const long items = (long)B * cdiv(H, DW_RY) * cdiv(W, DW_SEG);
+  const long threads = items * (C / 4);
+  FS_REQUIRE(threads < (1L << 31) * 256);
+  hipLaunchKernelGGL(dwconv3_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, w, bias, y, B, H, W, C, flip);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
-int fs_dwconv3_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int C, hipStream_t stream) {
-  FS_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && C / 4 <= 1024);
-  hipError_t e = hipMemsetAsync(dw, 0, (size_t)C * 9 * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
-  const long P = (long)B * H * W;
-  const int cw = C / 4;
-  const int threads = cw >= 256 ? cw : (256 / cw) * cw;         // whole channel rows per block, <= 1024
-  int ppb = (int)((P + 511) / 512); if (ppb < 16) ppb = 16;
-  hipLaunchKernelGGL(dwconv3_wgrad_kernel, dim3(cdiv(P, ppb)), dim3(threads), 0, stream, x, dy, dw, B, H, W, C, ppb);
+
+// number of slab rows ([9][C] floats each) fs_dwconv3_bwd_weight needs as scratch for a (B, H, W, C) problem
+int fs_dwconv3_wgrad_lanes(int B, int H, int W, int C) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4) return 0;
+  const long items = (long)B * cdiv(H, DW_RY) * cdiv(W, DW_SEG);
+  long lanes = (512L * 256) / (C / 4);           // about two blocks per CU in all
+  if (lanes < 1) lanes = 1;
+  if (lanes > items) lanes = items;
+  return (int)lanes;
+}
+
+// accumulate != 0: dw is ADDED to (gradient-arena target), else overwritten.  ws = fs_dwconv3_wgrad_lanes() * 9 * C floats of scratch.
+int fs_dwconv3_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int B, int H, int W, int C, int accumulate,
+                          hipStream_t stream) {
+  FS_REQUIRE(x && dy && dw && ws && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+  const int lanes = fs_dwconv3_wgrad_lanes(B, H, W, C);
+  const long threads = (long)lanes * (C / 4);
+  hipLaunchKernelGGL(dwconv3_wgrad_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, dy, ws, B, H, W, C, lanes);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dwconv3_wgrad_reduce_kernel, dim3(cdiv(9L * C, 256)), dim3(256), 0, stream, ws, lanes, C, dw, accumulate);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

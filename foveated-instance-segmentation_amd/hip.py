@@ -52,7 +52,7 @@ SIGNATURES = {
     "fs_add_n": "pppppl",
     "fs_upsample_slice_fwd": "piiiipiiii",
     "fs_upsample_slice_bwd": "piiiiipiii",
-    "fs_colsum": "plip",
+    "fs_colsum": "plipi",
     "fs_maxpool_fwd": "pppiiiiiiiii",
     "fs_maxpool_bwd": "pppiiiiiiiii",
     "fs_dropout": "pplfu",
@@ -66,11 +66,11 @@ SIGNATURES = {
     "fs_seg_loss_bwd": "pppppiiif",
     "fs_adam_step": "pppplfffffif",
     "fs_layernorm_fwd": "pppppplif",
-    "fs_layernorm_bwd": "ppppppppli",
+    "fs_layernorm_bwd": "pppppppplii",
     "fs_gelu_fwd": "ppl",
     "fs_gelu_bwd": "pppl",
     "fs_dwconv3_fwd": "ppppiiiii",
-    "fs_dwconv3_bwd_weight": "pppiiii",
+    "fs_dwconv3_bwd_weight": "ppppiiiii",
     "fs_residual_droppath": "pppllfu",
     "fs_attention_fwd": "pppppiiiiffu",
     "fs_attention_bwd": "ppppppppppiiiiffu",
@@ -80,7 +80,7 @@ _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 _lib = None
 # declared in the header, host-side only (no stream argument)
 HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice",
-             "fs_bn_bwd_slabs")
+             "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes")
 
 
 class HipLibraryError(RuntimeError):
@@ -113,6 +113,8 @@ def load():
     lib.fs_conv2d_kernel_choice.argtypes = [_I] * 13 + [_L]
     lib.fs_bn_bwd_slabs.restype = _I
     lib.fs_bn_bwd_slabs.argtypes = [_L, _I]
+    lib.fs_dwconv3_wgrad_lanes.restype = _I
+    lib.fs_dwconv3_wgrad_lanes.argtypes = [_I] * 4
     _lib = lib
     global _default_mode
     _default_mode = ("f32", "bf16x3", "f16x2")[lib.fs_get_conv_precision()]

@@ -242,9 +242,13 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None, dil=1, accumulate=F
     return out if out is not None else dw.permute(3, 2, 0, 1)
 
 
-def colsum(x2d_rows, C):
+def colsum(x2d_rows, C, into=None):
+    """Column sums (bias gradients).  into = a gradient-arena target: the sums are ADDED to it and None is returned."""
+    if into is not None:
+        hip.call("fs_colsum", hip.ptr(x2d_rows), x2d_rows.numel() // C, C, hip.ptr(into), 1)
+        return None
     out = torch.empty(C, device=x2d_rows.device, dtype=torch.float32)
-    hip.call("fs_colsum", hip.ptr(x2d_rows), x2d_rows.numel() // C, C, hip.ptr(out))
+    hip.call("fs_colsum", hip.ptr(x2d_rows), x2d_rows.numel() // C, C, hip.ptr(out), 0)
     return out
 
 
@@ -474,26 +478,33 @@ class ConvBnAct(Function):
 
 
 class ConvBias(Function):
-    """y = conv(x, w) + bias without normalisation (used for the FC layer as a 1x1 conv)."""
+    """y = [dropout_p](conv(x, w) + bias) without normalisation (nn.Linear as a 1x1 conv, patch embeddings, sequence-reduction convs).
+    drop_p > 0: the hidden-state Dropout that follows the layer (SegformerSelfOutput / MixFFN) runs in the conv epilogue -- same hash
+    of the output's element index as the stand-alone fs_dropout -- and its backward masks dy once before the two gradient launches."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad):
+    def forward(ctx, x, w, bias, stride, pad, drop_p=0.0, drop_key=0):
         ctx.save_for_backward(x, w)
-        ctx.sp = (stride, pad, bias is not None)
-        return conv2d_fwd(x, w, bias, stride, pad)
+        ctx.sp = (stride, pad, bias is not None, float(drop_p), int(drop_key))
+        ctx.bias_ref = bias
+        return conv2d_fwd(x, w, bias, stride, pad, float(drop_p), int(drop_key))
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        stride, pad, has_bias = ctx.sp
+        stride, pad, has_bias, drop_p, drop_key = ctx.sp
         dy = dy.contiguous()
+        if drop_p > 0.0:
+            masked = torch.empty_like(dy)
+            hip.call("fs_dropout", hip.ptr(dy), hip.ptr(masked), dy.numel(), drop_p, drop_key)
+            dy = masked
         dx = conv2d_bwd_data(dy, w, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
         tgt = _direct_grad_target(w)
         dw = conv2d_bwd_weight(x, dy, w.shape, stride, pad, out=tgt, accumulate=tgt is not None)
         if tgt is not None:
             dw = None
-        db = colsum(dy, dy.shape[-1]) if has_bias else None
-        return dx, dw, db, None, None
+        db = colsum(dy, dy.shape[-1], into=_direct_grad_target(ctx.bias_ref)) if has_bias else None
+        return dx, dw, db, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -902,6 +913,7 @@ class LayerNorm(Function):
         rstd = torch.empty(M, device=x.device, dtype=torch.float32)
         hip.call("fs_layernorm_fwd", hip.ptr(x), hip.ptr(gamma), hip.ptr(beta), hip.ptr(y), hip.ptr(mean), hip.ptr(rstd), M, C, float(eps))
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.beta_ref = beta
         return y
 
     @staticmethod
@@ -909,10 +921,14 @@ class LayerNorm(Function):
         x, gamma, mean, rstd = ctx.saved_tensors
         C = x.shape[-1]
         dx = torch.empty_like(x)
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(gamma)
+        tg, tb = _direct_grad_target(gamma), _direct_grad_target(ctx.beta_ref)
+        direct = tg is not None and tb is not None
+        dgamma = tg if direct else torch.empty_like(gamma)
+        dbeta = tb if direct else torch.empty_like(gamma)
         hip.call("fs_layernorm_bwd", hip.ptr(g.contiguous()), hip.ptr(x), hip.ptr(gamma), hip.ptr(mean), hip.ptr(rstd), hip.ptr(dx),
-                 hip.ptr(dgamma), hip.ptr(dbeta), x.numel() // C, C)
+                 hip.ptr(dgamma), hip.ptr(dbeta), x.numel() // C, C, 1 if direct else 0)
+        if direct:
+            dgamma = dbeta = None
         return dx, dgamma, dbeta, None
 
 
@@ -942,6 +958,7 @@ class DwConv3(Function):
         hip.call("fs_dwconv3_fwd", hip.ptr(x), hip.ptr(w), hip.ptr(bias), hip.ptr(y), B, H, W, C, 0)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -951,9 +968,14 @@ class DwConv3(Function):
         g = g.contiguous()
         dx = torch.empty_like(x)
         hip.call("fs_dwconv3_fwd", hip.ptr(g), hip.ptr(w), None, hip.ptr(dx), B, H, W, C, 1)
-        dw = torch.empty_like(w)
-        hip.call("fs_dwconv3_bwd_weight", hip.ptr(x), hip.ptr(g), hip.ptr(dw), B, H, W, C)
-        db = colsum(g, C) if ctx.has_bias else None
+        tgt = _direct_grad_target(w)
+        tgt = tgt if (tgt is not None and tgt.is_contiguous()) else None
+        dw = tgt if tgt is not None else torch.empty_like(w)
+        ws = torch.empty(hip.load().fs_dwconv3_wgrad_lanes(B, H, W, C) * 9 * C, device=x.device, dtype=torch.float32)
+        hip.call("fs_dwconv3_bwd_weight", hip.ptr(x), hip.ptr(g), hip.ptr(dw), hip.ptr(ws), B, H, W, C, 1 if tgt is not None else 0)
+        if tgt is not None:
+            dw = None
+        db = colsum(g, C, into=_direct_grad_target(ctx.bias_ref)) if ctx.has_bias else None
         return dx, dw, db
 
 

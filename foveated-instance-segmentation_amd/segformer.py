@@ -41,11 +41,13 @@ class HipLinear(nn.Module):
         self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(torch.zeros(cout))
 
-    def forward(self, x):
+    def forward(self, x, drop_p=0.0, drop_path=""):
+        """drop_p > 0 (training): the nn.Dropout(drop_p) that follows this layer, keyed by its module path, fused into the epilogue."""
         cin = x.shape[-1]
         lead = x.shape[:-1]
         w4 = self.weight.view(self.weight.shape[0], cin, 1, 1)
-        y = ops.ConvBias.apply(x.reshape(1, -1, 1, cin), w4, self.bias, 1, 0)
+        key = ops.DropoutState.key(ops.layer_id_from_name(drop_path)) if drop_p > 0 else 0
+        y = ops.ConvBias.apply(x.reshape(1, -1, 1, cin), w4, self.bias, 1, 0, float(drop_p), key)
         return y.view(*lead, -1)
 
 
@@ -102,7 +104,7 @@ class SelfOutput(nn.Module):
         self._path = ""
 
     def forward(self, x):
-        return _drop(self.dense(x), HIDDEN_DROPOUT, self.training, self._path + ".dropout")
+        return self.dense(x, HIDDEN_DROPOUT if self.training else 0.0, self._path + ".dropout")
 
 
 class SegformerAttention(nn.Module):
@@ -135,8 +137,7 @@ class MixFFN(nn.Module):
     def forward(self, x):
         y = ops.Gelu.apply(self.dwconv(self.dense1(x)))
         y = _drop(y, HIDDEN_DROPOUT, self.training, self._path + ".dropout1")
-        y = self.dense2(y)
-        return _drop(y, HIDDEN_DROPOUT, self.training, self._path + ".dropout2")
+        return self.dense2(y, HIDDEN_DROPOUT if self.training else 0.0, self._path + ".dropout2")
 
 
 class SegformerLayer(nn.Module):

@@ -182,7 +182,8 @@ int fs_upsample_slice_fwd(const float* src, int B, int th, int tw, int C, float*
                           fs_stream_t stream);
 int fs_upsample_slice_bwd(const float* g, int B, int Ho, int Wo, int Cg, int coff, float* dsrc, int th, int tw, int C,
                           fs_stream_t stream);
-int fs_colsum(const float* x, long M, int C, float* out, fs_stream_t stream);
+/* column sums of M rows of C floats (bias gradients); accumulate != 0: ADDED to out (a gradient-arena target), else overwritten. */
+int fs_colsum(const float* x, long M, int C, float* out, int accumulate, fs_stream_t stream);
 /* nn.MaxPool2d(k, stride, pad) on NHWC; arg = flat input pixel index of the maximum (int32), used by the backward.
  * torchvision ResNet stem behind models/deeplab.py:15. */
 int fs_maxpool_fwd(const float* x, float* out, int* arg, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad,
@@ -217,15 +218,20 @@ int fs_seg_loss_bwd(const float* pred, const long long* gt, const float* coef, c
 /* nn.LayerNorm(C, eps) over the last dim of M rows; mean/rstd (M floats each) kept for the backward. */
 int fs_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long M, int C,
                      float eps, fs_stream_t stream);
+/* accumulate != 0: dgamma / dbeta are ADDED to (gradient-arena targets), else overwritten. */
 int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
-                     float* dgamma, float* dbeta, long M, int C, fs_stream_t stream);
+                     float* dgamma, float* dbeta, long M, int C, int accumulate, fs_stream_t stream);
 /* exact (erf) GELU. */
 int fs_gelu_fwd(const float* x, float* y, long n, fs_stream_t stream);
 int fs_gelu_bwd(const float* g, const float* x, float* dx, long n, fs_stream_t stream);
 /* depthwise Conv2d(C, C, 3, 1, 1, groups=C) on NHWC, weight (C,1,3,3); flip=1 gives the input gradient. */
 int fs_dwconv3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int flip,
                    fs_stream_t stream);
-int fs_dwconv3_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int C, fs_stream_t stream);
+/* weight gradient: ws = fs_dwconv3_wgrad_lanes(B, H, W, C) * 9 * C floats of scratch (per-thread partial sums, added up by a second
+ * launch: no atomics, no memset); accumulate != 0: dw is ADDED to, else overwritten. */
+int fs_dwconv3_wgrad_lanes(int B, int H, int W, int C);      /* host only */
+int fs_dwconv3_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int B, int H, int W, int C, int accumulate,
+                          fs_stream_t stream);
 /* out = x + DropPath_p(y) (per-sample keep, hash keyed); x NULL -> out = scaled y (the backward of the y branch). */
 int fs_residual_droppath(const float* x, const float* y, float* out, long n, long per_sample, float drop_p, uint32_t key,
                          fs_stream_t stream);
