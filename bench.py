@@ -45,12 +45,13 @@ def _profiled_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this same command
     (profiles/rNN/hbm_traffic_serial*.json; FETCH_SIZE doubled per the gfx950 correction).  PMC counters
     cannot be read from inside the benchmark process, so this is the offline measurement, or None."""
-    for rel in ("profiles/r02/hbm_traffic_serial.json", "profiles/r01/hbm_traffic_serial.json"):
+    for rel in ("profiles/r03/hbm_traffic_serial.json", "profiles/r02/hbm_traffic_serial.json", "profiles/r01/hbm_traffic_serial.json"):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 table = json.load(f)
             # all template instances of one kernel: "name" matches "name<...>", "name<a, b" matches "name<a, b, c>"
-            hits = [v for k, v in table.items() if k == kernel or k.startswith(kernel + "<") or ("<" in kernel and k.startswith(kernel))]
+            names = kernel if isinstance(kernel, (list, tuple)) else [kernel]
+            hits = [v for k, v in table.items() if any(k == n or k.startswith(n + "<") or ("<" in n and k.startswith(n)) for n in names)]
             n = sum(v["launches"] for v in hits)
             avg = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n
             return {"hbm_bytes_per_launch": int(avg), "source": rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
@@ -64,7 +65,9 @@ def _profiled_mfma_busy(mode, kernel):
     (profiles/r02/pmc/sq_<mode>_<kernel>_fwd_shape0.txt: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)), or None."""
     import ast
     import re
-    rel = f"profiles/r02/pmc/sq_{mode}_{kernel}_fwd_shape0.txt"
+    rel = f"profiles/r03/pmc/sq_{mode}_{kernel}_fwd_shape0.txt"
+    if not os.path.exists(os.path.join(ROOT, rel)):
+        rel = f"profiles/r02/pmc/sq_{mode}_{kernel}_fwd_shape0.txt"
     try:
         vals = {}
         for line in open(os.path.join(ROOT, rel)):
@@ -401,9 +404,9 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
         # every 3x3 stride-1 layer of this workload has an even width: in bf16x3 all of them take the F(2,3) row kernel, in f16x2 those
         # with >= 128 source channels do (csrc/conv_wino.hip: fs_wino_eligible) and the rest the plain halo kernel
         wino = os.environ.get("FS_WINOGRAD", "1") != "0"
-        kname = "conv3x3_wino_kernel" if wino else "conv3x3_halo_kernel"
-        what = (f"conv3x3_wino_kernel<{tag}> (3x3 stride-1 forward + bwd-data, halo-tiled implicit GEMM with F(2,3) minimal filtering along the "
-                "row: 12 of the direct form's 18 MFMA steps per pixel pair are executed"
+        kname = ["conv3x3_wino_kernel", "conv3x3_wino8_kernel"] if wino else "conv3x3_halo_kernel"
+        what = (f"conv3x3_wino_kernel<{tag}> (+ its eight-wave form conv3x3_wino8_kernel on wide layers; 3x3 stride-1 forward + bwd-data, halo-tiled "
+                "implicit GEMM with F(2,3) minimal filtering along the row: 12 of the direct form's 18 MFMA steps per pixel pair are executed"
                 + ("; layers below 128 source channels run conv3x3_halo_kernel, the direct form" if mode == "f16x2" else "") + f"; {how}; ")
         if not wino:
             what = f"conv3x3_halo_kernel<{tag}> (3x3 stride-1 forward + bwd-data, halo-tiled implicit GEMM; {how}; "

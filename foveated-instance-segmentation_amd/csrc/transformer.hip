@@ -237,16 +237,24 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const float* __restr
   for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(dst + (long)t * C) = acc[t];
 }
 
-// dw[c][t] (+)= sum over slab rows of slab[row][t][c]
+// dw[c][t] (+)= sum over slab rows of slab[row][t][c]: block = 32 consecutive (t, c) elements x 8 row groups
 __global__ __launch_bounds__(256) void dwconv3_wgrad_reduce_kernel(const float* __restrict__ slab, int nlanes, int C, float* __restrict__ dw,
                                                                   int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // i = t * C + c: coalesced over c
-  if (i >= 9 * C) return;
-  const int t = i / C, c = i - t * C;
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, rgp = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + e;                          // i = t * C + c: 128-byte segments per slab row
   float s = 0.f;
-  for (int r = 0; r < nlanes; ++r) s += slab[(long)r * 9 * C + i];
-  float* d = dw + c * 9 + t;
-  *d = (accumulate ? *d : 0.f) + s;
+  if (i < 9 * C)
+    for (int r = rgp; r < nlanes; r += 8) s += slab[(long)r * 9 * C + i];
+  red[rgp][e] = s;
+  __syncthreads();
+  if (rgp == 0 && i < 9 * C) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k][e];
+    const int t = i / C, c = i - t * C;
+    float* d = dw + c * 9 + t;
+    *d = (accumulate ? *d : 0.f) + s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -682,7 +690,7 @@ int fs_dwconv3_fwd(const float* x, const float* w, const float* bias, float* y, 
 int fs_dwconv3_wgrad_lanes(int B, int H, int W, int C) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4) return 0;
   const long items = (long)B * cdiv(H, DW_RY) * cdiv(W, DW_SEG);
-  long lanes = (512L * 256) / (C / 4);           // about two blocks per CU in all
+  long lanes = (256L * 256) / (C / 4);           // about one 256-thread block per CU in all
   if (lanes < 1) lanes = 1;
   if (lanes > items) lanes = items;
   return (int)lanes;
@@ -696,7 +704,7 @@ int fs_dwconv3_bwd_weight(const float* x, const float* dy, float* dw, float* ws,
   const long threads = (long)lanes * (C / 4);
   hipLaunchKernelGGL(dwconv3_wgrad_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, dy, ws, B, H, W, C, lanes);
   FS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dwconv3_wgrad_reduce_kernel, dim3(cdiv(9L * C, 256)), dim3(256), 0, stream, ws, lanes, C, dw, accumulate);
+  hipLaunchKernelGGL(dwconv3_wgrad_reduce_kernel, dim3(cdiv(9L * C, 32)), dim3(256), 0, stream, ws, lanes, C, dw, accumulate);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
