@@ -47,6 +47,9 @@ struct WinoArgs {
 #ifdef FS_WINO_TRACE
   long long* dbg;                  // [workgroup][32] phase time stamps of wave 0 (tools/wino_trace.sh)
 #endif
+#ifdef FS_WINO_CLOCK
+  long long* clk;                  // [workgroup][2] kernel-long deltas of s_memtime and s_memrealtime (tools/wino_clock.sh)
+#endif
 };
 
 #ifdef FS_WINO_TRACE
@@ -134,6 +137,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int l31 = lane & 31, lh = lane >> 5;
 #ifdef FS_WINO_TRACE
   bool first_tile = true;
+#endif
+#ifdef FS_WINO_CLOCK
+  const long long ck0 = clock64(), rt0 = wall_clock64();      // s_memtime (shader cycles), s_memrealtime (100 MHz)
 #endif
   WINO_STAMP(0);
   // ---- persistent schedule: XCD x owns a contiguous range of tiles (the column tiles of one pixel tile and neighbouring halos meet
@@ -459,6 +465,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #endif
     wg = wg_next; mt = mt_n; n0 = n0_n; bvoff = bvoff_n; par ^= 1;
   }
+#ifdef FS_WINO_CLOCK
+  // in-kernel clock (MI355X_MICROARCH.md, DVFS give-back (6)): delta s_memtime / delta s_memrealtime x 100 MHz, to a buffer nothing else reads
+  if (tid == 0 && a.clk != nullptr) { a.clk[2 * blockIdx.x] = clock64() - ck0; a.clk[2 * blockIdx.x + 1] = wall_clock64() - rt0; }
+#endif
 }
 
 // ---- eight-wave variant with the split work INSIDE the MFMA phase (bf16x3, round 3) ----------------------------------------------
@@ -821,6 +831,11 @@ int wino_grid_slots() {
   return slots[dev];
 }
 
+#ifdef FS_WINO_CLOCK
+long long* g_clk = nullptr;
+int g_clk_n = 0;
+#endif
+
 // Which 3x3 layers take the eight-wave kernel: bf16x3, more than 64 output channels (128-column workgroups) and at least 8 channel
 // chunks -- measured in one gpurun call against the persistent 4-wave kernel: 256 -> 256 @ 20x20 139 vs 150 us, 512 -> 512 @ 10x10
 // 150 vs 165 us, 960 -> 240 @ 80x80 5.81 vs 5.92 ms; 128 -> 128 @ 40x40 the same; its 64-column form (k-halves) 19 % slower on
@@ -868,6 +883,10 @@ int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int 
     }
   }
   const unsigned grid = (unsigned)(ntile < slots ? ntile : slots);
+#ifdef FS_WINO_CLOCK
+  if (g_clk == nullptr && hipMalloc(&g_clk, sizeof(long long) * 2 * 4096) != hipSuccess) return FS_ERR_ARG;
+  a.clk = g_clk; g_clk_n = (int)grid;
+#endif
 #ifdef FS_WINO_TRACE
   static long long* dbg = nullptr;
   const long nwg = grid;
@@ -898,6 +917,20 @@ int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int 
 }
 
 }  // namespace
+
+#ifdef FS_WINO_CLOCK
+// diagnostic build only (tools/wino_clock.sh): median over the workgroups of the LAST 4-wave launch of delta s_memtime / delta s_memrealtime
+extern "C" double fs_debug_wino_clock_ghz() {
+  if (g_clk == nullptr || g_clk_n <= 0) return 0.0;
+  static long long host[2 * 4096];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, g_clk, sizeof(long long) * 2 * g_clk_n, hipMemcpyDeviceToHost) != hipSuccess) return 0.0;
+  double r[4096]; int n = 0;
+  for (int i = 0; i < g_clk_n; ++i) if (host[2 * i + 1] > 0) r[n++] = (double)host[2 * i] / (double)host[2 * i + 1] * 0.1;
+  if (n == 0) return 0.0;
+  for (int i = 1; i < n; ++i) { double v = r[i]; int j = i - 1; while (j >= 0 && r[j] > v) { r[j + 1] = r[j]; --j; } r[j + 1] = v; }
+  return r[n / 2];
+}
+#endif
 
 // f16x2 spends half the MFMAs per product, so the doubled split work of the transform only pays from 4 channel chunks up
 // (profiles/r02/winograd_kernel_times.txt: 64 -> 64 @ 80x80 103 us against 94 us, 128 -> 128 @ 40x40 90.6 against 93.7)
