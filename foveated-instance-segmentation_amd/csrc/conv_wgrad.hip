@@ -257,6 +257,231 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
   }
 }
 
+// ---- 3x3 / stride 1 / pad 1 weight gradient in the F(2,3) transform domain (bf16x3, even widths; round 3) -------------------------
+// The conv kernels are power-limited, so what shortens them is issuing fewer MFMAs.  The forward's row transform
+//     out[2j] = m0 + m1 + m2,  out[2j+1] = m1 - m2 - m3,   m_c = sum_{ky, ci} T_c(x row y+ky-1, pair j) * U_c(g row ky)
+// gives, for the loss gradient e0 = dY[2j], e1 = dY[2j+1] of a PAIR of output pixels,
+//     dU_c[ky][ci][co] = sum over pairs of T_c[ci] * dM_c[co],     dM = (e0, e0 + e1, e0 - e1, -e1),
+//     dW[ky][0] = dU0 + (dU1 + dU2)/2,   dW[ky][1] = (dU1 - dU2)/2,   dW[ky][2] = (dU1 + dU2)/2 + dU3      (U = G g transposed)
+// i.e. 12 accumulator tiles over K = pixel PAIRS instead of 9 over K = pixels: 2/3 of the MFMA work.  T and dM are formed in fp32 and
+// then split into the three bf16 planes (both operands keep 24 bits), as in conv_wino.hip.
+//   workgroup = 512 threads = 8 waves = 4 quadrants of the 64 (ci) x 64 (co) tile x 2 component pairs {0,1} / {2,3}; a wave holds
+//   3 filter rows x 2 components = 6 accumulators.  Patch = Ph rows x PP pairs <= 32 pairs, halo (Ph + 2) x PP <= 48 pair slots.
+//   LDS: T  [3 planes][4 comps][2 channel halves][48 slots][32 ch] 73.7 KB + dM [3][4][2][32 pairs][32 ch] 49.2 KB: one workgroup per CU.
+//   Operand fragments by ds_read_b64_tr_b16 exactly as in conv_wgrad_class_kernel (K = pair index contiguous per lane).
+constexpr int WP_SLOTS = 48, WP_PAIRS = 32;
+constexpr int XT_HALF = WP_SLOTS * 64, XT_COMP = 2 * XT_HALF, XT_PLANE = 4 * XT_COMP;      // bytes
+constexpr int DM_HALF = WP_PAIRS * 64, DM_COMP = 2 * DM_HALF, DM_PLANE = 4 * DM_COMP;
+struct WwArgs {
+  const float* x; const float* dy; float* dw;
+  int B, H, W, Cin, Cout;
+  int Ph, PP, tiles_y, tiles_x, npatch, patches_per_split, tiles_ci, tiles_co;
+  unsigned x_bytes, dy_bytes, magic_pp;
+};
+
+template <class P>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_wino_kernel(WwArgs a) {
+  static_assert(!P::SCALED, "bf16x3 only");
+  typedef typename P::x8 X8;
+  typedef typename P::x4 X4;
+  constexpr int NPL = P::NPL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // T image, then dM image
+  constexpr int DM0 = NPL * XT_PLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int hw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cp = hw >> 2, wm = (hw >> 1) & 1, wn = hw & 1;
+  const int ntile = a.tiles_ci * a.tiles_co;
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd = nwg >> 3, rmd = nwg & 7;
+  const int wg = (xcd < rmd ? xcd * (qd + 1) : rmd * (qd + 1) + (xcd - rmd) * qd) + loc;
+  const int split = wg / ntile, tile = wg - split * ntile;
+  const int tci = tile / a.tiles_co, tco = tile - tci * a.tiles_co;
+  const int ci0 = tci * 64, co0 = tco * 64;
+  const int p_begin = split * a.patches_per_split;
+  const int p_end = (p_begin + a.patches_per_split < a.npatch) ? p_begin + a.patches_per_split : a.npatch;
+  const int nslots = (a.Ph + 2) * a.PP, npairs = a.Ph * a.PP, nk = (npairs + 15) >> 4;
+  const int tpi = a.tiles_y * a.tiles_x;
+
+  // ---- loaders: X item i = (halo slot (tid >> 4) + 32 i, channel quad tid & 15), 4 pixels d0..d3 each; dY item = (pair tid >> 4, quad) ----
+  const int cq = tid & 15;
+  int xcode[2], xdelta[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int slot = (tid >> 4) + 32 * i;
+    const int hy = div_small1(slot, a.magic_pp), pj = slot - hy * a.PP;
+    xcode[i] = (slot < nslots && ci0 + 4 * cq < a.Cin) ? ((hy << 16) | pj) : -1;
+    xdelta[i] = ((hy * a.W + 2 * pj) * a.Cin + ci0 + 4 * cq) * 4;        // relative to pixel (y0 - 1, x0 - 1)
+  }
+  int ycode, ydelta;
+  {
+    const int pr = tid >> 4;
+    const int py = div_small1(pr, a.magic_pp), px = pr - py * a.PP;
+    ycode = (pr < npairs && co0 + 4 * cq < a.Cout) ? ((py << 16) | px) : -1;
+    ydelta = ((py * a.W + 2 * px) * a.Cout + co0 + 4 * cq) * 4;
+  }
+  const int xw = (cq >> 3) * XT_HALF + (tid >> 4) * 64 + (cq & 7) * 8;        // + i * 32 slots * 64 + comp * XT_COMP + plane * XT_PLANE
+  const int yw = DM0 + (cq >> 3) * DM_HALF + (tid >> 4) * 64 + (cq & 7) * 8;
+  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.x, a.x_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(a.dy, a.dy_bytes);
+
+  // ---- transposed-read lane constants (conv_wgrad_class_kernel): 16-lane group g reads k rows q = 0..3, columns cb + 4 pp .. + 3 ----
+  const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, g = lane >> 4, lh = g >> 1, cb = 16 * (g & 1);
+  int xb[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      int pidx = 16 * ks + 8 * lh + 4 * t + q;
+      if (pidx >= npairs) pidx = 0;             // padded k: dM is zero there, any valid T address will do
+      const int py = div_small1(pidx, a.magic_pp), px = pidx - py * a.PP;
+      xb[ks][t] = wm * XT_HALF + (py * a.PP + px) * 64 + (cb + 4 * pp) * 2;
+    }
+  const int yb = DM0 + wn * DM_HALF + (8 * lh + q) * 64 + (cb + 4 * pp) * 2;      // + ks * 1024 + t * 256 + comp * DM_COMP + plane * DM_PLANE
+  const int rowoff = a.PP * 64;                                                   // one halo row down (filter row ky)
+
+  f32x16 acc[3][2];       // [filter row][component of this wave's pair]
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ky][cc][r] = 0.f;
+
+  auto tr = [&](int off) -> X4 { return P::tr_read(lds + off); };
+  auto cat = [](X4 lo, X4 hi) -> X8 { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); };
+
+  int pb_, pty, ptx;
+  {
+    pb_ = p_begin / tpi;
+    const int trem = p_begin - pb_ * tpi;
+    pty = trem / a.tiles_x; ptx = trem - pty * a.tiles_x;
+  }
+  f32x4 rx[2][4], ry[2];
+  auto load_patch = [&]() {
+    const int b = pb_, y0 = pty * a.Ph, x0 = ptx * 2 * a.PP;
+    if (++ptx >= a.tiles_x) { ptx = 0; if (++pty >= a.tiles_y) { pty = 0; ++pb_; } }
+    const int xbase = ((b * a.H + y0 - 1) * a.W + x0 - 1) * a.Cin * 4;              // may be negative (padding); base + delta is not, where valid
+    const int ybase = ((b * a.H + y0) * a.W + x0) * a.Cout * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i == 1 && hw >= 4) continue;                                               // slots 32..47 belong to waves 0..3 (wave-uniform)
+      const int iy = y0 - 1 + (xcode[i] >> 16), ix = x0 - 1 + 2 * (xcode[i] & 0xffff);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = xcode[i] >= 0 && iy >= 0 && iy < a.H && ix + e >= 0 && ix + e < a.W;
+        rx[i][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? xbase + xdelta[i] + e * a.Cin * 4 : (int)OOB, 0, 0));
+      }
+    }
+    const int y = y0 + (ycode >> 16), xx = x0 + 2 * (ycode & 0xffff);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const bool ok = ycode >= 0 && y < a.H && xx + e < a.W;
+      ry[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, ok ? ybase + ydelta + e * a.Cout * 4 : (int)OOB, 0, 0));
+    }
+  };
+
+  const int niter = p_end - p_begin;
+  if (niter > 0) load_patch();
+  for (int it = 0; it < niter; ++it) {
+    __syncthreads();     // every wave has finished reading the previous patch's images
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i == 1 && hw >= 4) continue;
+      const f32x4 d0 = rx[i][0], d1 = rx[i][1], d2 = rx[i][2], d3 = rx[i][3];
+      const f32x4 T[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        X4 p[NPL];
+        P::split4(T[c], p);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&lds[xw + i * 2048 + c * XT_COMP + pl * XT_PLANE]) = p[pl];
+      }
+    }
+    {
+      const f32x4 e0 = ry[0], e1 = ry[1];
+      const f32x4 M[4] = {e0, e0 + e1, e0 - e1, -e1};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        X4 p[NPL];
+        P::split4(M[c], p);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&lds[yw + c * DM_COMP + pl * DM_PLANE]) = p[pl];
+      }
+    }
+    __syncthreads();
+    if (it + 1 < niter) load_patch();        // the next patch travels while this one is multiplied
+
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks < nk) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const int c = 2 * cp + cc;
+          X8 fb[NPL], fa[2][NPL];
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl)
+            fb[pl] = cat(tr(yb + ks * 1024 + c * DM_COMP + pl * DM_PLANE), tr(yb + ks * 1024 + 256 + c * DM_COMP + pl * DM_PLANE));
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl)
+            fa[0][pl] = cat(tr(xb[ks][0] + c * XT_COMP + pl * XT_PLANE), tr(xb[ks][1] + c * XT_COMP + pl * XT_PLANE));
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            if (ky + 1 < 3) {
+              const int ro = (ky + 1) * rowoff;
+#pragma unroll
+              for (int pl = 0; pl < NPL; ++pl)
+                fa[(ky + 1) & 1][pl] = cat(tr(xb[ks][0] + ro + c * XT_COMP + pl * XT_PLANE), tr(xb[ks][1] + ro + c * XT_COMP + pl * XT_PLANE));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const X8(&A)[NPL] = fa[ky & 1];
+#pragma unroll
+            for (int t = 0; t < P::NTERM; ++t) acc[ky][cc] = P::mfma(A[P::ta(t)], fb[P::tb(t)], acc[ky][cc]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- dU -> dW contributions of this wave's two components, split-K atomics ----
+  const int co = co0 + 32 * wn + (lane & 31);
+  if (co < a.Cout && p_begin < p_end) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (ci >= a.Cin) continue;
+        const float u0 = acc[ky][0][r], u1 = acc[ky][1][r];
+        // cp = 0: (dU0, dU1) -> dW0 += dU0 + dU1/2, dW1 += dU1/2, dW2 += dU1/2;   cp = 1: (dU2, dU3) -> dW0 += dU2/2, dW1 -= dU2/2, dW2 += dU2/2 + dU3
+        const float h = cp == 0 ? 0.5f * u1 : 0.5f * u0;
+        const float w0 = cp == 0 ? u0 + h : h;
+        const float w1 = cp == 0 ? h : -h;
+        const float w2 = cp == 0 ? h : h + u1;
+        float* d = a.dw + ((long)(ky * 3) * a.Cin + ci) * a.Cout + co;
+        atomicAdd(d, w0);
+        atomicAdd(d + (long)a.Cin * a.Cout, w1);
+        atomicAdd(d + 2L * a.Cin * a.Cout, w2);
+      }
+  }
+}
+
+// Ph rows x PP pairs <= 32 pairs, (Ph + 2) PP <= 48 slots, PP >= 1: fewest patches, then largest fill
+void choose_wgrad_wino_patch(int H, int W, int& Ph, int& PP) {
+  const int wp = W / 2;
+  long best = -1;
+  Ph = 1; PP = 1;
+  for (int pp = 1; pp <= 32 && pp <= wp; ++pp)
+    for (int ph = 1; ph <= 32 && ph <= H + 1; ++ph) {
+      if (ph * pp > WP_PAIRS || (ph + 2) * pp > WP_SLOTS) continue;
+      const long patches = (long)cdiv(H, ph) * cdiv(wp, pp);
+      const long cost = patches * (cdiv(ph * pp, 16) * 2 + 1) * 1000 - ph * pp;      // k-steps of 16 pairs + a fixed cost per patch
+      if (best < 0 || cost < best) { best = cost; Ph = ph; PP = pp; }
+    }
+}
+
 // Patch choice: Ph*Pw <= 64 pixels (padded to a multiple of 16 for the k-steps), halo (Ph+2)(Pw+2) <= 112 slots;
 // minimise patches * (k-steps per patch + 1.5).
 void choose_wgrad_patch(int H, int W, int NR, int NS, int& Ph, int& Pw) {
@@ -332,5 +557,43 @@ int fs_wgrad_split(int mode, const float* x, const float* dy, float* dw, int B, 
   a.x_bytes = (unsigned)((size_t)B * H * W * Cin * 4);
   a.dy_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * 4);
   const int ntile = a.tiles_ci * a.tiles_co;
+  static const int wino_pol = [] { const char* e = getenv("FS_WGRAD_WINO"); return e ? atoi(e) : 1; }();      // read once (kernel A/B): 0 never, 2 always
+  const bool wino_wgrad = wino_pol != 0, wino_wgrad_all = wino_pol == 2;
+  if (mode == 1 && wino_wgrad && R == 3 && S == 3 && stride == 1 && pad == 1 && H == Ho && W == Wo && W % 2 == 0 && W >= 2) {
+    // bf16x3, even width: the transform-domain kernel (2/3 of the MFMAs)
+    WwArgs w;
+    w.x = x; w.dy = dy; w.dw = dw; w.B = B; w.H = H; w.W = W; w.Cin = Cin; w.Cout = Cout;
+    choose_wgrad_wino_patch(H, W, w.Ph, w.PP);
+    w.tiles_y = cdiv(H, w.Ph); w.tiles_x = cdiv(W / 2, w.PP);
+    w.npatch = B * w.tiles_y * w.tiles_x;
+    w.tiles_ci = a.tiles_ci; w.tiles_co = a.tiles_co;
+    w.x_bytes = a.x_bytes; w.dy_bytes = a.dy_bytes;
+    w.magic_pp = div_magic1(w.PP);
+    int nsplit = 256 / ntile;                  // one 512-thread workgroup per CU
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > w.npatch) nsplit = w.npatch;
+    w.patches_per_split = cdiv(w.npatch, nsplit);
+    nsplit = cdiv(w.npatch, w.patches_per_split);
+    // Measured against conv_wgrad_class_kernel in one gpurun call (us, bf16x3, B = 64): 64->64 @ 80x80 207 vs 183, 128->128 @ 40x40 195 vs
+    // 178, 256->256 @ 20x20 218 vs 191, 512->512 @ 10x10 217 vs 209 -- SLOWER where a workgroup sees few patches (one 8-wave workgroup per
+    // CU pays more per barrier round than two independent 4-wave ones, and the doubled split work is not hidden) -- but 960->240 @ 80x80
+    // 7.0 vs 8.1 ms: long pixel loops per channel tile.  So only layers with >= 64 patches per workgroup come here (the C1 heads: 960 -> 240 at B >= 4).
+    if (w.patches_per_split < 64 && !wino_wgrad_all) goto direct;
+    constexpr int lds = PrecX3::NPL * (XT_PLANE + DM_PLANE);
+    {
+      static unsigned long long done = 0ull;
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess) return FS_ERR_ARG;
+      if (dev < 0 || dev >= 64 || !((done >> dev) & 1ull)) {
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_wino_kernel<PrecX3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (attr != hipSuccess) return (int)attr;
+        if (dev >= 0 && dev < 64) done |= 1ull << dev;
+      }
+    }
+    hipLaunchKernelGGL((conv_wgrad_wino_kernel<PrecX3>), dim3((unsigned)(ntile * nsplit)), dim3(512), lds, stream, w);
+    FS_LAUNCH_CHECK();
+    return FS_OK;
+  }
+direct:
   return mode == 2 ? run_classes<PrecF16>(a, ntile, R, S, stride, pad, stream) : run_classes<PrecX3>(a, ntile, R, S, stride, pad, stream);
 }
