@@ -51,6 +51,7 @@ struct ConvArgs {
   uint32_t drop_thresh, drop_key;   // thresh 0 = no dropout
   hipStream_t stream_ = nullptr;    // host only
   float* stats_ = nullptr;          // host only: BN partial-sum slab (affine forward)
+  const FsBnSums* bn_ = nullptr;    // host only: bwd-data writes the consumer BatchNorm's backward sums into stats_ (F(2,3) kernels)
   void* ws_ = nullptr;              // host only: caller's scratch for the pre-split weight pack (may be null)
   long ws_bytes_ = 0;
   const unsigned* w_amax_ = nullptr;   // host only: max|w| bits kept by the caller (f16x2 mode), may be null
@@ -1077,7 +1078,8 @@ int launch_affine(const ConvArgs& c, long M) {
   }
   if (use_wino(c))
     return fs_wino_conv3x3(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cs, c.Cd,
-                           c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key, c.stream_);
+                           c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key, c.bn_, c.stream_);
+  if (c.bn_ != nullptr) return FS_ERR_ARG;        // the caller asked for fused sums on a shape fs_conv2d_bwd_data_bnsum_slabs reported 0 for
   if (use_halo(c))
     return fs_halo_conv3x3(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cs, c.Cd,
                            c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key,
@@ -1254,8 +1256,9 @@ int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float
 }
 
 // include/fovealseg.h: fs_conv2d_bwd_data   (dX has the forward input's shape B,H,W,Cin)
-int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
-                       int Cout, int R, int S, int stride, int pad, int dil, void* ws, long ws_bytes, const unsigned* w_amax, hipStream_t stream) {
+static int conv2d_bwd_data_impl(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
+                                int Cout, int R, int S, int stride, int pad, int dil, void* ws, long ws_bytes, const unsigned* w_amax,
+                                const FsBnSums* bn, float* slab, hipStream_t stream) {
   FS_REQUIRE(dy && w && dx && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
   FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
   ConvArgs a{dy, w, nullptr, dx, B, Ho, Wo, Cout, H, W, Cin, R, S, stride, pad, dil, 1, 1.f, 0u, 0u};
@@ -1263,7 +1266,9 @@ int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H,
   const long M = (long)B * H * W;
   a.stream_ = stream;
   a.ws_ = ws; a.ws_bytes_ = ws_bytes; a.w_amax_ = w_amax;
+  a.bn_ = bn; a.stats_ = slab;
   if (aligned_ok(a)) return launch_affine(a, M);
+  FS_REQUIRE(bn == nullptr);
   dim3 grid(cdiv(M, BM), cdiv(Cin, BN));
   if ((Cin % 4 == 0) && (Cout % 4 == 0))
     hipLaunchKernelGGL(conv_igemm_kernel<true>, grid, dim3(256), 0, stream, a);
@@ -1271,6 +1276,34 @@ int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H,
     hipLaunchKernelGGL(conv_igemm_kernel<false>, grid, dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;
+}
+
+int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
+                       int Cout, int R, int S, int stride, int pad, int dil, void* ws, long ws_bytes, const unsigned* w_amax, hipStream_t stream) {
+  return conv2d_bwd_data_impl(dy, w, dx, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws, ws_bytes, w_amax, nullptr, nullptr, stream);
+}
+
+// include/fovealseg.h: rows of the slab fs_conv2d_bwd_data_bnsum writes for this problem, 0 = this shape's kernel cannot form the sums
+int fs_conv2d_bwd_data_bnsum_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                                   long ws_bytes) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dil != 1 || Cin % 4) return 0;
+  ConvArgs a{nullptr, nullptr, nullptr, nullptr, B, Ho, Wo, Cout, H, W, Cin, R, S, stride, pad, dil, 1, 1.f, 0u, 0u};
+  static unsigned char dummy;
+  a.ws_ = ws_bytes > 0 ? &dummy : nullptr; a.ws_bytes_ = ws_bytes;
+  if (!aligned_ok(a) || (use_tapset(a) && !use_halo(a)) || !use_wino(a)) return 0;
+  return fs_wino_stats_slabs(g_conv_precision, B, H, W, Cout, Cin);      // bwd-data: source channels = Cout, destination = Cin
+}
+
+// include/fovealseg.h: fs_conv2d_bwd_data + the BatchNorm-backward column sums of the layer that produced x (dx is that layer's dz)
+int fs_conv2d_bwd_data_bnsum(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R,
+                             int S, int stride, int pad, int dil, void* ws, long ws_bytes, const unsigned* w_amax, const float* bn_y,
+                             const unsigned char* bn_mask, const float* bn_mean, const float* bn_invstd, float* slab, const float* add_src,
+                             const unsigned char* add_mask, hipStream_t stream) {
+  FS_REQUIRE((bn_y != nullptr || add_src != nullptr) && (add_mask == nullptr || add_src != nullptr));
+  FS_REQUIRE(bn_y == nullptr || (bn_mean && bn_invstd && slab));
+  FS_REQUIRE(fs_conv2d_bwd_data_bnsum_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes) > 0);
+  const FsBnSums bn{bn_y, bn_mask, bn_mean, bn_invstd, add_src, add_mask};
+  return conv2d_bwd_data_impl(dy, w, dx, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws, ws_bytes, w_amax, &bn, slab, stream);
 }
 
 // include/fovealseg.h: fs_conv2d_bwd_weight   (dw is overwritten, or added to when accumulate != 0)

@@ -23,12 +23,14 @@ int fs_weight_amax_segments_impl(const float* arena, const long* offsets, const 
 
 // ---- conv_wino.hip: the same problem class with F(2,3) minimal filtering along the row (12 MFMA steps per pixel pair instead of 18).
 // Even W >= 4, B*(H+1) < 65536, channel counts multiples of 4, K >= 32 (K >= 128 in f16x2); FS_WINOGRAD=0 switches it off.
+// optional epilogue mode of the bwd-data call: BatchNorm-backward column sums of the layer whose output gradient is being written
+struct FsBnSums { const float* y; const unsigned char* mask; const float* mean; const float* invstd; const float* add_src; const unsigned char* add_mask; };
 bool fs_wino_eligible(int mode, int B, int H, int W, int Cs, int Cd);
 long fs_wino_pack_bytes(int mode, int Cs, int Cd);
 int fs_wino_stats_slabs(int mode, int B, int H, int W, int Cs, int Cd);
 int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
                     int B, int H, int W, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh,
-                    uint32_t drop_key, hipStream_t stream);
+                    uint32_t drop_key, const FsBnSums* bn, hipStream_t stream);
 
 // ---- conv_pointwise.hip: 1x1 / stride 1 / pad 0 as a GEMM with pre-split weights (forward and bwd-data).  mode: 1 = bf16x3, 2 = f16x2 ----
 bool fs_pointwise_eligible(int Cs, int Cd, int R, int S, int stride, int pad, int dil);

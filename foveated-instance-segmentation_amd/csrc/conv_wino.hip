@@ -43,6 +43,12 @@ struct WinoArgs {
   int Ph, PP, tiles_x, nx, ny, Hv;
   unsigned src_bytes, ws_bytes, dst_bytes;
   unsigned magic_pp, magic_hv, magic_ny, magic_tx;
+  // bwd-data only: dst is the gradient dz of a conv + BatchNorm + activation layer's output -> `stats` receives that layer's
+  // BatchNorm-backward column sums (sum g, sum g * xhat; g = dz * act', xhat = (y - mean) * invstd) instead of (sum v, sum v^2)
+  const float* bn_y; const unsigned char* bn_mask; const float* bn_mean; const float* bn_invstd;
+  // ... and (optionally) dst = conv result + add_src [masked by add_mask: 1 byte per 4 channels]: the residual branch's gradient joins the
+  // conv branch's in this epilogue instead of in a separate n-ary add (add_src = the next BatchNorm's dz, add_mask = its activation bits)
+  const float* add_src; const unsigned char* add_mask;
   float drop_scale; uint32_t drop_thresh, drop_key;
 #ifdef FS_WINO_TRACE
   long long* dbg;                  // [workgroup][32] phase time stamps of wave 0 (tools/wino_trace.sh)
@@ -417,6 +423,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = a.bias[n + j];
       }
+      f32x4 bn_mu = {0.f, 0.f, 0.f, 0.f}, bn_is = {0.f, 0.f, 0.f, 0.f};
+      if (a.bn_y != nullptr && nok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bn_mu[j] = a.bn_mean[n + j]; bn_is[j] = a.bn_invstd[n + j]; }
+      }
       const float* mine = reinterpret_cast<const float*>(smem) + wave * 4096 + cp * 2048;
       const float* theirs = reinterpret_cast<const float*>(smem) + (wave ^ 2) * 4096 + cp * 2048;
       f32x4 csum = {0.f, 0.f, 0.f, 0.f}, csq = {0.f, 0.f, 0.f, 0.f};
@@ -436,8 +447,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
             if (a.drop_thresh != 0u) x = fs_dropout_keep((uint32_t)(e + j), a.drop_key, a.drop_thresh) ? x * a.drop_scale : 0.f;
             v[j] = live ? x : 0.f;
           }
+          if (a.add_src != nullptr && live) {
+            f32x4 r = *reinterpret_cast<const f32x4*>(a.add_src + e);
+            if (a.add_mask != nullptr) {
+              const unsigned mk = a.add_mask[e >> 2];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) r[j] = ((mk >> j) & 1u) ? r[j] : 0.f;
+            }
+            v += r;
+          }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
-          csum += v; csq += v * v;
+          if (a.bn_y != nullptr) {           // BatchNorm-backward sums of the layer whose output gradient this is
+            if (live) {
+              const f32x4 yy = *reinterpret_cast<const f32x4*>(a.bn_y + e);
+              f32x4 gq = v;
+              if (a.bn_mask != nullptr) {
+                const unsigned mk = a.bn_mask[e >> 2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gq[j] = ((mk >> j) & 1u) ? gq[j] : 0.f;
+              }
+              csum += gq; csq += gq * ((yy - bn_mu) * bn_is);
+            }
+          } else {
+            csum += v; csq += v * v;
+          }
         }
       if (a.stats != nullptr) {
         // column sums over the wave's 64 rows: lanes with equal channel quad (lane & 7) hold different rows
@@ -736,6 +769,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_kernel(WinoArgs a) {
       for (int j = 0; j < 4; ++j) bv[j] = a.bias[n + j];
     }
     f32x4 csum = {0.f, 0.f, 0.f, 0.f}, csq = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bn_mu = {0.f, 0.f, 0.f, 0.f}, bn_is = {0.f, 0.f, 0.f, 0.f};
+    if (a.bn_y != nullptr && nok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bn_mu[j] = a.bn_mean[n + j]; bn_is[j] = a.bn_invstd[n + j]; }
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       {
@@ -775,8 +813,30 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_kernel(WinoArgs a) {
             if (a.drop_thresh != 0u) x = fs_dropout_keep((uint32_t)(e + j), a.drop_key, a.drop_thresh) ? x * a.drop_scale : 0.f;
             v[j] = live ? x : 0.f;
           }
+          if (a.add_src != nullptr && live) {
+            f32x4 r = *reinterpret_cast<const f32x4*>(a.add_src + e);
+            if (a.add_mask != nullptr) {
+              const unsigned mk = a.add_mask[e >> 2];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) r[j] = ((mk >> j) & 1u) ? r[j] : 0.f;
+            }
+            v += r;
+          }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
-          csum += v; csq += v * v;
+          if (a.bn_y != nullptr) {           // BatchNorm-backward sums of the layer whose output gradient this is
+            if (live) {
+              const f32x4 yy = *reinterpret_cast<const f32x4*>(a.bn_y + e);
+              f32x4 gq = v;
+              if (a.bn_mask != nullptr) {
+                const unsigned mk = a.bn_mask[e >> 2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gq[j] = ((mk >> j) & 1u) ? gq[j] : 0.f;
+              }
+              csum += gq; csq += gq * ((yy - bn_mu) * bn_is);
+            }
+          } else {
+            csum += v; csq += v * v;
+          }
         }
       }
       __syncthreads();
@@ -953,8 +1013,10 @@ int fs_wino_stats_slabs(int mode, int B, int H, int W, int Cs, int Cd) {
 
 int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
                     int B, int H, int W, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh,
-                    uint32_t drop_key, hipStream_t stream) {
+                    uint32_t drop_key, const FsBnSums* bn, hipStream_t stream) {
   WinoArgs a;
+  a.bn_y = bn ? bn->y : nullptr; a.bn_mask = bn ? bn->mask : nullptr; a.bn_mean = bn ? bn->mean : nullptr; a.bn_invstd = bn ? bn->invstd : nullptr;
+  a.add_src = bn ? bn->add_src : nullptr; a.add_mask = bn ? bn->add_mask : nullptr;
   a.src = src; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = dst; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cs = Cs; a.Cd = Cd;
   const int ncol = wino_use8(mode, Cs, Cd) ? 128 : 64;      // columns per workgroup

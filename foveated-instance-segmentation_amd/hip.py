@@ -37,6 +37,7 @@ SIGNATURES = {
     "fs_conv2d_fwd": "ppppiiiiiiiiiiiifuplp",
     "fs_conv2d_fwd_stats": "pppppiiiiiiiiiiiifuplp",
     "fs_conv2d_bwd_data": "pppiiiiiiiiiiiiplp",
+    "fs_conv2d_bwd_data_bnsum": "pppiiiiiiiiiiiiplp" + "ppppp" + "pp",
     "fs_weight_amax_segments": "pppip",
     "fs_conv2d_bwd_weight": "pppiiiiiiiiiiiii",
     "fs_bn_stats": "pliffppppp",
@@ -80,7 +81,7 @@ _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 _lib = None
 # declared in the header, host-side only (no stream argument)
 HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice",
-             "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes")
+             "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes", "fs_conv2d_bwd_data_bnsum_slabs")
 
 
 class HipLibraryError(RuntimeError):
@@ -115,6 +116,8 @@ def load():
     lib.fs_bn_bwd_slabs.argtypes = [_L, _I]
     lib.fs_dwconv3_wgrad_lanes.restype = _I
     lib.fs_dwconv3_wgrad_lanes.argtypes = [_I] * 4
+    lib.fs_conv2d_bwd_data_bnsum_slabs.restype = _I
+    lib.fs_conv2d_bwd_data_bnsum_slabs.argtypes = [_I] * 12 + [_L]
     _lib = lib
     global _default_mode
     _default_mode = ("f32", "bf16x3", "f16x2")[lib.fs_get_conv_precision()]
@@ -158,6 +161,15 @@ def conv_stats_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_byte
     v = _ws_cache.get(key)
     if v is None:
         v = _ws_cache[key] = int(load().fs_conv2d_stats_slabs(*key[1:]))
+    return v
+
+
+def bwd_data_bnsum_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes):
+    """Slab rows of fs_conv2d_bwd_data_bnsum for this problem under the current precision mode, 0 = not available (cached)."""
+    key = ("bdsum", B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes)
+    v = _ws_cache.get(key)
+    if v is None:
+        v = _ws_cache[key] = int(load().fs_conv2d_bwd_data_bnsum_slabs(*key[1:]))
     return v
 
 

@@ -183,15 +183,45 @@ def conv2d_fwd_stats(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1, w_a
     return y, slab, nwg
 
 
-def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1, w_amax=None):
+def _unmask_bits(amask, like):
+    """1 byte per 4 channels -> float {0,1} tensor shaped like `like` (fallback path only)."""
+    bits = (amask.view(-1, 1) >> torch.arange(4, device=amask.device, dtype=torch.uint8)) & 1
+    return bits.reshape(like.shape).to(like.dtype)
+
+
+def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1, w_amax=None, src_bn=None, addend=None):
+    """dX of conv2d.  src_bn = the `_fs_bn` record of the layer that PRODUCED x (x = its output z, this conv its consumer): where the
+    kernel this shape runs on can, its epilogue also forms that layer's BatchNorm-backward column sums and the slab is left in BN_SLABS
+    under dx's address for ConvBnAct.backward to pick up (if autograd adds another consumer's gradient to dx the sum is a new tensor,
+    the lookup misses and the layer runs its own reduction pass).  addend = (dz, mask bytes | None): a second gradient of x -- the
+    residual branch's -- added in the same epilogue (ConvBnAct.backward stashes it in PENDING_RES only after asking the library that
+    this shape's kernel takes it)."""
     B, H, W, Cin = x_shape
     Cout, _, R, S = w.shape
     _, Ho, Wo, _ = dy.shape
     dx = torch.empty(B, H, W, Cin, device=dy.device, dtype=torch.float32)
     kind = _conv_kind(Cout, Cin, R, S, stride, pad, dil)
     ws, ws_bytes = _conv_workspace(dy.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 1)
-    _launch(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx),
+    flops = 2.0 * B * Ho * Wo * Cout * R * S * Cin
+    if src_bn is not None and not (FUSE_BN_BWD_SUMS and FANOUT and tuple(src_bn[0].shape) == (B, H, W, Cin)):
+        src_bn = None
+    if src_bn is not None or addend is not None:
+        rows = hip.bwd_data_bnsum_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes)
+        if rows > 0:
+            y, amask, mean, invstd = src_bn[:4] if src_bn is not None else (None, None, None, None)
+            slab = torch.empty(rows * Cin * 2, device=dy.device, dtype=torch.float32) if src_bn is not None else None
+            a_src, a_mask = addend if addend is not None else (None, None)
+            _launch(kind, flops, "fs_conv2d_bwd_data_bnsum", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx), B, H, W, Cin, Ho, Wo, Cout, R, S,
+                    stride, pad, dil, hip.ptr(ws), ws_bytes, hip.ptr(w_amax), hip.ptr(y), hip.ptr(amask), hip.ptr(mean), hip.ptr(invstd),
+                    hip.ptr(slab), hip.ptr(a_src), hip.ptr(a_mask))
+            if slab is not None:
+                BN_SLABS[dx.data_ptr()] = (slab, rows, dx)
+            return dx
+    _launch(kind, flops, "fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx),
             B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, hip.ptr(ws), ws_bytes, hip.ptr(w_amax))
+    if addend is not None:          # the library no longer takes the addend for this shape (precision mode changed since the stash): add here
+        a_src, a_mask = addend
+        dx = dx + (a_src if a_mask is None else a_src * _unmask_bits(a_mask, a_src))
     return dx
 
 
@@ -310,6 +340,7 @@ class FanOut(Function):
     @staticmethod
     def forward(ctx, x, n):
         ctx.bn = getattr(x, "_fs_bn", None)
+        ctx.set_materialize_grads(False)      # a consumer whose gradient was absorbed elsewhere returns None: keep it None, not a zero tensor
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
@@ -344,11 +375,26 @@ class FanOut(Function):
         return acc, None
 
 
+_FAN_IDS = [0]
+# A two-way fan-out whose consumers are a convolution and a residual input (BasicBlock, models/hrnetv2_nodownsp.py:46-62): the conv
+# consumer's forward leaves its geometry in FAN_GEOM under the fan id, the residual consumer's backward (it always runs first) asks the
+# library whether that convolution's bwd-data epilogue takes an addend and, if so, leaves (dz, mask bytes) in PENDING_RES instead of
+# materialising the residual gradient; the conv consumer's backward passes it on (conv2d_bwd_data) -- no n-ary add, no dres tensor.
+FAN_GEOM = {}
+PENDING_RES = {}
+
+
 def fan_out(x, n):
     """n references to x for n consumers (n >= 2 and FS_FANOUT on: through FanOut, else x itself n times)."""
     if n < 2 or not FANOUT or not x.requires_grad:
         return (x,) * n
-    return FanOut.apply(x, n)
+    outs = FanOut.apply(x, n)
+    if n == 2:
+        _FAN_IDS[0] += 1
+        tag = (_FAN_IDS[0], getattr(x, "_fs_bn", None))
+        for o in outs:
+            o._fs_fan = tag
+    return outs
 
 
 FANOUT_SUBSAMPLE = os.environ.get("FS_FANOUT_SUBSAMPLE", "1") != "0"
@@ -429,6 +475,12 @@ class ConvBnAct(Function):
         ctx.save_for_backward(x, w, gamma, y, z if amask is None else None, mean, invstd, amask)
         ctx.beta_ref = beta
         ctx.w_amax = wa          # the weights do not change between this forward and its backward
+        ctx.src_bn = getattr(x, "_fs_bn", None)       # x is the output of another conv + BatchNorm layer: its record, for the bwd-data epilogue
+        ctx.fan = getattr(x, "_fs_fan", None)         # x is one of the two aliases of a fan-out: this conv may absorb the other alias's gradient
+        if ctx.fan is not None:
+            FAN_GEOM[ctx.fan[0]] = (tuple(x.shape), tuple(w.shape), meta["stride"], meta["pad"], dil)
+        rfan = getattr(res, "_fs_fan", None) if res is not None else None
+        ctx.res_fan = (rfan[0], FAN_GEOM.get(rfan[0])) if rfan is not None else None
         if act_has_bwd(meta["act"], amask):
             z._fs_bn = (y, amask, mean, invstd, meta["act"])     # for the producer of dz (FanOut.backward): this layer's BN-backward operands
         return z
@@ -441,7 +493,19 @@ class ConvBnAct(Function):
         B, Ho, Wo, C = y.shape
         M = B * Ho * Wo
         dy = torch.empty_like(y)
-        dres = torch.empty_like(y) if m["has_res"] else None
+        # residual gradient: absorbed by the bwd-data epilogue of the convolution that shares the fan-out with `res`, where it can be
+        absorb = None
+        if (m["has_res"] and ctx.res_fan is not None and ctx.res_fan[1] is not None and FUSE_BN_BWD_SUMS and FANOUT
+                and (m["act"] == ACT_NONE or amask is not None)):
+            xs, wsh, st, pd, dl = ctx.res_fan[1]
+            if xs == tuple(y.shape):
+                fB, fH, fW, fCin = xs
+                fCout, _, fR, fS = wsh
+                fHo, fWo = _out_hw(fH, fW, fR, fS, st, pd, dl)
+                wsb = hip.conv_workspace_bytes(fH, fW, fCin, fHo, fWo, fCout, fR, fS, st, pd, dl, 1)
+                if hip.bwd_data_bnsum_slabs(fB, fH, fW, fCin, fHo, fWo, fCout, fR, fS, st, pd, dl, wsb) > 0:
+                    absorb = ctx.res_fan[0]
+        dres = torch.empty_like(y) if (m["has_res"] and absorb is None) else None
         tg, tb = _direct_grad_target(gamma), _direct_grad_target(ctx.beta_ref)
         direct_affine = tg is not None and tb is not None
         dgamma = tg if direct_affine else torch.empty(C, device=y.device, dtype=torch.float32)
@@ -463,14 +527,20 @@ class ConvBnAct(Function):
         _launch("bn_bwd", 4.0 * M * C * (3 + m["has_res"]) + (M * C // 4 if amask is not None else 0),
                 "fs_bn_bwd_apply", hip.ptr(dz), hip.ptr(z), hip.ptr(amask), hip.ptr(y), hip.ptr(coef), M, C, m["act"], float(m["drop_p"]),
                 int(m["drop_key"]), hip.ptr(dy), hip.ptr(dres))
+        if absorb is not None:
+            PENDING_RES[absorb] = (dz, amask if m["act"] != ACT_NONE else None)
         tgt = _direct_grad_target(w)
+        # this conv's own input: the other alias's gradient (if a residual consumer stashed it) joins dx in the epilogue, and then dx is
+        # the WHOLE gradient of the fan-out's input, so that tensor's producer record (fan tag) is the one the BatchNorm sums are for
+        pend = PENDING_RES.pop(ctx.fan[0], None) if ctx.fan is not None else None
+        src_bn = ctx.src_bn if ctx.fan is None else (ctx.fan[1] if pend is not None else None)
         if not WGRAD_FIRST:
-            dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax) if ctx.needs_input_grad[0] else None
+            dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax, src_bn=src_bn, addend=pend) if ctx.needs_input_grad[0] else None
         dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"], accumulate=tgt is not None)
         if tgt is not None:
             dw = None
         if WGRAD_FIRST:     # dx is what the next backward node reads: produce it last so it is the freshest tensor in the cache
-            dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax) if ctx.needs_input_grad[0] else None
+            dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax, src_bn=src_bn, addend=pend) if ctx.needs_input_grad[0] else None
         dbias = colsum(dy, C) if m["has_bias"] else None
         if direct_affine:
             dgamma = dbeta = None

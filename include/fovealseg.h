@@ -129,6 +129,21 @@ int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float
 /* convolution_backward: input gradient / weight gradient (dw overwritten). */
 int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R,
                        int S, int stride, int pad, int dil, void* ws, long ws_bytes, const unsigned* w_amax, fs_stream_t stream);
+/* The same call where x is the output z of a conv + BatchNorm + activation layer and this convolution is its only consumer
+ * (models/hrnetv2_nodownsp.py:49-56: conv1 -> bn1 -> relu -> conv2): dx is that layer's dz, and the epilogue that holds it in registers
+ * also writes the layer's BatchNorm-backward partial sums (fs_bn_bwd_partial's slab) -- bn_y / bn_mask / bn_mean / bn_invstd are the
+ * layer's forward record, bn_mask NULL = no activation.  add_src (nullable): a second gradient of x to be added in the same epilogue
+ * -- the residual branch of a BasicBlock (models/hrnetv2_nodownsp.py:59-62): add_src = the block's last BatchNorm's dz, add_mask its
+ * activation bits (1 byte per 4 channels, NULL = unmasked) -- so autograd's add at the block input disappears as well (bn_y may be NULL
+ * when only the addend is wanted).
+ * fs_conv2d_bwd_data_bnsum_slabs (host only) gives the slab's row count, or 0 when the kernel this shape runs on cannot form the sums
+ * (then call fs_conv2d_bwd_data + fs_bn_bwd_partial). */
+int fs_conv2d_bwd_data_bnsum_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                                   long ws_bytes);
+int fs_conv2d_bwd_data_bnsum(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R,
+                             int S, int stride, int pad, int dil, void* ws, long ws_bytes, const unsigned* w_amax, const float* bn_y,
+                             const unsigned char* bn_mask, const float* bn_mean, const float* bn_invstd, float* slab, const float* add_src,
+                             const unsigned char* add_mask, fs_stream_t stream);
 /* accumulate = 0: dw is overwritten; 1: the gradient is ADDED to dw (torch's .grad accumulation; saves the memset when the caller
  * keeps a zeroed gradient arena). */
 int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,

@@ -1755,7 +1755,7 @@ def test_winograd_row_kernel(case):
         fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
 
 
-@pytest.mark.parametrize("C,hw,act_last", [(64, 20, True), (24, 9, False), (256, 6, True)])
+@pytest.mark.parametrize("C,hw,act_last", [(64, 20, True), (24, 9, False), (256, 6, True), (128, 40, True)])
 def test_bn_backward_sums_from_the_gradient_producer(C, hw, act_last):
     """Round 3: where the gradient of a conv + BatchNorm + activation output is formed by ops.FanOut's n-ary add, that add also writes
     the layer's BatchNorm-backward column sums (fs_add_n_bnsum) and the layer's own reduction pass (fs_bn_bwd_partial) is skipped.
@@ -1778,6 +1778,8 @@ def test_bn_backward_sums_from_the_gradient_producer(C, hw, act_last):
     def run(fused):
         ops.FUSE_BN_BWD_SUMS = fused
         ops.BN_SLABS.clear()
+        ops.FAN_GEOM.clear()
+        ops.PENDING_RES.clear()
         for b in blocks:
             b.zero_grad()
         x = x0.clone().requires_grad_(True)
@@ -1802,10 +1804,19 @@ def test_bn_backward_sums_from_the_gradient_producer(C, hw, act_last):
         g_plain, calls_plain = run(False)
     finally:
         ops.FUSE_BN_BWD_SUMS = True
-    # 4 BatchNorm layers; bn2 of both blocks receives its gradient from a FanOut add -> 2 fused sums, 2 reduction passes left
-    assert calls_plain.count("fs_bn_bwd_partial") == 4 and calls_plain.count("fs_add_n_bnsum") == 0
-    assert calls_fused.count("fs_add_n_bnsum") == 2 and calls_fused.count("fs_bn_bwd_partial") == 2
-    assert not ops.BN_SLABS                                         # every slab was consumed
+    # 4 BatchNorm layers.  bn2 of both blocks receives its gradient from a FanOut add (fs_add_n_bnsum); bn1 of both blocks from conv2's
+    # bwd-data, whose epilogue forms the sums where the F(2,3) kernel runs (fs_conv2d_bwd_data_bnsum: even width, >= 32 channels)
+    ws = fovealseg.hip.conv_workspace_bytes(hw, hw, C, hw, hw, C, 3, 3, 1, 1, 1, 1)
+    conv_fuses = fovealseg.hip.bwd_data_bnsum_slabs(3, hw, hw, C, hw, hw, C, 3, 3, 1, 1, 1, ws) > 0
+    assert conv_fuses == (C >= 32 and hw % 2 == 0)
+    assert calls_plain.count("fs_bn_bwd_partial") == 4 and calls_plain.count("fs_add_n_bnsum") == 0 and calls_plain.count("fs_conv2d_bwd_data_bnsum") == 0
+    # ... and where it does, conv1's bwd-data epilogue also ABSORBS the residual branch's gradient (the other alias of the block input's
+    # fan-out): no n-ary add at the block inputs, no materialised dres; block 1's conv1 then forms block 0's bn2 sums as well
+    assert calls_fused.count("fs_add_n_bnsum") == (1 if conv_fuses else 2)          # the last block's output still has two plain consumers
+    assert calls_fused.count("fs_add_n") == 0 if conv_fuses else True
+    assert calls_fused.count("fs_conv2d_bwd_data_bnsum") == (4 if conv_fuses else 0)
+    assert calls_fused.count("fs_bn_bwd_partial") == (0 if conv_fuses else 2)
+    assert not ops.BN_SLABS and not ops.PENDING_RES                 # every slab and every stashed residual gradient was consumed
     for a, b in zip(g_fused, g_plain):
         scale = float(b.abs().max()) + 1e-30
         assert float((a - b).abs().max()) <= 2e-5 * scale          # same sums, different summation order (and bwd-weight atomics)
