@@ -60,6 +60,16 @@ def _profiled_traffic(kernel):
     return None
 
 
+def _profiled_traffic_table():
+    for rel in ("profiles/r03/hbm_traffic_serial.json",):
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                return json.load(f), rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except Exception:
+            continue
+    return None
+
+
 def _profiled_mfma_busy(mode, kernel):
     """MFMA-pipe busy fraction and sustained clock of the dominant kernel from the committed SQ-counter passes
     (profiles/r02/pmc/sq_<mode>_<kernel>_fwd_shape0.txt: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)), or None."""
@@ -387,12 +397,23 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
                 "gflop_per_launch": round(kk["flops"] / kk["launches"] / 1e9, 3),
                 "share_of_serial_step": round(kk["total_ms"] / (1000.0 * serial_elapsed), 3)}
 
-    def hbm_entry(kk, desc, knames):
+    def hbm_entry(kk, desc, knames, per="launch"):
         ach = kk["flops"] / (kk["total_ms"] * 1e-3) / 1e9
-        parts = [_profiled_traffic(k) for k in knames]
         traffic, source = None, None
-        if all(parts):
-            traffic, source = sum(t["hbm_bytes_per_launch"] for t in parts), parts[0]["source"]
+        if per == "layer":
+            # bytes of ALL the named kernels per launch of the LAST one (the pass every layer runs): kernels that only some layers run
+            # (the reduction pass where no producer formed the sums) count with their share
+            tr = _profiled_traffic_table()
+            if tr is not None:
+                table, source = tr
+                rows = [[v for k, v in table.items() if k == n or k.startswith(n + "<")] for n in knames]
+                if rows[-1]:
+                    base = sum(v["launches"] for v in rows[-1])
+                    traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for r in rows for v in r) / base)
+        else:
+            parts = [_profiled_traffic(k) for k in knames]
+            if all(parts):
+                traffic, source = sum(t["hbm_bytes_per_launch"] for t in parts), parts[0]["source"]
         return {"kernel": desc, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": source,
                 "launches_per_step": kk["launches"] // nsteps,
@@ -437,8 +458,10 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
         out["roofline_bn_fwd"] = hbm_entry(summ["bn_fwd"], "BatchNorm apply + residual + activation forward (algorithmic bytes = conv output read, [residual read,] "
                                            "activation written, 1 mask byte per 4 channels)", ["bn_act_fwd_kernel"])
     if "bn_bwd" in summ:
-        out["roofline_bn_bwd"] = hbm_entry(summ["bn_bwd"], "BatchNorm + activation backward (one C-ABI call; algorithmic bytes = dz, conv output and mask read once, "
-                                           "dy [and the residual gradient] written once)", ["bn_bwd_reduce_kernel", "bn_bwd_apply_kernel"])
+        out["roofline_bn_bwd"] = hbm_entry(summ["bn_bwd"], "BatchNorm + activation backward (partial sums where no producer formed them + finalize + apply; "
+                                           "algorithmic bytes = dz, conv output and mask read once, dy [and the residual gradient] written once; "
+                                           "traffic = bytes of the three kernels per layer)",
+                                           ["bn_bwd_partial_kernel", "bn_bwd_finalize_kernel", "bn_bwd_apply_kernel"], per="layer")
     fe = {}
     for kind, (kname, desc) in FRONTEND_KINDS.items():
         if kind in summ:

@@ -164,7 +164,9 @@ def _conv_workspace(device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, tra
 
 
 FUSE_BN_STATS = True     # BatchNorm batch statistics come out of the conv epilogue (fs_conv2d_fwd_stats)
-FUSE_BN_BWD_SUMS = True  # BatchNorm-backward column sums come out of the kernel that produces the gradient, where one does (FanOut)
+# BatchNorm-backward column sums come out of the kernel that produces the gradient, where one does (FanOut's add, the F(2,3) bwd-data
+# epilogue); FS_FUSE_BN_BWD=0 (read once, A/B runs) keeps every layer on its own reduction pass
+FUSE_BN_BWD_SUMS = os.environ.get("FS_FUSE_BN_BWD", "1") != "0"
 
 
 def conv2d_fwd_stats(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1, w_amax=None):
