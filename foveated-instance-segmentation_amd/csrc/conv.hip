@@ -1233,6 +1233,31 @@ int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, i
   return FS_OK;
 }
 
+// include/fovealseg.h: 1 when fs_conv2d_fwd_affine_act can serve this shape (the F(2,3) kernels' row epilogue), else 0
+int fs_conv2d_fwd_affine_act_ok(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                                long ws_bytes) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || dil != 1 || Cout % 4) return 0;
+  ConvArgs a{nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0, 1.f, 0u, 0u};
+  static unsigned char dummy;
+  a.ws_ = ws_bytes > 0 ? &dummy : nullptr; a.ws_bytes_ = ws_bytes;
+  return (aligned_ok(a) && !(use_tapset(a) && !use_halo(a)) && use_wino(a)) ? 1 : 0;
+}
+
+// include/fovealseg.h: inference forward  z = act((conv(x, w) + bias) * scale[c] + shift[c] [+ res])  in one launch
+int fs_conv2d_fwd_affine_act(const float* x, const float* w, const float* bias, const float* scale, const float* shift, const float* res,
+                             float* z, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                             int act, void* ws, long ws_bytes, const unsigned* w_amax, hipStream_t stream) {
+  FS_REQUIRE(x && w && z && scale && shift && act >= 0 && act <= 2);
+  FS_REQUIRE(fs_conv2d_fwd_affine_act_ok(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes) == 1);
+  FS_REQUIRE(Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
+  ConvArgs a{x, w, bias, z, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0, 1.f, 0u, 0u};
+  a.stream_ = stream;
+  a.ws_ = ws; a.ws_bytes_ = ws_bytes; a.w_amax_ = w_amax;
+  const FsBnSums ep{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, scale, shift, res, act};
+  a.bn_ = &ep;
+  return launch_affine(a, (long)B * Ho * Wo);
+}
+
 // include/fovealseg.h: fs_conv2d_fwd_stats -- forward conv that also emits per-workgroup BatchNorm partials.
 // stats = [ceil(B*Ho*Wo/128)][Cout][2] floats.  Requires Cin%4==0 && Cout%4==0 (the affine kernel).
 int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* stats, int B, int H, int W, int Cin,
@@ -1302,7 +1327,7 @@ int fs_conv2d_bwd_data_bnsum(const float* dy, const float* w, float* dx, int B, 
   FS_REQUIRE((bn_y != nullptr || add_src != nullptr) && (add_mask == nullptr || add_src != nullptr));
   FS_REQUIRE(bn_y == nullptr || (bn_mean && bn_invstd && slab));
   FS_REQUIRE(fs_conv2d_bwd_data_bnsum_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes) > 0);
-  const FsBnSums bn{bn_y, bn_mask, bn_mean, bn_invstd, add_src, add_mask};
+  const FsBnSums bn{bn_y, bn_mask, bn_mean, bn_invstd, add_src, add_mask, nullptr, nullptr, nullptr, 0};
   return conv2d_bwd_data_impl(dy, w, dx, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws, ws_bytes, w_amax, &bn, slab, stream);
 }
 

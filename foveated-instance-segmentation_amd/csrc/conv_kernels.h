@@ -24,7 +24,11 @@ int fs_weight_amax_segments_impl(const float* arena, const long* offsets, const 
 // ---- conv_wino.hip: the same problem class with F(2,3) minimal filtering along the row (12 MFMA steps per pixel pair instead of 18).
 // Even W >= 4, B*(H+1) < 65536, channel counts multiples of 4, K >= 32 (K >= 128 in f16x2); FS_WINOGRAD=0 switches it off.
 // optional epilogue mode of the bwd-data call: BatchNorm-backward column sums of the layer whose output gradient is being written
-struct FsBnSums { const float* y; const unsigned char* mask; const float* mean; const float* invstd; const float* add_src; const unsigned char* add_mask; };
+struct FsBnSums {
+  const float* y; const unsigned char* mask; const float* mean; const float* invstd;      // bwd-data: BatchNorm-backward sums of the consumer layer
+  const float* add_src; const unsigned char* add_mask;                                    // bwd-data: second gradient joining in the epilogue
+  const float* ep_scale; const float* ep_shift; const float* ep_res; int ep_act;          // forward (inference): affine + residual + activation
+};
 bool fs_wino_eligible(int mode, int B, int H, int W, int Cs, int Cd);
 long fs_wino_pack_bytes(int mode, int Cs, int Cd);
 int fs_wino_stats_slabs(int mode, int B, int H, int W, int Cs, int Cd);

@@ -49,6 +49,9 @@ struct WinoArgs {
   // ... and (optionally) dst = conv result + add_src [masked by add_mask: 1 byte per 4 channels]: the residual branch's gradient joins the
   // conv branch's in this epilogue instead of in a separate n-ary add (add_src = the next BatchNorm's dz, add_mask = its activation bits)
   const float* add_src; const unsigned char* add_mask;
+  // forward, inference: dst = act((conv + bias) * ep_scale[c] + ep_shift[c] [+ ep_res]) -- eval-mode BatchNorm, residual and activation in
+  // the epilogue, so the separate normalise / activate pass over the conv output disappears (ep_scale NULL = off)
+  const float* ep_scale; const float* ep_shift; const float* ep_res; int ep_act;
   float drop_scale; uint32_t drop_thresh, drop_key;
 #ifdef FS_WINO_TRACE
   long long* dbg;                  // [workgroup][32] phase time stamps of wave 0 (tools/wino_trace.sh)
@@ -423,6 +426,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = a.bias[n + j];
       }
+      f32x4 ep_sc = {1.f, 1.f, 1.f, 1.f}, ep_sh = {0.f, 0.f, 0.f, 0.f};
+      if (a.ep_scale != nullptr && nok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ep_sc[j] = a.ep_scale[n + j]; ep_sh[j] = a.ep_shift[n + j]; }
+      }
       f32x4 bn_mu = {0.f, 0.f, 0.f, 0.f}, bn_is = {0.f, 0.f, 0.f, 0.f};
       if (a.bn_y != nullptr && nok) {
 #pragma unroll
@@ -446,6 +454,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
             float x = P::SCALED ? fmaf(m[j] * f2, f1, bv[j]) : m[j] + bv[j];
             if (a.drop_thresh != 0u) x = fs_dropout_keep((uint32_t)(e + j), a.drop_key, a.drop_thresh) ? x * a.drop_scale : 0.f;
             v[j] = live ? x : 0.f;
+          }
+          if (a.ep_scale != nullptr && live) {
+            v = v * ep_sc + ep_sh;
+            if (a.ep_res != nullptr) v += *reinterpret_cast<const f32x4*>(a.ep_res + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fs_act(v[j], a.ep_act);
           }
           if (a.add_src != nullptr && live) {
             f32x4 r = *reinterpret_cast<const f32x4*>(a.add_src + e);
@@ -769,6 +783,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_kernel(WinoArgs a) {
       for (int j = 0; j < 4; ++j) bv[j] = a.bias[n + j];
     }
     f32x4 csum = {0.f, 0.f, 0.f, 0.f}, csq = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ep_sc = {1.f, 1.f, 1.f, 1.f}, ep_sh = {0.f, 0.f, 0.f, 0.f};
+    if (a.ep_scale != nullptr && nok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ep_sc[j] = a.ep_scale[n + j]; ep_sh[j] = a.ep_shift[n + j]; }
+    }
     f32x4 bn_mu = {0.f, 0.f, 0.f, 0.f}, bn_is = {0.f, 0.f, 0.f, 0.f};
     if (a.bn_y != nullptr && nok) {
 #pragma unroll
@@ -812,6 +831,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_kernel(WinoArgs a) {
             float x = m[j] + bv[j];
             if (a.drop_thresh != 0u) x = fs_dropout_keep((uint32_t)(e + j), a.drop_key, a.drop_thresh) ? x * a.drop_scale : 0.f;
             v[j] = live ? x : 0.f;
+          }
+          if (a.ep_scale != nullptr && live) {
+            v = v * ep_sc + ep_sh;
+            if (a.ep_res != nullptr) v += *reinterpret_cast<const f32x4*>(a.ep_res + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fs_act(v[j], a.ep_act);
           }
           if (a.add_src != nullptr && live) {
             f32x4 r = *reinterpret_cast<const f32x4*>(a.add_src + e);
@@ -1017,6 +1042,7 @@ int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bia
   WinoArgs a;
   a.bn_y = bn ? bn->y : nullptr; a.bn_mask = bn ? bn->mask : nullptr; a.bn_mean = bn ? bn->mean : nullptr; a.bn_invstd = bn ? bn->invstd : nullptr;
   a.add_src = bn ? bn->add_src : nullptr; a.add_mask = bn ? bn->add_mask : nullptr;
+  a.ep_scale = bn ? bn->ep_scale : nullptr; a.ep_shift = bn ? bn->ep_shift : nullptr; a.ep_res = bn ? bn->ep_res : nullptr; a.ep_act = bn ? bn->ep_act : 0;
   a.src = src; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = dst; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cs = Cs; a.Cd = Cd;
   const int ncol = wino_use8(mode, Cs, Cd) ? 128 : 64;      // columns per workgroup

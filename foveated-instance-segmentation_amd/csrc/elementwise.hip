@@ -96,6 +96,17 @@ __global__ __launch_bounds__(256) void bn_finalize_slab_kernel(const float* __re
   }
 }
 
+// eval-mode BatchNorm as one multiply-add per element: scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+__global__ void bn_eval_affine_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, int C, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] * (1.0f / sqrtf(running_var[c] + eps));
+  scale[c] = sc;
+  shift[c] = beta[c] - running_mean[c] * sc;
+}
+
 __global__ void bn_eval_prepare_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
                                        int C, float eps, float* __restrict__ mean, float* __restrict__ invstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -595,6 +606,15 @@ int fs_bn_eval_prepare(const float* running_mean, const float* running_var, int 
   FS_REQUIRE(running_mean && running_var && mean && invstd && C > 0);
   hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, running_mean, running_var, C, eps,
                      mean, invstd);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_bn_eval_affine(const float* running_mean, const float* running_var, const float* gamma, const float* beta, int C, float eps,
+                      float* scale, float* shift, hipStream_t stream) {
+  FS_REQUIRE(running_mean && running_var && gamma && beta && scale && shift && C > 0);
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, running_mean, running_var, gamma, beta, C, eps, scale,
+                     shift);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

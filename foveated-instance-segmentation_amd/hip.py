@@ -36,6 +36,7 @@ SIGNATURES = {
     "fs_fill_nearest": "pppiiii",
     "fs_conv2d_fwd": "ppppiiiiiiiiiiiifuplp",
     "fs_conv2d_fwd_stats": "pppppiiiiiiiiiiiifuplp",
+    "fs_conv2d_fwd_affine_act": "ppppppp" + "iiiiiiiiiiii" + "i" + "plp",
     "fs_conv2d_bwd_data": "pppiiiiiiiiiiiiplp",
     "fs_conv2d_bwd_data_bnsum": "pppiiiiiiiiiiiiplp" + "ppppp" + "pp",
     "fs_weight_amax_segments": "pppip",
@@ -43,6 +44,7 @@ SIGNATURES = {
     "fs_bn_stats": "pliffppppp",
     "fs_bn_finalize_slab": "piliffpppp",
     "fs_bn_eval_prepare": "ppifpp",
+    "fs_bn_eval_affine": "ppppifpp",
     "fs_bn_act_fwd": "pppppppplii",
     "fs_bn_bwd_partial": "ppppppliip",
     "fs_add_n_bnsum": "pppppppppliip",
@@ -81,7 +83,8 @@ _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 _lib = None
 # declared in the header, host-side only (no stream argument)
 HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice",
-             "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes", "fs_conv2d_bwd_data_bnsum_slabs")
+             "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes", "fs_conv2d_bwd_data_bnsum_slabs",
+             "fs_conv2d_fwd_affine_act_ok")
 
 
 class HipLibraryError(RuntimeError):
@@ -118,6 +121,8 @@ def load():
     lib.fs_dwconv3_wgrad_lanes.argtypes = [_I] * 4
     lib.fs_conv2d_bwd_data_bnsum_slabs.restype = _I
     lib.fs_conv2d_bwd_data_bnsum_slabs.argtypes = [_I] * 12 + [_L]
+    lib.fs_conv2d_fwd_affine_act_ok.restype = _I
+    lib.fs_conv2d_fwd_affine_act_ok.argtypes = [_I] * 12 + [_L]
     _lib = lib
     global _default_mode
     _default_mode = ("f32", "bf16x3", "f16x2")[lib.fs_get_conv_precision()]
@@ -162,6 +167,15 @@ def conv_stats_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_byte
     if v is None:
         v = _ws_cache[key] = int(load().fs_conv2d_stats_slabs(*key[1:]))
     return v
+
+
+def fwd_affine_act_ok(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes):
+    """True where fs_conv2d_fwd_affine_act serves this shape under the current precision mode (cached)."""
+    key = ("faa", B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes)
+    v = _ws_cache.get(key)
+    if v is None:
+        v = _ws_cache[key] = int(load().fs_conv2d_fwd_affine_act_ok(*key[1:]))
+    return v == 1
 
 
 def bwd_data_bnsum_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes):

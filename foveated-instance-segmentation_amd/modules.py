@@ -70,7 +70,8 @@ def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, act, res=None, drop_p=0.
     training = bn.training
     meta = dict(stride=conv.stride if stride is None else stride, pad=conv.padding, dil=conv.dilation, act=act, training=training, momentum=bn.momentum,
                 drop_p=drop_p, drop_key=ops.DropoutState.key(layer_id) if (training and drop_p > 0) else 0,
-                running_mean=bn.running_mean, running_var=bn.running_var, num_batches_tracked=_NbtCounter(bn))
+                running_mean=bn.running_mean, running_var=bn.running_var, num_batches_tracked=_NbtCounter(bn),
+                grad_enabled=torch.is_grad_enabled())
     x, w = ops.pad_in_channels(x, conv.weight)
     z = ops.ConvBnAct.apply(x, w, conv.bias, bn.weight, bn.bias, res, meta)
     if ops.ACT_TRACE is not None and act != ACT_NONE:

@@ -164,6 +164,7 @@ def _conv_workspace(device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, tra
 
 
 FUSE_BN_STATS = True     # BatchNorm batch statistics come out of the conv epilogue (fs_conv2d_fwd_stats)
+FUSE_EVAL_BN = True      # inference: eval-mode BatchNorm + residual + activation in the conv epilogue (fs_conv2d_fwd_affine_act)
 # BatchNorm-backward column sums come out of the kernel that produces the gradient, where one does (FanOut's add, the F(2,3) bwd-data
 # epilogue); FS_FUSE_BN_BWD=0 (read once, A/B runs) keeps every layer on its own reduction pass
 FUSE_BN_BWD_SUMS = os.environ.get("FS_FUSE_BN_BWD", "1") != "0"
@@ -445,6 +446,24 @@ class ConvBnAct(Function):
         fused_stats = training and FUSE_BN_STATS and Cin % 4 == 0 and Cout % 4 == 0
         dil = meta.get("dil", 1)
         wa = weight_amax(w)
+        # (ctx.needs_input_grad mirrors requires_grad of the inputs even under no_grad: "no backward will follow" = grad mode was off at
+        #  the call site, which modules.conv_bn_act records in meta before Function.apply switches it off)
+        if not training and FUSE_EVAL_BN and not meta.get("grad_enabled", True) and Cin % 4 == 0 and Cout % 4 == 0:
+            # inference: eval-mode BatchNorm, residual and activation in the conv epilogue where this shape's kernel has one
+            B_, H_, W_, _ = x.shape
+            R_, S_ = w.shape[2], w.shape[3]
+            Ho_, Wo_ = _out_hw(H_, W_, R_, S_, meta["stride"], meta["pad"], dil)
+            ws, ws_bytes = _conv_workspace(x.device, H_, W_, Cin, Ho_, Wo_, Cout, R_, S_, meta["stride"], meta["pad"], dil, 0)
+            if hip.fwd_affine_act_ok(B_, H_, W_, Cin, Ho_, Wo_, Cout, R_, S_, meta["stride"], meta["pad"], dil, ws_bytes):
+                coef = torch.empty(2, Cout, device=x.device, dtype=torch.float32)
+                hip.call("fs_bn_eval_affine", hip.ptr(meta["running_mean"]), hip.ptr(meta["running_var"]), hip.ptr(gamma), hip.ptr(beta), Cout,
+                         BN_EPS, hip.ptr(coef[0]), hip.ptr(coef[1]))
+                z = torch.empty(B_, Ho_, Wo_, Cout, device=x.device, dtype=torch.float32)
+                _launch(_conv_kind(Cin, Cout, R_, S_, meta["stride"], meta["pad"], dil), 2.0 * B_ * Ho_ * Wo_ * Cout * R_ * S_ * Cin,
+                        "fs_conv2d_fwd_affine_act", hip.ptr(x), hip.ptr(rsck(w)), hip.ptr(bias), hip.ptr(coef[0]), hip.ptr(coef[1]), hip.ptr(res),
+                        hip.ptr(z), B_, H_, W_, Cin, Ho_, Wo_, Cout, R_, S_, meta["stride"], meta["pad"], dil, meta["act"], hip.ptr(ws), ws_bytes,
+                        hip.ptr(wa))
+                return z
         if fused_stats:
             y, slab, nwg = conv2d_fwd_stats(x, w, bias, meta["stride"], meta["pad"], drop_p, meta["drop_key"], dil, w_amax=wa)
         else:

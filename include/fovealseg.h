@@ -126,6 +126,16 @@ int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, i
 int fs_conv2d_fwd_stats(const float* x, const float* w, const float* bias, float* y, float* stats, int B, int H, int W, int Cin,
                         int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key,
                         void* ws, long ws_bytes, const unsigned* w_amax, fs_stream_t stream);
+/* Inference forward with the BatchNorm of eval mode folded in: z = act((conv(x, w) + bias) * scale[c] + shift[c] [+ res]),
+ * scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale (lib/nn/modules/batchnorm.py:56-61 with training = False;
+ * models/hrnetv2_nodownsp.py:46-62 for the residual / ReLU order), act = 0 none / 1 ReLU / 2 ReLU6.  One launch, no intermediate conv
+ * output.  fs_conv2d_fwd_affine_act_ok (host only) = 1 where the kernel this shape runs on has the row epilogue, else call
+ * fs_conv2d_fwd + fs_bn_eval_prepare + fs_bn_act_fwd. */
+int fs_conv2d_fwd_affine_act_ok(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                                long ws_bytes);
+int fs_conv2d_fwd_affine_act(const float* x, const float* w, const float* bias, const float* scale, const float* shift, const float* res,
+                             float* z, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                             int act, void* ws, long ws_bytes, const unsigned* w_amax, fs_stream_t stream);
 /* convolution_backward: input gradient / weight gradient (dw overwritten). */
 int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R,
                        int S, int stride, int pad, int dil, void* ws, long ws_bytes, const unsigned* w_amax, fs_stream_t stream);
@@ -158,6 +168,10 @@ int fs_bn_finalize_slab(const float* slab, int nwg, long M, int C, float momentu
                         float* running_var, float* mean, float* invstd, fs_stream_t stream);
 int fs_bn_eval_prepare(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* invstd,
                        fs_stream_t stream);
+/* the same statistics as the two per-channel coefficients fs_conv2d_fwd_affine_act takes: scale = gamma / sqrt(running_var + eps),
+ * shift = beta - running_mean * scale */
+int fs_bn_eval_affine(const float* running_mean, const float* running_var, const float* gamma, const float* beta, int C, float eps,
+                      float* scale, float* shift, fs_stream_t stream);
 /* out = act((y-mean)*invstd*gamma + beta [+ res]).  mask (nullable, M*C/4 bytes): bit j of byte e/4 = act'(out[e+j]) != 0, so the
  * backward passes read one byte instead of four floats of `out`.  models/hrnetv2_nodownsp.py:51-52,56-62. */
 int fs_bn_act_fwd(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* res,

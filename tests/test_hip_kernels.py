@@ -1820,3 +1820,46 @@ def test_bn_backward_sums_from_the_gradient_producer(C, hw, act_last):
     for a, b in zip(g_fused, g_plain):
         scale = float(b.abs().max()) + 1e-30
         assert float((a - b).abs().max()) <= 2e-5 * scale          # same sums, different summation order (and bwd-weight atomics)
+
+
+@pytest.mark.parametrize("C,hw,act,use_res", [(64, 20, 1, True), (128, 12, 2, False), (96, 10, 0, False), (64, 9, 1, True)])
+def test_inference_conv_with_folded_batchnorm(C, hw, act, use_res, prec):
+    """Round 3: under no_grad in eval mode the BatchNorm (running statistics), the residual add and the activation run in the conv
+    epilogue where the shape's kernel has the row epilogue (fs_conv2d_fwd_affine_act) -- one launch, no intermediate conv output.
+    Must equal the three-launch route (conv -> bn_eval_prepare -> bn_act_fwd) that G7 / G8 pin to the reference; odd widths and the
+    f32 mode fall back to that route by themselves."""
+    from fovealseg import modules as Mods
+    torch.manual_seed(C * hw + act)
+    conv = Mods.HipConv2d(C, C, 3, 1, 1).to(DEV)
+    bn = Mods.HipBatchNorm2d(C, 0.1).to(DEV).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.5); bn.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(2, hw, hw, C, device=DEV)
+    res = torch.randn(2, hw, hw, C, device=DEV) if use_res else None
+    calls = []
+    orig = fovealseg.hip.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    outs = {}
+    try:
+        fovealseg.hip.call = spy
+        for fused in (True, False):
+            ops.FUSE_EVAL_BN = fused
+            calls.clear()
+            with torch.no_grad():
+                outs[fused] = Mods.conv_bn_act(x, conv, bn, act, res=res)
+            outs[("calls", fused)] = list(calls)
+    finally:
+        fovealseg.hip.call = orig
+        ops.FUSE_EVAL_BN = True
+    ws = fovealseg.hip.conv_workspace_bytes(hw, hw, C, hw, hw, C, 3, 3, 1, 1, 1, 0)
+    can = fovealseg.hip.fwd_affine_act_ok(2, hw, hw, C, hw, hw, C, 3, 3, 1, 1, 1, ws)
+    assert can == (prec != "f32" and hw % 2 == 0 and (prec == "bf16x3" or C >= 128))
+    assert ("fs_conv2d_fwd_affine_act" in outs[("calls", True)]) == can
+    assert "fs_bn_act_fwd" in outs[("calls", False)] and "fs_conv2d_fwd_affine_act" not in outs[("calls", False)]
+    assert relerr(outs[True].cpu(), outs[False].cpu()) <= 5e-6
+    if act == 1:
+        assert float(outs[True].min()) >= 0.0
