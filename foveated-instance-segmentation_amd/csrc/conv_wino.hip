@@ -400,6 +400,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
           xw[2048 + (b * 32 + row) * 32] = od;
         }
     }
+    // bwd-data extras (BatchNorm-backward sums, residual addend): a four-row window of their operands is kept in flight. Rows 0-3 are
+    // requested HERE, before the exchange barrier, and row k + 4 when row k has been consumed, so the HBM latency overlaps the barrier,
+    // the LDS reads and four rows of stores instead of sitting in front of every row
+    f32x4 pf_y[4], pf_a[4];
+    unsigned pf_ym[4], pf_am[4];
+    const bool want_y = a.bn_y != nullptr, want_a = a.add_src != nullptr;
+    // (issued without a branch: a conditional definition would make the window loop-carried and spill it over the MFMA loop; an absent
+    // operand has a zero-size descriptor, whose loads return 0 without touching memory)
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.bn_y, want_y ? a.dst_bytes : 0u), rs_a = make_rsrc(a.add_src, want_a ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_ym = make_rsrc(a.bn_mask, a.bn_mask != nullptr ? a.dst_bytes >> 4 : 0u);
+    const __amdgpu_buffer_rsrc_t rs_am = make_rsrc(a.add_mask, a.add_mask != nullptr ? a.dst_bytes >> 4 : 0u);
+    const unsigned ym_all = a.bn_mask != nullptr ? 0u : 0xFu, am_all = a.add_mask != nullptr ? 0u : 0xFu;
+    auto pf_issue = [&](int slot, int i) {
+      int l_ = lane;
+      asm volatile("" : "+v"(l_));
+      const int n_ = n0 + 32 * wn + (l_ & 7) * 4;
+      const int pix = rowpix[par * 64 + (i >> 2) * 32 + 8 * (i & 3) + (l_ >> 3)];
+      const bool live = pix >= 0 && n_ < a.Cd;
+      const unsigned e = (unsigned)(pix + n_ + cp * a.Cd);
+      const int o16 = live ? (int)(e * 4u) : (int)OOB, o1 = live ? (int)(e >> 2) : (int)OOB;
+      pf_y[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, o16, 0, 0));
+      pf_ym[slot] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_ym, o1, 0, 0) | ym_all;
+      pf_a[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, o16, 0, 0));
+      pf_am[slot] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_am, o1, 0, 0) | am_all;
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf_issue(i, i);
     __syncthreads();
     if (has_next) {          // the accumulators are dead: the next tile's first halo image travels while this tile's rows are stored
       setup_loader(y0_n, x0_n);
@@ -461,30 +488,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fs_act(v[j], a.ep_act);
           }
-          if (a.add_src != nullptr && live) {
-            f32x4 r = *reinterpret_cast<const f32x4*>(a.add_src + e);
-            if (a.add_mask != nullptr) {
-              const unsigned mk = a.add_mask[e >> 2];
+          if (want_a && live) {
+            f32x4 r = pf_a[k];
+            const unsigned mk = pf_am[k];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) r[j] = ((mk >> j) & 1u) ? r[j] : 0.f;
-            }
+            for (int j = 0; j < 4; ++j) r[j] = ((mk >> j) & 1u) ? r[j] : 0.f;
             v += r;
           }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
-          if (a.bn_y != nullptr) {           // BatchNorm-backward sums of the layer whose output gradient this is
+          if (want_y) {                      // BatchNorm-backward sums of the layer whose output gradient this is
             if (live) {
-              const f32x4 yy = *reinterpret_cast<const f32x4*>(a.bn_y + e);
+              const f32x4 yy = pf_y[k];
+              const unsigned mk = pf_ym[k];
               f32x4 gq = v;
-              if (a.bn_mask != nullptr) {
-                const unsigned mk = a.bn_mask[e >> 2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) gq[j] = ((mk >> j) & 1u) ? gq[j] : 0.f;
-              }
+              for (int j = 0; j < 4; ++j) gq[j] = ((mk >> j) & 1u) ? gq[j] : 0.f;
               csum += gq; csq += gq * ((yy - bn_mu) * bn_is);
             }
           } else {
             csum += v; csq += v * v;
           }
+          if (b == 0) pf_issue(k, 4 + k);
         }
       if (a.stats != nullptr) {
         // column sums over the wave's 64 rows: lanes with equal channel quad (lane & 7) hold different rows
@@ -783,6 +807,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_kernel(WinoArgs a) {
       for (int j = 0; j < 4; ++j) bv[j] = a.bias[n + j];
     }
     f32x4 csum = {0.f, 0.f, 0.f, 0.f}, csq = {0.f, 0.f, 0.f, 0.f};
+    const bool want_y = a.bn_y != nullptr, want_a = a.add_src != nullptr;
+    // four-row window of the bwd-data extras' operands (BatchNorm-backward sums, residual addend), as in the 4-wave kernel: round 0's rows
+    // are requested before the first exchange barrier, round 1's row k when round 0's row k has been consumed; issued without a branch
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.bn_y, want_y ? a.dst_bytes : 0u), rs_a = make_rsrc(a.add_src, want_a ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_ym = make_rsrc(a.bn_mask, a.bn_mask != nullptr ? a.dst_bytes >> 4 : 0u);
+    const __amdgpu_buffer_rsrc_t rs_am = make_rsrc(a.add_mask, a.add_mask != nullptr ? a.dst_bytes >> 4 : 0u);
+    const unsigned ym_all = a.bn_mask != nullptr ? 0u : 0xFu, am_all = a.add_mask != nullptr ? 0u : 0xFu;
+    f32x4 pf_y[4], pf_a[4];
+    unsigned pf_ym[4], pf_am[4];
+    auto pf_issue = [&](int slot, int i) {
+      int l_ = lane;
+      asm volatile("" : "+v"(l_));
+      const int pix = rowpix[par * 64 + (i >> 2) * 32 + 8 * (i & 3) + (l_ >> 3)];
+      const bool live = pix >= 0 && nok;
+      const unsigned e = (unsigned)(pix + n + cp * a.Cd);
+      const int o16 = live ? (int)(e * 4u) : (int)OOB, o1 = live ? (int)(e >> 2) : (int)OOB;
+      pf_y[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, o16, 0, 0));
+      pf_ym[slot] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_ym, o1, 0, 0) | ym_all;
+      pf_a[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, o16, 0, 0));
+      pf_am[slot] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_am, o1, 0, 0) | am_all;
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf_issue(i, i);
     f32x4 ep_sc = {1.f, 1.f, 1.f, 1.f}, ep_sh = {0.f, 0.f, 0.f, 0.f};
     if (a.ep_scale != nullptr && nok) {
 #pragma unroll
@@ -838,30 +885,27 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_kernel(WinoArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fs_act(v[j], a.ep_act);
           }
-          if (a.add_src != nullptr && live) {
-            f32x4 r = *reinterpret_cast<const f32x4*>(a.add_src + e);
-            if (a.add_mask != nullptr) {
-              const unsigned mk = a.add_mask[e >> 2];
+          if (want_a && live) {
+            f32x4 r = pf_a[kk];
+            const unsigned mk = pf_am[kk];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) r[j] = ((mk >> j) & 1u) ? r[j] : 0.f;
-            }
+            for (int j = 0; j < 4; ++j) r[j] = ((mk >> j) & 1u) ? r[j] : 0.f;
             v += r;
           }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
-          if (a.bn_y != nullptr) {           // BatchNorm-backward sums of the layer whose output gradient this is
+          if (want_y) {                      // BatchNorm-backward sums of the layer whose output gradient this is
             if (live) {
-              const f32x4 yy = *reinterpret_cast<const f32x4*>(a.bn_y + e);
+              const f32x4 yy = pf_y[kk];
+              const unsigned mk = pf_ym[kk];
               f32x4 gq = v;
-              if (a.bn_mask != nullptr) {
-                const unsigned mk = a.bn_mask[e >> 2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) gq[j] = ((mk >> j) & 1u) ? gq[j] : 0.f;
-              }
+              for (int j = 0; j < 4; ++j) gq[j] = ((mk >> j) & 1u) ? gq[j] : 0.f;
               csum += gq; csq += gq * ((yy - bn_mu) * bn_is);
             }
           } else {
             csum += v; csq += v * v;
           }
+          if (b == 0) pf_issue(kk, 4 + kk);
         }
       }
       __syncthreads();
