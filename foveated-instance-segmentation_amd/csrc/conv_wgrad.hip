@@ -468,6 +468,185 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino_kernel(WwArgs a) {
   }
 }
 
+// ---- 1x1 / stride 1 weight gradient = the weight gradient of a linear layer: dW[ci][co] = sum_rows X[row][ci] * dY[row][co] (round 3) ----
+// The class kernel above pays its per-patch cost (exposed loads, two barriers) for 24 MFMAs per wave when the class is a single tap; here
+// a workgroup owns a (WM*MI*32) x (WN*NI*32) tile of dW (128 x 128 for wide layers: 2 x 2 accumulators per wave, half the LDS fragment
+// reads per MFMA of a 32 x 32 wave tile) and a contiguous range of rows (split-K, fp32 atomics at the end), walks it in chunks of 32 rows
+// (two k-steps of 16), and the next chunk's global loads are in flight during the MFMA phase.  LDS images as in the class kernel:
+// [plane][32-channel block][32 rows][32 ch] 16-bit, natural order, both operands read transposed by ds_read_b64_tr_b16.
+// Unscaled split only (bf16x3): the f16x2 mode keeps the class kernel and its running exponents.
+struct LwArgs {
+  const float* x;     // [rows][Cin]
+  const float* dy;    // [rows][Cout]
+  float* dw;          // [Cin][Cout], zero-initialised or accumulated into
+  int rows, Cin, Cout, tiles_ci, tiles_co, rows_per_split;
+  unsigned x_bytes, dy_bytes;
+};
+
+template <class P, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(LwArgs a) {
+  static_assert(WM * WN == 4, "four waves");
+  typedef typename P::x8 X8;
+  typedef typename P::x4 X4;
+  constexpr int NPL = P::NPL;
+  constexpr int XB = WM * MI, YB = WN * NI;               // 32-channel blocks of the tile
+  constexpr int BLK = 32 * 64;                            // bytes of one block image: 32 rows x 32 channels x 2 B
+  constexpr int XPL = XB * BLK, YPL = YB * BLK;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NPL * (XPL + YPL)];
+  unsigned char* const Xl = lds;
+  unsigned char* const Yl = lds + NPL * XPL;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int ntile = a.tiles_ci * a.tiles_co;
+  // XCD-aware order (as the class kernel): the ntile workgroups of one split -- same rows, different channel tiles -- share one L2
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd = nwg >> 3, rmd = nwg & 7;
+  const int wg = (xcd < rmd ? xcd * (qd + 1) : rmd * (qd + 1) + (xcd - rmd) * qd) + loc;
+  const int split = wg / ntile, tile = wg - split * ntile;
+  const int tci = tile / a.tiles_co, tco = tile - tci * a.tiles_co;
+  const int ci0 = tci * (XB * 32), co0 = tco * (YB * 32);
+  const int k_begin = split * a.rows_per_split;
+  const int k_end = k_begin + a.rows_per_split < a.rows ? k_begin + a.rows_per_split : a.rows;
+
+  // loader: item i of a thread = (row tid >> 3 of the chunk, channel quad tid & 7 of block i): 8 lanes read 128 contiguous bytes of a row,
+  // a wave writes 8 rows x 64 B = 512 contiguous bytes of one block image
+  const int lrow = tid >> 3, quad = tid & 7;
+  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.x, a.x_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(a.dy, a.dy_bytes);
+  int xoff[XB], yoff[YB];        // byte offset of item i in row 0, -1 = channel beyond the tensor
+#pragma unroll
+  for (int i = 0; i < XB; ++i) { const int c = ci0 + 32 * i + 4 * quad; xoff[i] = c < a.Cin ? c * 4 : -1; }
+#pragma unroll
+  for (int i = 0; i < YB; ++i) { const int c = co0 + 32 * i + 4 * quad; yoff[i] = c < a.Cout ? c * 4 : -1; }
+  f32x4 rx[XB], ry[YB];
+  auto load_chunk = [&](int k) {
+    const int r = k + lrow;
+    const bool rok = r < k_end;
+    const int xr = r * a.Cin * 4, yr = r * a.Cout * 4;
+#pragma unroll
+    for (int i = 0; i < XB; ++i)
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, rok && xoff[i] >= 0 ? xr + xoff[i] : (int)OOB, 0, 0));
+#pragma unroll
+    for (int i = 0; i < YB; ++i)
+      ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, rok && yoff[i] >= 0 ? yr + yoff[i] : (int)OOB, 0, 0));
+  };
+  const int wofs = lrow * 64 + quad * 8;     // + block * BLK + plane * XPL / YPL
+
+  // transposed-read lane constants (class kernel): 16-lane group g reads rows q = 0..3 of its 8-row half, columns cb + 4 pp .. + 3
+  const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, g = lane >> 4, lh = g >> 1, cb = 16 * (g & 1);
+  const int rofs = (8 * lh + q) * 64 + (cb + 4 * pp) * 2;      // + ks * 1024 + t * 256 + block * BLK + plane * PL
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  auto tr = [&](const unsigned char* base, int off) -> X4 { return P::tr_read(base + off); };
+  auto cat = [](X4 lo, X4 hi) -> X8 { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); };
+
+  if (k_begin < k_end) load_chunk(k_begin);
+  for (int k = k_begin; k < k_end; k += 32) {
+    X4 px[XB][NPL], py[YB][NPL];
+#pragma unroll
+    for (int i = 0; i < XB; ++i) P::split4(rx[i], px[i]);
+#pragma unroll
+    for (int i = 0; i < YB; ++i) P::split4(ry[i], py[i]);
+    __syncthreads();                 // every wave has finished reading the previous chunk
+#pragma unroll
+    for (int i = 0; i < XB; ++i)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Xl[wofs + i * BLK + pl * XPL]) = px[i][pl];
+#pragma unroll
+    for (int i = 0; i < YB; ++i)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Yl[wofs + i * BLK + pl * YPL]) = py[i][pl];
+    __syncthreads();
+    if (k + 32 < k_end) load_chunk(k + 32);          // in flight during the MFMA phase
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      X8 fa[MI][NPL], fb[NI][NPL];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          const int o = rofs + ks * 1024 + (wm * MI + mi) * BLK + pl * XPL;
+          fa[mi][pl] = cat(tr(Xl, o), tr(Xl, o + 256));
+        }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          const int o = rofs + ks * 1024 + (wn * NI + ni) * BLK + pl * YPL;
+          fb[ni][pl] = cat(tr(Yl, o), tr(Yl, o + 256));
+        }
+#pragma unroll
+      for (int t = 0; t < P::NTERM; ++t)          // smallest terms first
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = P::mfma(fa[mi][P::ta(t)], fb[ni][P::tb(t)], acc[mi][ni]);
+    }
+  }
+
+  if (k_begin >= k_end) return;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int co = co0 + (wn * NI + ni) * 32 + (lane & 31);
+      if (co >= a.Cout) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (ci < a.Cin) atomicAdd(&a.dw[(long)ci * a.Cout + co], acc[mi][ni][r]);
+      }
+    }
+}
+
+template <class P, int WM, int WN, int MI, int NI>
+int launch_linear_wgrad(LwArgs a, int target, hipStream_t stream) {
+  a.tiles_ci = cdiv(a.Cin, WM * MI * 32); a.tiles_co = cdiv(a.Cout, WN * NI * 32);
+  const int ntile = a.tiles_ci * a.tiles_co;
+  int nsplit = target / ntile;
+  if (nsplit < 1) nsplit = 1;
+  a.rows_per_split = cdiv(cdiv(a.rows, nsplit), 32) * 32;
+  nsplit = cdiv(a.rows, a.rows_per_split);
+  hipLaunchKernelGGL((linear_wgrad_kernel<P, WM, WN, MI, NI>), dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// Tile and split choice, from a sweep over the SegFormer-B5 and HRNet 1x1 layers (profiles/r03/linear_wgrad_sweep.txt): narrow operands
+// take a 64-wide tile on their side; wide layers take 128 x 128 over 512 workgroups while a split still sees >= 512 rows (the row loop
+// dominates), otherwise 64 x 64 over 1024 (a quarter of the atomics per workgroup: the epilogue dominates).
+int run_linear_wgrad(LwArgs l, hipStream_t stream) {
+  static const int force = [] { const char* e = getenv("FS_LW_TILE"); return e ? atoi(e) : 0; }();       // kernel A/B only, read once
+  static const int force_wgs = [] { const char* e = getenv("FS_LW_WGS"); return e ? atoi(e) : 0; }();
+  int tile, target = 512;
+  if (l.Cin <= 64 && l.Cout <= 64) tile = 1;
+  else if (l.Cin <= 64) tile = 2;
+  else if (l.Cout <= 64) tile = 3;
+  else {
+    const int ntile = cdiv(l.Cin, 128) * cdiv(l.Cout, 128);
+    const int nsplit = 512 / ntile > 0 ? 512 / ntile : 1;
+    tile = l.rows / nsplit >= 512 ? 4 : 1;
+    if (tile == 1) target = 1024;
+  }
+  if (force >= 1 && force <= 4) tile = force;
+  if (force_wgs > 0) target = force_wgs;
+  switch (tile) {
+    case 1: return launch_linear_wgrad<PrecX3, 2, 2, 1, 1>(l, target, stream);      //  64 x  64
+    case 2: return launch_linear_wgrad<PrecX3, 1, 4, 2, 1>(l, target, stream);      //  64 x 128
+    case 3: return launch_linear_wgrad<PrecX3, 4, 1, 1, 2>(l, target, stream);      // 128 x  64
+    default: return launch_linear_wgrad<PrecX3, 2, 2, 2, 2>(l, target, stream);     // 128 x 128
+  }
+}
+
 // Ph rows x PP pairs <= 32 pairs, (Ph + 2) PP <= 48 slots, PP >= 1: fewest patches, then largest fill
 void choose_wgrad_wino_patch(int H, int W, int& Ph, int& PP) {
   const int wp = W / 2;
@@ -595,5 +774,12 @@ int fs_wgrad_split(int mode, const float* x, const float* dy, float* dw, int B, 
     return FS_OK;
   }
 direct:
+  static const bool linear_on = [] { const char* e = getenv("FS_WGRAD_LINEAR"); return e == nullptr || atoi(e) != 0; }();      // read once (kernel A/B)
+  if (mode == 1 && linear_on && R == 1 && S == 1 && stride == 1 && pad == 0 && H == Ho && W == Wo) {
+    LwArgs l;
+    l.x = x; l.dy = dy; l.dw = dw; l.rows = B * H * W; l.Cin = Cin; l.Cout = Cout;
+    l.x_bytes = a.x_bytes; l.dy_bytes = a.dy_bytes;
+    return run_linear_wgrad(l, stream);
+  }
   return mode == 2 ? run_classes<PrecF16>(a, ntile, R, S, stride, pad, stream) : run_classes<PrecX3>(a, ntile, R, S, stride, pad, stream);
 }

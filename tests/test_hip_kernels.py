@@ -190,6 +190,37 @@ def test_conv_fwd_bwd_production_sizes(case, prec):
     assert relerr(dw.cpu(), w64.grad) <= 2e-5
 
 
+# Weight gradient of a linear layer / 1x1 convolution (csrc/conv_wgrad.hip linear_wgrad_kernel, bf16x3): rows x Cin x Cout chosen to reach
+# every tile (64x64, 64x128, 128x64, 128x128 needs >= 512 rows per split), ragged channel counts (not multiples of 32), ragged row
+# counts (not multiples of the 32-row chunk), fewer rows than one chunk, and accumulation into an existing gradient.
+LINEAR_WGRAD_CASES = [(1000, 48, 96), (4100, 64, 64), (333, 64, 200), (2050, 200, 64), (70001, 160, 136), (17, 320, 1280), (6400, 512, 512),
+                      (1600, 1280, 320), (25600, 320, 324)]
+
+
+@pytest.mark.parametrize("rows,Ci,Co", LINEAR_WGRAD_CASES)
+def test_linear_weight_gradient(rows, Ci, Co):
+    fovealseg.hip.set_conv_precision("bf16x3")
+    try:
+        g = torch.Generator().manual_seed(rows + Ci + Co)
+        x = torch.randn(rows, Ci, generator=g)
+        dy = torch.randn(rows, Co, generator=g)
+        ref = (x.double().t() @ dy.double())                                  # [Ci][Co]
+        xd, dyd = x.to(DEV).view(1, rows, 1, Ci), dy.to(DEV).view(1, rows, 1, Co)
+        dw = ops.conv2d_bwd_weight(xd, dyd, (Co, Ci, 1, 1), 1, 0)             # (Co,Ci,1,1) view of the RSCK buffer
+        got = dw[:, :, 0, 0].t().double().cpu()
+        # 24-bit operands (2^-24 per factor, random over `rows` products) and fp32 accumulation, the split-K partial sums added by
+        # atomics at the magnitude of the running sum: measured 4e-7 of max |dW| on these shapes
+        assert relerr(got, ref) <= 3e-6
+        # accumulate = True adds to what the buffer holds
+        buf = ops.new_rsck_weight(Co, Ci, 1, 1, device=DEV)
+        ops.rsck(buf).fill_(1.5)
+        ops.conv2d_bwd_weight(xd, dyd, (Co, Ci, 1, 1), 1, 0, out=buf, accumulate=True)
+        got2 = buf[:, :, 0, 0].t().double().cpu()
+        assert relerr(got2 - 1.5, ref) <= 2e-5            # (each atomic add now rounds at the magnitude of the running sum)
+    finally:
+        fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
+
+
 SPLIT_SHAPES = [(2, 24, 24, 64, 64, 1), (1, 20, 20, 128, 96, 1), (2, 24, 24, 64, 128, 2)]   # halo 3x3, 2-chunk 3x3, tap-class stride 2
 
 

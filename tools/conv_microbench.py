@@ -25,6 +25,16 @@ SHAPES = [  # B, H, W, Cin, Cout, k, stride
     (64, 20, 20, 512, 512, 3, 2),
 ]
 
+# the linear layers of configs[3] (SegFormer-B5 at 160x160, B=16) as 1x1 convs over (1, tokens, 1, C): MB_SET=segformer
+SEGFORMER = [   # strides (1,2,2,2): 160x160, 80x80, 40x40, 20x20 tokens per image
+    (16, 160, 160, 64, 64, 1, 1), (16, 160, 160, 64, 256, 1, 1), (16, 160, 160, 256, 64, 1, 1),
+    (16, 80, 80, 128, 128, 1, 1), (16, 80, 80, 128, 512, 1, 1), (16, 80, 80, 512, 128, 1, 1),
+    (16, 40, 40, 320, 320, 1, 1), (16, 20, 20, 320, 320, 1, 1), (16, 40, 40, 320, 1280, 1, 1), (16, 40, 40, 1280, 320, 1, 1),
+    (16, 20, 20, 512, 512, 1, 1), (16, 20, 20, 512, 2048, 1, 1), (16, 20, 20, 2048, 512, 1, 1),
+]
+if os.environ.get("MB_SET") == "segformer":
+    SHAPES = SEGFORMER
+
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
