@@ -97,6 +97,119 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int c = threadIdx.x; c < C; c += blockDim.x) { atomicAdd(&dgamma[c], sm[c]); atomicAdd(&dbeta[c], sm[C + c]); }
 }
 
+// Sixteen lanes per row (C <= 320): the Mix-Transformer widths are 64 .. 512, where a wave per row leaves 3/4 (C = 64) to 3/8 (C = 320,
+// second pass) of its lanes idle -- 0.6 TB/s on the 160 x 160 stage.  Lane l of a group owns the float4s at 4 l + 64 j, j < NJ = ceil(C / 64):
+// a group reads 256 contiguous bytes per j, a wave works on four rows, and the row reductions are four DPP-width shuffles.
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int NJ>
+__global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ y,
+                                                              float* __restrict__ mean, float* __restrict__ rstd, long M, int C, float eps) {
+  const int l16 = threadIdx.x & 15;
+  const long row = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const bool rok = row < M;                     // (lanes of a missing row stay for the shuffles)
+  const float* xr = x + row * C;
+  f32x4 v[NJ];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = 4 * l16 + 64 * j;
+    v[j] = f32x4{0, 0, 0, 0};
+    if (rok && c < C) { v[j] = *reinterpret_cast<const f32x4*>(xr + c); s += v[j].x + v[j].y + v[j].z + v[j].w; }
+  }
+  const float mu = group16_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = 4 * l16 + 64 * j;
+    if (c < C) { const f32x4 d = v[j] - mu; q += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w; }
+  }
+  const float rs = rsqrtf(group16_sum(q) / (float)C + eps);
+  if (!rok) return;
+  if (l16 == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = 4 * l16 + 64 * j;
+    if (c < C) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+      *reinterpret_cast<f32x4*>(y + row * C + c) = (v[j] - mu) * rs * g + b;
+    }
+  }
+}
+
+template <int NJ>
+__global__ __launch_bounds__(256) void layernorm_bwd16_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, float* __restrict__ dx,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, long M, int C,
+                                                              int rows_per_block) {
+  extern __shared__ float sm[];          // [2][C] block partials of dgamma / dbeta
+  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) sm[c] = 0.f;
+  __syncthreads();
+  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+  f32x4 ag[NJ], ab[NJ], gm[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = 4 * l16 + 64 * j;
+    ag[j] = f32x4{0, 0, 0, 0}; ab[j] = f32x4{0, 0, 0, 0};
+    gm[j] = c < C ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0, 0, 0, 0};
+  }
+  for (long rb = r0; rb < r1; rb += 16) {       // (uniform trip count per wave: the shuffles need all four groups)
+    const long row = rb + grp;
+    const bool rok = row < r1;
+    const float mu = rok ? mean[row] : 0.f, rs = rok ? rstd[row] : 0.f;
+    f32x4 gg[NJ], xh[NJ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = 4 * l16 + 64 * j;
+      gg[j] = f32x4{0, 0, 0, 0}; xh[j] = f32x4{0, 0, 0, 0};
+      if (rok && c < C) {
+        const f32x4 go = *reinterpret_cast<const f32x4*>(g + row * C + c);
+        xh[j] = (*reinterpret_cast<const f32x4*>(x + row * C + c) - mu) * rs;
+        ag[j] += go * xh[j]; ab[j] += go;
+        gg[j] = go * gm[j];
+        s1 += gg[j].x + gg[j].y + gg[j].z + gg[j].w;
+        const f32x4 t = gg[j] * xh[j];
+        s2 += t.x + t.y + t.z + t.w;
+      }
+    }
+    const float m1 = group16_sum(s1) / (float)C, m2 = group16_sum(s2) / (float)C;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = 4 * l16 + 64 * j;
+      if (rok && c < C) *reinterpret_cast<f32x4*>(dx + row * C + c) = rs * (gg[j] - m1 - xh[j] * m2);
+    }
+  }
+  // the four groups of a wave hold partials of the same channels: add them across the wave first (lanes l, l ^ 16, l ^ 32, l ^ 48)
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ag[j][e] += __shfl_xor(ag[j][e], 16, 64); ag[j][e] += __shfl_xor(ag[j][e], 32, 64);
+      ab[j][e] += __shfl_xor(ab[j][e], 16, 64); ab[j][e] += __shfl_xor(ab[j][e], 32, 64);
+    }
+  if ((threadIdx.x & 63) < 16) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = 4 * l16 + 64 * j;
+      if (c < C) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { atomicAdd(&sm[c + e], ag[j][e]); atomicAdd(&sm[C + c + e], ab[j][e]); }
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) { atomicAdd(&dgamma[c], sm[c]); atomicAdd(&dbeta[c], sm[C + c]); }
+}
+
 // ------------------------------------------------------------------------------------------
 // exact GELU
 // ------------------------------------------------------------------------------------------
@@ -637,7 +750,14 @@ extern "C" {
 int fs_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long M, int C,
                      float eps, hipStream_t stream) {
   FS_REQUIRE(x && gamma && beta && y && mean && rstd && M > 0 && C > 0 && C % 4 == 0 && C <= 2048);
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, M, C, eps);
+  const int need = cdiv(C, 64);
+  const dim3 grid16((unsigned)cdiv(M, 16));
+#define FS_LN_FWD16(NJ_) hipLaunchKernelGGL(layernorm_fwd16_kernel<NJ_>, grid16, dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, M, C, eps)
+  if (need <= 1) FS_LN_FWD16(1);
+  else if (need <= 2) FS_LN_FWD16(2);
+  else if (need <= 5) FS_LN_FWD16(5);
+  else hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, M, C, eps);
+#undef FS_LN_FWD16
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -652,9 +772,21 @@ int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const f
     e = hipMemsetAsync(dbeta, 0, C * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
   }
-  int rpb = (int)((M + 1023) / 1024); if (rpb < 4) rpb = 4;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 2 * C * sizeof(float), stream, g, x, gamma, mean, rstd,
-                     dx, dgamma, dbeta, M, C, rpb);
+  const int need = cdiv(C, 64);
+  if (need <= 5) {                  // (wider rows fill a wave per row; 8 float4s per lane of five arrays would spill)
+    // 16 rows in flight per workgroup; ~2048 workgroups (8 per CU) so the 2 C global atomics per workgroup stay a small share
+    int rpb = (int)((M + 2047) / 2048); rpb = (rpb + 15) / 16 * 16; if (rpb < 16) rpb = 16;
+    const dim3 grid((unsigned)cdiv(M, rpb));
+#define FS_LN_BWD16(NJ_) hipLaunchKernelGGL(layernorm_bwd16_kernel<NJ_>, grid, dim3(256), 2 * C * sizeof(float), stream, g, x, gamma, mean, rstd, dx, dgamma, dbeta, M, C, rpb)
+    if (need <= 1) FS_LN_BWD16(1);
+    else if (need <= 2) FS_LN_BWD16(2);
+    else FS_LN_BWD16(5);
+#undef FS_LN_BWD16
+  } else {
+    int rpb = (int)((M + 1023) / 1024); if (rpb < 4) rpb = 4;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 2 * C * sizeof(float), stream, g, x, gamma, mean, rstd,
+                       dx, dgamma, dbeta, M, C, rpb);
+  }
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -1365,8 +1365,10 @@ def test_deeplab_through_module_surface():
 # ------------------------------------------------------------------------------------------------
 def test_layernorm_gelu_dwconv_droppath():
     g = torch.Generator().manual_seed(41)
-    for C in (64, 320, 2048):
-        x = torch.randn(3, 37, C, generator=g)
+    # 16-lanes-per-row kernels for C <= 320 (one to five float4s per lane; 132 = ragged last float4 column), a wave per row above;
+    # 111 rows = a ragged last group of 16, 40 003 rows = several 16-row rounds per workgroup in the backward
+    for C, lead in ((64, (3, 37)), (128, (3, 37)), (132, (3, 37)), (320, (3, 37)), (512, (3, 37)), (2048, (3, 37)), (64, (1, 40003)), (320, (1, 5001))):
+        x = torch.randn(*lead, C, generator=g)
         w, b = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
         xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
         ref = F.layer_norm(xr, (C,), wr, br, 1e-6)
