@@ -1332,6 +1332,25 @@ int fs_conv2d_bwd_data_bnsum(const float* dy, const float* w, float* dx, int B, 
 }
 
 // include/fovealseg.h: fs_conv2d_bwd_weight   (dw is overwritten, or added to when accumulate != 0)
+// include/fovealseg.h: fs_linear_bwd_weight_bias_ok -- 1 when the fused launch below exists for this shape in the current mode
+int fs_linear_bwd_weight_bias_ok(long rows, int Cin, int Cout) { return fs_linear_wgrad_eligible(g_conv_precision, rows, Cin, Cout) ? 1 : 0; }
+
+// include/fovealseg.h: fs_linear_bwd_weight_bias -- dW[Cin][Cout] = x^T dy and dbias[Cout] = column sums of dy in one launch
+int fs_linear_bwd_weight_bias(const float* x, const float* dy, float* dw, float* dbias, long rows, int Cin, int Cout, int accumulate_w,
+                              int accumulate_b, hipStream_t stream) {
+  FS_REQUIRE(x && dy && dw && dbias);
+  FS_REQUIRE(fs_linear_bwd_weight_bias_ok(rows, Cin, Cout) == 1);
+  if (!accumulate_w) {
+    const hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cin * Cout, stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (!accumulate_b) {
+    const hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cout, stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  return fs_linear_wgrad(x, dy, dw, dbias, rows, Cin, Cout, stream);
+}
+
 int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo,
                          int Cout, int R, int S, int stride, int pad, int dil, int accumulate, hipStream_t stream) {
   FS_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);

@@ -47,6 +47,8 @@ int fs_pointwise_conv(int mode, const float* src, const float* w, const float* b
 // ---- conv_wgrad.hip: split-precision weight gradient, one launch per tap class (dw zeroed by the caller or accumulated into) ----
 // any square filter / stride whose tap classes have at most 2 taps per dimension (3x3 s2/s4, 1x1 any stride), plus 3x3 s1
 bool fs_wgrad_split_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil);
+bool fs_linear_wgrad_eligible(int mode, long rows, int Cin, int Cout);
+int fs_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, long rows, int Cin, int Cout, hipStream_t stream);
 int fs_wgrad_split(int mode, const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S,
                    int stride, int pad, hipStream_t stream);
 

@@ -479,6 +479,7 @@ struct LwArgs {
   const float* x;     // [rows][Cin]
   const float* dy;    // [rows][Cout]
   float* dw;          // [Cin][Cout], zero-initialised or accumulated into
+  float* dbias;       // nullable: [Cout] column sums of dy (the layer's bias gradient), zero-initialised or accumulated into
   int rows, Cin, Cout, tiles_ci, tiles_co, rows_per_split;
   unsigned x_bytes, dy_bytes;
 };
@@ -549,8 +550,18 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(LwArgs a) {
   auto tr = [&](const unsigned char* base, int off) -> X4 { return P::tr_read(base + off); };
   auto cat = [](X4 lo, X4 hi) -> X8 { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); };
 
+  // bias gradient: the workgroups of the first ci tile also sum the dY rows they load anyway (rows beyond the range load as zero)
+  const bool want_b = a.dbias != nullptr && tci == 0;
+  f32x4 bs[YB];
+#pragma unroll
+  for (int i = 0; i < YB; ++i) bs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
   if (k_begin < k_end) load_chunk(k_begin);
   for (int k = k_begin; k < k_end; k += 32) {
+    if (want_b) {
+#pragma unroll
+      for (int i = 0; i < YB; ++i) bs[i] += ry[i];
+    }
     X4 px[XB][NPL], py[YB][NPL];
 #pragma unroll
     for (int i = 0; i < XB; ++i) P::split4(rx[i], px[i]);
@@ -594,6 +605,16 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(LwArgs a) {
   }
 
   if (k_begin >= k_end) return;
+  if (want_b) {        // lanes of a wave with equal channel quad (lane & 7) hold different rows
+#pragma unroll
+    for (int i = 0; i < YB; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = bs[i][e];
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (lane < 8 && yoff[i] >= 0) atomicAdd(&a.dbias[co0 + 32 * i + 4 * quad + e], v);
+      }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -716,6 +737,18 @@ int run_classes(WgArgs& a, int ntile, int R, int S, int stride, int pad, hipStre
 }
 }  // namespace
 
+// dW and dbias of a linear layer in one launch (bf16x3 only; include/fovealseg.h fs_linear_bwd_weight_bias)
+bool fs_linear_wgrad_eligible(int mode, long rows, int Cin, int Cout) {
+  return mode == 1 && rows > 0 && Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 16 && Cout >= 16 &&
+         (size_t)rows * Cin * 4 < 4294967000UL && (size_t)rows * Cout * 4 < 4294967000UL;
+}
+int fs_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, long rows, int Cin, int Cout, hipStream_t stream) {
+  LwArgs l;
+  l.x = x; l.dy = dy; l.dw = dw; l.dbias = dbias; l.rows = (int)rows; l.Cin = Cin; l.Cout = Cout;
+  l.x_bytes = (unsigned)((size_t)rows * Cin * 4); l.dy_bytes = (unsigned)((size_t)rows * Cout * 4);
+  return run_linear_wgrad(l, stream);
+}
+
 bool fs_wgrad_split_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil) {
   (void)pad;
   if (dil != 1 || Cin % 4 || Cout % 4 || Cin < 16 || Cout < 16 || R != S) return false;
@@ -777,7 +810,7 @@ direct:
   static const bool linear_on = [] { const char* e = getenv("FS_WGRAD_LINEAR"); return e == nullptr || atoi(e) != 0; }();      // read once (kernel A/B)
   if (mode == 1 && linear_on && R == 1 && S == 1 && stride == 1 && pad == 0 && H == Ho && W == Wo) {
     LwArgs l;
-    l.x = x; l.dy = dy; l.dw = dw; l.rows = B * H * W; l.Cin = Cin; l.Cout = Cout;
+    l.x = x; l.dy = dy; l.dw = dw; l.dbias = nullptr; l.rows = B * H * W; l.Cin = Cin; l.Cout = Cout;
     l.x_bytes = a.x_bytes; l.dy_bytes = a.dy_bytes;
     return run_linear_wgrad(l, stream);
   }

@@ -41,6 +41,7 @@ SIGNATURES = {
     "fs_conv2d_bwd_data_bnsum": "pppiiiiiiiiiiiiplp" + "ppppp" + "pp",
     "fs_weight_amax_segments": "pppip",
     "fs_conv2d_bwd_weight": "pppiiiiiiiiiiiii",
+    "fs_linear_bwd_weight_bias": "pppp" + "lii" + "ii",
     "fs_bn_stats": "pliffppppp",
     "fs_bn_finalize_slab": "piliffpppp",
     "fs_bn_eval_prepare": "ppifpp",
@@ -84,7 +85,7 @@ _lib = None
 # declared in the header, host-side only (no stream argument)
 HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice",
              "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes", "fs_conv2d_bwd_data_bnsum_slabs",
-             "fs_conv2d_fwd_affine_act_ok")
+             "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok")
 
 
 class HipLibraryError(RuntimeError):
@@ -123,6 +124,8 @@ def load():
     lib.fs_conv2d_bwd_data_bnsum_slabs.argtypes = [_I] * 12 + [_L]
     lib.fs_conv2d_fwd_affine_act_ok.restype = _I
     lib.fs_conv2d_fwd_affine_act_ok.argtypes = [_I] * 12 + [_L]
+    lib.fs_linear_bwd_weight_bias_ok.restype = _I
+    lib.fs_linear_bwd_weight_bias_ok.argtypes = [_L, _I, _I]
     _lib = lib
     global _default_mode
     _default_mode = ("f32", "bf16x3", "f16x2")[lib.fs_get_conv_precision()]
@@ -166,6 +169,15 @@ def conv_stats_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_byte
     v = _ws_cache.get(key)
     if v is None:
         v = _ws_cache[key] = int(load().fs_conv2d_stats_slabs(*key[1:]))
+    return v
+
+
+def linear_bwd_weight_bias_ok(rows, Cin, Cout):
+    """True where fs_linear_bwd_weight_bias (dW and dbias of a linear layer in one launch) exists under the current precision mode."""
+    key = ("lwb", rows, Cin, Cout)
+    v = _ws_cache.get(key)
+    if v is None:
+        v = _ws_cache[key] = int(load().fs_linear_bwd_weight_bias_ok(rows, Cin, Cout)) == 1
     return v
 
 

@@ -591,6 +591,16 @@ class ConvBias(Function):
             dy = masked
         dx = conv2d_bwd_data(dy, w, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
         tgt = _direct_grad_target(w)
+        cout, cin, r, s = w.shape
+        rows = dy.numel() // cout
+        if has_bias and r == 1 and s == 1 and stride == 1 and pad == 0 and hip.linear_bwd_weight_bias_ok(rows, cin, cout):
+            # a linear layer: the bias gradient (column sums of dy) rides in the weight-gradient launch, which reads dy anyway
+            btgt = _direct_grad_target(ctx.bias_ref)
+            dw = rsck(tgt) if tgt is not None else torch.empty(1, 1, cin, cout, device=x.device, dtype=torch.float32)
+            db = btgt if btgt is not None else torch.empty(cout, device=x.device, dtype=torch.float32)
+            _launch("conv_wgrad", 2.0 * rows * cout * cin, "fs_linear_bwd_weight_bias", hip.ptr(x), hip.ptr(dy), hip.ptr(dw), hip.ptr(db),
+                    rows, cin, cout, 1 if tgt is not None else 0, 1 if btgt is not None else 0)
+            return (dx, None if tgt is not None else dw.permute(3, 2, 0, 1), None if btgt is not None else db, None, None, None, None)
         dw = conv2d_bwd_weight(x, dy, w.shape, stride, pad, out=tgt, accumulate=tgt is not None)
         if tgt is not None:
             dw = None

@@ -154,6 +154,13 @@ int fs_conv2d_bwd_data_bnsum(const float* dy, const float* w, float* dx, int B, 
                              int S, int stride, int pad, int dil, void* ws, long ws_bytes, const unsigned* w_amax, const float* bn_y,
                              const unsigned char* bn_mask, const float* bn_mean, const float* bn_invstd, float* slab, const float* add_src,
                              const unsigned char* add_mask, fs_stream_t stream);
+/* nn.Linear backward w.r.t. its parameters in one launch (the ATen addmm / sum backward behind transformers' modeling_segformer linears,
+ * call sites models/segformer.py:9-11,33-37): dw[Cin][Cout] = x^T dy over `rows` rows, dbias[Cout] = column sums of dy.  Exists in the
+ * bf16x3 mode for Cin, Cout multiples of 4 and >= 16 (fs_linear_bwd_weight_bias_ok == 1); otherwise FS_ERR_ARG -- callers then use
+ * fs_conv2d_bwd_weight + fs_colsum.  accumulate_w / accumulate_b as `accumulate` below. */
+int fs_linear_bwd_weight_bias_ok(long rows, int Cin, int Cout);
+int fs_linear_bwd_weight_bias(const float* x, const float* dy, float* dw, float* dbias, long rows, int Cin, int Cout, int accumulate_w,
+                              int accumulate_b, fs_stream_t stream);
 /* accumulate = 0: dw is overwritten; 1: the gradient is ADDED to dw (torch's .grad accumulation; saves the memset when the caller
  * keeps a zeroed gradient arena). */
 int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,

@@ -217,6 +217,14 @@ def test_linear_weight_gradient(rows, Ci, Co):
         ops.conv2d_bwd_weight(xd, dyd, (Co, Ci, 1, 1), 1, 0, out=buf, accumulate=True)
         got2 = buf[:, :, 0, 0].t().double().cpu()
         assert relerr(got2 - 1.5, ref) <= 2e-5            # (each atomic add now rounds at the magnitude of the running sum)
+        # the fused entry point: the same dW plus the bias gradient (column sums of dy) from the one launch
+        assert fovealseg.hip.linear_bwd_weight_bias_ok(rows, Ci, Co)
+        dw3 = torch.empty(Ci, Co, device=DEV)
+        db3 = torch.full((Co,), 0.25, device=DEV)
+        fovealseg.hip.call("fs_linear_bwd_weight_bias", fovealseg.hip.ptr(xd), fovealseg.hip.ptr(dyd), fovealseg.hip.ptr(dw3),
+                           fovealseg.hip.ptr(db3), rows, Ci, Co, 0, 1)
+        assert relerr(dw3.double().cpu(), ref) <= 3e-6
+        assert relerr(db3.double().cpu() - 0.25, dy.double().sum(0)) <= 3e-6
     finally:
         fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
 
