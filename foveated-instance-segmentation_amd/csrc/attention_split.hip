@@ -1,0 +1,237 @@
+// Sequence-reduced multi-head attention (head_dim 64, any key count) on the 16-bit matrix pipe in split precision (bf16x3, conv_split.h):
+// every fp32 operand -- q*scale, k, v, the softmax probabilities -- enters as three bf16 planes (24 bits, the fp32 operand width) and a
+// product is six v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Against the exact-fp32 kernels of transformer.hip (v_mfma_f32_32x32x2_f32,
+// 16 passes per 2 k) that is 3/8 of the matrix-pipe time; the rest of the gain is the TRANSPOSED score tile:
+//
+//     S^T[key][q] = K (q*scale)^T        A = K rows (keys), B = Q rows (lane = query)
+//
+// whose accumulator layout puts a query in a LANE and its keys in REGISTERS (element i of lane (r, h) = key (i&3) + 8(i>>2) + 4h, query r).
+// The softmax statistics of a query are then one scalar per lane (running max m, running sum l; the two 32-lane halves hold the same
+// queries and different keys, one xor-32 shuffle joins them) instead of sixteen 32-lane reductions per tile, and the probabilities are
+// ALREADY the B operand of
+//
+//     O^T[d][q] = V^T P~^T               A = V^T rows (head dim), B = P~^T straight from the registers (k = keys in register order)
+//
+// so P never goes through LDS.  The k order of that product is the register order: position j of half h in k-step s2 of key tile t is key
+// 32t + 16 s2 + 4h + (j&3) + 8(j>>2); the A operand reads V^T[d][those keys] as two 8-byte pieces.
+//
+// K and V are small (B x Nk x C) and shared by every query tile, so a pre-pass writes them ONCE as planes in the LDS image order
+// (fs_attention_split_ws_bytes of scratch): per (batch*head, 64-key chunk) a 48 KB block [K: 3 planes][64 keys][64 d] then
+// [V^T: 3 planes][64 d][64 keys], keys beyond Nk zero.  The attention kernel copies a block to LDS per chunk (K rows at a 144-byte pitch:
+// conflict-free ds_read_b128 over 16 lanes; V^T rows at 136 bytes: conflict-free ds_read_b64 over 32 lanes) and does no operand splitting
+// of its own except P.
+//
+// Replaces: torch.matmul / softmax / dropout / matmul of transformers==4.46.2 SegformerEfficientSelfAttention.forward (third-party; call
+// sites models/segformer.py:9-11,33-37).  Dropout keeps the element hash of transformer.hip (index (bh*N + q)*Nk + key), so a replayed
+// mask is the same in both kernel families.
+#include "conv_split.h"
+
+namespace {
+
+using namespace fs_split;
+typedef PrecX3 P;
+typedef P::x8 X8;
+typedef P::x4 X4;
+
+constexpr int HD = 64, KC = 64;
+constexpr int KPITCH = 144, VPITCH = 136;                  // bytes per LDS row
+constexpr int KPL = KC * KPITCH, VPL = HD * VPITCH;        // bytes per LDS plane
+constexpr int LDS_K = 0, LDS_V = 3 * KPL;
+constexpr int LDS_BYTES = 3 * KPL + 3 * VPL;               // 53 760: two workgroups per CU
+constexpr int BLOCK_BYTES = 6 * KC * HD * 2;               // one packed (bh, chunk) block in HBM: 49 152
+
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+__device__ __forceinline__ X8 cat(X4 lo, X4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ void split8(f32x4 a, f32x4 b, X8 (&out)[3]) {
+  X4 pa[3], pb[3];
+  P::split4(a, pa);
+  P::split4(b, pb);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) out[pl] = cat(pa[pl], pb[pl]);
+}
+
+// ---- pre-pass: K -> row-major planes, V -> transposed planes, per (bh, chunk) block ----
+__global__ __launch_bounds__(256) void attn_pack_kv_kernel(const float* __restrict__ k, const float* __restrict__ v, unsigned char* __restrict__ ws,
+                                                           int Nk, int heads, int nchunk) {
+  const int c = blockIdx.x, bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int C = heads * HD;
+  const float* kb = k + (long)b * Nk * C + hd * HD;
+  const float* vb = v + (long)b * Nk * C + hd * HD;
+  unsigned char* blk = ws + ((long)bh * nchunk + c) * BLOCK_BYTES;
+  // item = (key row, channel quad): 64 x 16 items, 4 per thread
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int item = threadIdx.x + 256 * it;
+    const int key = item >> 4, c4 = (item & 15) * 4;
+    const int gk = c * KC + key;
+    f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+    if (gk < Nk) {
+      kv = *reinterpret_cast<const f32x4*>(kb + (long)gk * C + c4);
+      vv = *reinterpret_cast<const f32x4*>(vb + (long)gk * C + c4);
+    }
+    X4 pk[3], pv[3];
+    P::split4(kv, pk);
+    P::split4(vv, pv);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      *reinterpret_cast<X4*>(blk + (pl * KC + key) * (HD * 2) + c4 * 2) = pk[pl];
+      __bf16* vt = reinterpret_cast<__bf16*>(blk + 3 * KC * HD * 2 + pl * HD * KC * 2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vt[(c4 + e) * KC + key] = pv[pl][e];
+    }
+  }
+}
+
+// one 48 KB block -> the LDS image (K rows at KPITCH, V^T rows at VPITCH)
+__device__ __forceinline__ void stage_block(const unsigned char* __restrict__ blk, unsigned char* lds, int tid) {
+#pragma unroll
+  for (int it = 0; it < 12; ++it) {
+    const int piece = tid + 256 * it;                 // 3072 pieces of 16 bytes; pieces 0..1535 are K, the rest V^T (uniform per `it`)
+    const u32x4 d = *reinterpret_cast<const u32x4*>(blk + piece * 16);
+    const int rem = it < 6 ? piece : piece - 1536, pl = rem >> 9, row = (rem >> 3) & 63, seg = rem & 7;
+    if (it < 6) {
+      *reinterpret_cast<u32x4*>(lds + LDS_K + pl * KPL + row * KPITCH + seg * 16) = d;
+    } else {
+      typedef unsigned u2 __attribute__((ext_vector_type(2)));
+      unsigned char* dst = lds + LDS_V + pl * VPL + row * VPITCH + seg * 16;
+      *reinterpret_cast<u2*>(dst) = u2{d.x, d.y};
+      *reinterpret_cast<u2*>(dst + 8) = u2{d.z, d.w};
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_split_fwd_kernel(const float* __restrict__ q, const unsigned char* __restrict__ ws,
+                                                             float* __restrict__ o, float* __restrict__ lse, int N, int Nk, int heads,
+                                                             float scale, float drop_scale, uint32_t thresh, uint32_t key) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int C = heads * HD;
+  const int qrow = blockIdx.x * 128 + wave * 32 + r;           // this lane's query
+  const bool qok = qrow < N;
+  const int nchunk = (Nk + KC - 1) / KC;
+  const unsigned char* blk0 = ws + (long)bh * nchunk * BLOCK_BYTES;
+
+  // B operand of S^T: (q * scale)[qrow][16 ks + 8 h .. + 7] as planes
+  X8 qf[4][3];
+  {
+    const float* qp = q + ((long)b * N + (qok ? qrow : 0)) * C + hd * HD + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, c2 = {0.f, 0.f, 0.f, 0.f};
+      if (qok) { a = *reinterpret_cast<const f32x4*>(qp + 16 * ks) * scale; c2 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4) * scale; }
+      split8(a, c2, qf[ks]);
+    }
+  }
+  f32x16 O[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { O[0][i] = 0.f; O[1][i] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+  const uint32_t ebase = (uint32_t)(((long)bh * N + qrow) * Nk);
+
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();                           // every wave is done with the previous chunk's image
+    stage_block(blk0 + (long)c * BLOCK_BYTES, lds, tid);
+    __syncthreads();
+    f32x16 S[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) S[t][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        X8 kf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          kf[pl] = *reinterpret_cast<const X8*>(lds + LDS_K + pl * KPL + (32 * t + r) * KPITCH + (16 * ks + 8 * h) * 2);
+#pragma unroll
+        for (int tm = 0; tm < P::NTERM; ++tm) S[t] = P::mfma(kf[P::ta(tm)], qf[ks][P::tb(tm)], S[t]);
+      }
+    }
+    // online softmax, per lane (= per query); keys beyond Nk are excluded
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool ok = c * KC + 32 * t + acc_row(i, h) < Nk;
+        S[t][i] = ok ? S[t][i] : -INFINITY;
+        mloc = fmaxf(mloc, S[t][i]);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mn = fmaxf(m, mloc);
+    const float alpha = expf(m - mn);
+    m = mn;
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float p = expf(S[t][i] - mn);            // exp(-inf) = 0 for the excluded keys
+        psum += p;
+        if (thresh != 0u) p = fs_dropout_keep(ebase + (uint32_t)(c * KC + 32 * t + acc_row(i, h)), key, thresh) ? p * drop_scale : 0.f;
+        S[t][i] = p;
+      }
+    l = l * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { O[0][i] *= alpha; O[1][i] *= alpha; }
+    // O^T += V^T P~^T, k-steps in register order
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        X8 pf[3];
+        split8(f32x4{S[t][8 * s2], S[t][8 * s2 + 1], S[t][8 * s2 + 2], S[t][8 * s2 + 3]},
+               f32x4{S[t][8 * s2 + 4], S[t][8 * s2 + 5], S[t][8 * s2 + 6], S[t][8 * s2 + 7]}, pf);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          X8 vf[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            const unsigned char* a0 = lds + LDS_V + pl * VPL + (32 * dt + r) * VPITCH + (32 * t + 16 * s2 + 4 * h) * 2;
+            vf[pl] = cat(*reinterpret_cast<const X4*>(a0), *reinterpret_cast<const X4*>(a0 + 16));
+          }
+#pragma unroll
+          for (int tm = 0; tm < P::NTERM; ++tm) O[dt] = P::mfma(vf[P::ta(tm)], pf[P::tb(tm)], O[dt]);
+        }
+      }
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (!qok) return;
+  const float inv = 1.f / l;
+  float* orow = o + ((long)b * N + qrow) * C + hd * HD;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * h) =
+          f32x4{O[dt][4 * g], O[dt][4 * g + 1], O[dt][4 * g + 2], O[dt][4 * g + 3]} * inv;
+  if (h == 0) lse[(long)bh * N + qrow] = m + logf(l);
+}
+
+}  // namespace
+
+extern "C" {
+
+// include/fovealseg.h: scratch of the split-precision attention entry points (the packed K / V^T planes)
+long fs_attention_split_ws_bytes(int B, int Nk, int heads) {
+  if (B <= 0 || Nk <= 0 || heads <= 0) return 0;
+  return (long)B * heads * ((Nk + KC - 1) / KC) * BLOCK_BYTES;
+}
+
+int fs_attention_fwd_split(const float* q, const float* k, const float* v, float* o, float* lse, void* ws, long ws_bytes, int B, int N, int Nk,
+                           int heads, float scale, float drop_p, uint32_t key, hipStream_t stream) {
+  FS_REQUIRE(q && k && v && o && lse && ws && B > 0 && N > 0 && Nk > 0 && heads > 0 && drop_p >= 0.f && drop_p < 1.f);
+  FS_REQUIRE((long)B * heads * N * Nk < 4294967296L && (long)B * heads < 65536 && ws_bytes >= fs_attention_split_ws_bytes(B, Nk, heads));
+  float ds = 1.f; uint32_t thresh = 0u;
+  if (drop_p > 0.f) { ds = 1.0f / (float)(1.0 - (double)drop_p); thresh = (uint32_t)((double)drop_p * 4294967296.0); }
+  const int nchunk = (Nk + KC - 1) / KC;
+  hipLaunchKernelGGL(attn_pack_kv_kernel, dim3(nchunk, B * heads), dim3(256), 0, stream, k, v, reinterpret_cast<unsigned char*>(ws), Nk, heads, nchunk);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_split_fwd_kernel, dim3((N + 127) / 128, B * heads), dim3(256), 0, stream, q, reinterpret_cast<const unsigned char*>(ws), o,
+                     lse, N, Nk, heads, scale, ds, thresh, key);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+}  // extern "C"

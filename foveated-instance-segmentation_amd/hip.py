@@ -77,6 +77,7 @@ SIGNATURES = {
     "fs_dwconv3_bwd_weight": "ppppiiiii",
     "fs_residual_droppath": "pppllfu",
     "fs_attention_fwd": "pppppiiiiffu",
+    "fs_attention_fwd_split": "pppppp" + "l" + "iiii" + "ffu",
     "fs_attention_bwd": "ppppppppppiiiiffu",
 }
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
@@ -85,7 +86,7 @@ _lib = None
 # declared in the header, host-side only (no stream argument)
 HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice",
              "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes", "fs_conv2d_bwd_data_bnsum_slabs",
-             "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok")
+             "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes")
 
 
 class HipLibraryError(RuntimeError):
@@ -126,6 +127,8 @@ def load():
     lib.fs_conv2d_fwd_affine_act_ok.argtypes = [_I] * 12 + [_L]
     lib.fs_linear_bwd_weight_bias_ok.restype = _I
     lib.fs_linear_bwd_weight_bias_ok.argtypes = [_L, _I, _I]
+    lib.fs_attention_split_ws_bytes.restype = _L
+    lib.fs_attention_split_ws_bytes.argtypes = [_I] * 3
     _lib = lib
     global _default_mode
     _default_mode = ("f32", "bf16x3", "f16x2")[lib.fs_get_conv_precision()]
@@ -170,6 +173,11 @@ def conv_stats_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_byte
     if v is None:
         v = _ws_cache[key] = int(load().fs_conv2d_stats_slabs(*key[1:]))
     return v
+
+
+def attention_split_ws_bytes(B, Nk, heads):
+    """Scratch bytes of the split-precision attention entry points (packed K / V^T planes)."""
+    return int(load().fs_attention_split_ws_bytes(B, Nk, heads))
 
 
 def linear_bwd_weight_bias_ok(rows, Cin, Cout):

@@ -1102,6 +1102,9 @@ class ResidualDropPath(Function):
         return g, dy, None, None
 
 
+ATTN_SPLIT = os.environ.get("FS_ATTN_SPLIT", "1") != "0"      # kernel A/B: 0 keeps the exact-fp32 MFMA attention kernels in every mode
+
+
 class Attention(Function):
     """softmax(q k^T / sqrt(64)) (dropout p) v per head on the matrix cores; q (B,N,C), k/v (B,Nk,C), C = heads*64, any Nk."""
 
@@ -1112,8 +1115,15 @@ class Attention(Function):
         assert C == heads * 64, "head_dim must be 64"
         o = torch.empty_like(q)
         lse = torch.empty(B * heads * N, device=q.device, dtype=torch.float32)
-        _launch("attn_fwd", 4.0 * B * heads * N * Nk * 64, "fs_attention_fwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o), hip.ptr(lse),
-                B, N, Nk, heads, 0.125, float(p), int(key))
+        if ATTN_SPLIT and hip.get_conv_precision() == "bf16x3":
+            # the headline arithmetic (24-bit operands as three bf16 planes, fp32 accumulation) on the attention products as well
+            nb = hip.attention_split_ws_bytes(B, Nk, heads)
+            ws = torch.empty(nb, device=q.device, dtype=torch.uint8)
+            _launch("attn_fwd", 4.0 * B * heads * N * Nk * 64, "fs_attention_fwd_split", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o),
+                    hip.ptr(lse), hip.ptr(ws), nb, B, N, Nk, heads, 0.125, float(p), int(key))
+        else:
+            _launch("attn_fwd", 4.0 * B * heads * N * Nk * 64, "fs_attention_fwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o), hip.ptr(lse),
+                    B, N, Nk, heads, 0.125, float(p), int(key))
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.cfg = (heads, float(p), int(key))
         return o

@@ -277,6 +277,13 @@ int fs_residual_droppath(const float* x, const float* y, float* out, long n, lon
  * Replaces SegformerEfficientSelfAttention's matmul-softmax-dropout-matmul (transformers 4.46.2, models/segformer.py:2,88-100). */
 int fs_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int N, int Nk, int heads,
                      float scale, float drop_p, uint32_t key, fs_stream_t stream);
+/* The same forward in split precision (bf16x3: q*scale, k, v and the probabilities as three bf16 planes = 24-bit operands, six
+ * v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation and softmax) -- the arithmetic of the conv engine's headline mode, 3/8 of the
+ * matrix-pipe time of the exact kernel.  ws = fs_attention_split_ws_bytes(B, Nk, heads) bytes of scratch (K / V^T planes, written by a
+ * pre-pass inside the call).  Same dropout hash and element index as fs_attention_fwd.  csrc/attention_split.hip. */
+long fs_attention_split_ws_bytes(int B, int Nk, int heads);
+int fs_attention_fwd_split(const float* q, const float* k, const float* v, float* o, float* lse, void* ws, long ws_bytes, int B, int N,
+                           int Nk, int heads, float scale, float drop_p, uint32_t key, fs_stream_t stream);
 /* Backward of the above: dq, dk, dv overwritten.  o = the forward's output, go = its gradient, scratch = B*heads*N floats. */
 int fs_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse, float* dq,
                      float* dk, float* dv, float* scratch, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key,

@@ -1425,7 +1425,16 @@ def test_layernorm_gelu_dwconv_droppath():
 # Nk = 100 / 400: the sequence-reduced key counts at 80x80 / 160x160 inputs (BASELINE configs[3]); ragged N and Nk; N < one wave tile
 @pytest.mark.parametrize("heads,N,Nk,p", [(1, 200, 100, 0.0), (5, 77, 100, 0.2), (2, 130, 25, 0.2), (2, 1600, 400, 0.2), (1, 300, 7, 0.0),
                                          (8, 25, 25, 0.0), (1, 6400, 100, 0.2)])
-def test_attention_vs_torch(heads, N, Nk, p):
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])       # f32: the exact-fp32 MFMA kernels; bf16x3: csrc/attention_split.hip (forward)
+def test_attention_vs_torch(heads, N, Nk, p, mode):
+    fovealseg.hip.set_conv_precision(mode)
+    try:
+        _attention_vs_torch(heads, N, Nk, p)
+    finally:
+        fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
+
+
+def _attention_vs_torch(heads, N, Nk, p):
     g = torch.Generator().manual_seed(43)
     B, C = 2, heads * 64
     q, k, v = (torch.randn(B, n, C, generator=g) for n in (N, Nk, Nk))
