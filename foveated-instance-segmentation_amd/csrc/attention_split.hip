@@ -209,6 +209,159 @@ __global__ __launch_bounds__(256, 2) void attn_split_fwd_kernel(const float* __r
   if (h == 0) lse[(long)bh * N + qrow] = m + logf(l);
 }
 
+// ---- backward, dQ: the same transposed tiles with the query on the lane -----------------------------------------------------------
+//     S^T = K (q*scale)^T,  dP~^T = V dO^T   (A = K / V rows of a 32-key chunk, B = the lane's q / dO row as planes, held in registers)
+//     dS^T = P^T o (mask * dP~^T * drop_scale - D)     per lane: lse and D of the lane's query are scalars
+//     dQ^T[d][q] += K^T dS^T                 (A = K^T rows, keys in register order; B = dS^T planes straight from the registers)
+// No atomics (a workgroup owns its 128 queries), no LDS round trip for dS.  Packed per (bh, 32-key chunk): [K][V] row-major planes and
+// K^T planes, 36 KB; LDS pitches 144 B (rows of 64 d) / 72 B (rows of 32 keys).
+constexpr int KC2 = 32;
+constexpr int BW_ROWS = 3 * KC2 * HD * 2;                  // bytes of one tensor's three planes in a packed block: 12 288
+constexpr int BW_BLOCK = 3 * BW_ROWS;                      // K rm, V rm, K^T: 36 864
+constexpr int KPL2 = KC2 * KPITCH;                         // 4 608
+constexpr int TPITCH = 72, TPL = HD * TPITCH;              // K^T rows: 32 keys + 8 B; 4 608
+constexpr int L2_K = 0, L2_V = 3 * KPL2, L2_T = 6 * KPL2;
+constexpr int LDS2_BYTES = 6 * KPL2 + 3 * TPL;             // 41 472
+
+__global__ __launch_bounds__(256) void attn_pack_bwd_kernel(const float* __restrict__ k, const float* __restrict__ v, unsigned char* __restrict__ ws,
+                                                            int Nk, int heads, int nchunk) {
+  const int c = blockIdx.x, bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int C = heads * HD;
+  const float* kb = k + (long)b * Nk * C + hd * HD;
+  const float* vb = v + (long)b * Nk * C + hd * HD;
+  unsigned char* blk = ws + ((long)bh * nchunk + c) * BW_BLOCK;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = threadIdx.x + 256 * it;       // (key row, channel quad): 32 x 16
+    const int key = item >> 4, c4 = (item & 15) * 4;
+    const int gk = c * KC2 + key;
+    f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+    if (gk < Nk) {
+      kv = *reinterpret_cast<const f32x4*>(kb + (long)gk * C + c4);
+      vv = *reinterpret_cast<const f32x4*>(vb + (long)gk * C + c4);
+    }
+    X4 pk[3], pv[3];
+    P::split4(kv, pk);
+    P::split4(vv, pv);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      *reinterpret_cast<X4*>(blk + (pl * KC2 + key) * (HD * 2) + c4 * 2) = pk[pl];
+      *reinterpret_cast<X4*>(blk + BW_ROWS + (pl * KC2 + key) * (HD * 2) + c4 * 2) = pv[pl];
+      __bf16* kt = reinterpret_cast<__bf16*>(blk + 2 * BW_ROWS + pl * HD * KC2 * 2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) kt[(c4 + e) * KC2 + key] = pk[pl][e];
+    }
+  }
+}
+
+__device__ __forceinline__ void stage_block_bwd(const unsigned char* __restrict__ blk, unsigned char* lds, int tid) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int it = 0; it < 9; ++it) {
+    const int piece = tid + 256 * it;               // 2304 pieces of 16 bytes: 768 K, 768 V, 768 K^T (uniform per `it`)
+    const u32x4 d = *reinterpret_cast<const u32x4*>(blk + piece * 16);
+    if (it < 6) {
+      const int rem = it < 3 ? piece : piece - 768, pl = rem >> 8, row = (rem >> 3) & 31, seg = rem & 7;
+      *reinterpret_cast<u32x4*>(lds + (it < 3 ? L2_K : L2_V) + pl * KPL2 + row * KPITCH + seg * 16) = d;
+    } else {
+      const int rem = piece - 1536, pl = rem >> 8, row = (rem >> 2) & 63, seg = rem & 3;
+      unsigned char* dst = lds + L2_T + pl * TPL + row * TPITCH + seg * 16;
+      *reinterpret_cast<u2*>(dst) = u2{d.x, d.y};
+      *reinterpret_cast<u2*>(dst + 8) = u2{d.z, d.w};
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_split_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ go,
+                                                                const unsigned char* __restrict__ ws, const float* __restrict__ lse,
+                                                                const float* __restrict__ D, float* __restrict__ dq, int N, int Nk, int heads,
+                                                                float scale, float drop_scale, uint32_t thresh, uint32_t key) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS2_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int C = heads * HD;
+  const int qrow = blockIdx.x * 128 + wave * 32 + r;
+  const bool qok = qrow < N;
+  const int nchunk = (Nk + KC2 - 1) / KC2;
+  const unsigned char* blk0 = ws + (long)bh * nchunk * BW_BLOCK;
+
+  X8 qf[4][3], gf[4][3];          // B operands: (q*scale) and dO rows of this lane's query
+  {
+    const long off = ((long)b * N + (qok ? qrow : 0)) * C + hd * HD + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, a2 = a, g = a, g2 = a;
+      if (qok) {
+        a = *reinterpret_cast<const f32x4*>(q + off + 16 * ks) * scale; a2 = *reinterpret_cast<const f32x4*>(q + off + 16 * ks + 4) * scale;
+        g = *reinterpret_cast<const f32x4*>(go + off + 16 * ks); g2 = *reinterpret_cast<const f32x4*>(go + off + 16 * ks + 4);
+      }
+      split8(a, a2, qf[ks]);
+      split8(g, g2, gf[ks]);
+    }
+  }
+  const float L = qok ? lse[(long)bh * N + qrow] : INFINITY;       // p = exp(s - inf) = 0 for lanes past the end
+  const float Dq = qok ? D[(long)bh * N + qrow] : 0.f;
+  const uint32_t ebase = (uint32_t)(((long)bh * N + qrow) * Nk);
+  f32x16 dQ[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dQ[0][i] = 0.f; dQ[1][i] = 0.f; }
+
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();
+    stage_block_bwd(blk0 + (long)c * BW_BLOCK, lds, tid);
+    __syncthreads();
+    f32x16 S, dP;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      X8 kf[3], vf[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        kf[pl] = *reinterpret_cast<const X8*>(lds + L2_K + pl * KPL2 + r * KPITCH + (16 * ks + 8 * h) * 2);
+        vf[pl] = *reinterpret_cast<const X8*>(lds + L2_V + pl * KPL2 + r * KPITCH + (16 * ks + 8 * h) * 2);
+      }
+#pragma unroll
+      for (int tm = 0; tm < P::NTERM; ++tm) {
+        S = P::mfma(kf[P::ta(tm)], qf[ks][P::tb(tm)], S);
+        dP = P::mfma(vf[P::ta(tm)], gf[ks][P::tb(tm)], dP);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int keyi = c * KC2 + acc_row(i, h);
+      const float p = keyi < Nk ? expf(S[i] - L) : 0.f;
+      float mk = 1.f;
+      if (thresh != 0u) mk = fs_dropout_keep(ebase + (uint32_t)keyi, key, thresh) ? drop_scale : 0.f;
+      S[i] = p * (mk * dP[i] - Dq);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      X8 df[3];
+      split8(f32x4{S[8 * s2], S[8 * s2 + 1], S[8 * s2 + 2], S[8 * s2 + 3]}, f32x4{S[8 * s2 + 4], S[8 * s2 + 5], S[8 * s2 + 6], S[8 * s2 + 7]}, df);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        X8 tf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const unsigned char* a0 = lds + L2_T + pl * TPL + (32 * dt + r) * TPITCH + (16 * s2 + 4 * h) * 2;
+          tf[pl] = cat(*reinterpret_cast<const X4*>(a0), *reinterpret_cast<const X4*>(a0 + 16));
+        }
+#pragma unroll
+        for (int tm = 0; tm < P::NTERM; ++tm) dQ[dt] = P::mfma(tf[P::ta(tm)], df[P::tb(tm)], dQ[dt]);
+      }
+    }
+  }
+  if (!qok) return;
+  float* drow = dq + ((long)b * N + qrow) * C + hd * HD;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4*>(drow + 32 * dt + 8 * g + 4 * h) =
+          f32x4{dQ[dt][4 * g], dQ[dt][4 * g + 1], dQ[dt][4 * g + 2], dQ[dt][4 * g + 3]} * scale;
+}
+
 }  // namespace
 
 extern "C" {
@@ -230,6 +383,29 @@ int fs_attention_fwd_split(const float* q, const float* k, const float* v, float
   FS_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_split_fwd_kernel, dim3((N + 127) / 128, B * heads), dim3(256), 0, stream, q, reinterpret_cast<const unsigned char*>(ws), o,
                      lse, N, Nk, heads, scale, ds, thresh, key);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// include/fovealseg.h: scratch of fs_attention_bwd_dq_split (K, V, K^T planes per 32-key chunk)
+long fs_attention_bwd_split_ws_bytes(int B, int Nk, int heads) {
+  if (B <= 0 || Nk <= 0 || heads <= 0) return 0;
+  return (long)B * heads * ((Nk + KC2 - 1) / KC2) * BW_BLOCK;
+}
+
+// dQ of the attention backward in split precision; D = B*heads*N floats holding rowsum(dO * O) (fs_attention_bwd computes them into its scratch)
+int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D, float* dq,
+                              void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key,
+                              hipStream_t stream) {
+  FS_REQUIRE(q && k && v && go && lse && D && dq && ws && B > 0 && N > 0 && Nk > 0 && heads > 0 && drop_p >= 0.f && drop_p < 1.f);
+  FS_REQUIRE((long)B * heads * N * Nk < 4294967296L && (long)B * heads < 65536 && ws_bytes >= fs_attention_bwd_split_ws_bytes(B, Nk, heads));
+  float ds = 1.f; uint32_t thresh = 0u;
+  if (drop_p > 0.f) { ds = 1.0f / (float)(1.0 - (double)drop_p); thresh = (uint32_t)((double)drop_p * 4294967296.0); }
+  const int nchunk = (Nk + KC2 - 1) / KC2;
+  hipLaunchKernelGGL(attn_pack_bwd_kernel, dim3(nchunk, B * heads), dim3(256), 0, stream, k, v, reinterpret_cast<unsigned char*>(ws), Nk, heads, nchunk);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_split_bwd_dq_kernel, dim3((N + 127) / 128, B * heads), dim3(256), 0, stream, q, go,
+                     reinterpret_cast<const unsigned char*>(ws), lse, D, dq, N, Nk, heads, scale, ds, thresh, key);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

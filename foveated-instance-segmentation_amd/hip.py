@@ -79,6 +79,8 @@ SIGNATURES = {
     "fs_attention_fwd": "pppppiiiiffu",
     "fs_attention_fwd_split": "pppppp" + "l" + "iiii" + "ffu",
     "fs_attention_bwd": "ppppppppppiiiiffu",
+    "fs_attention_bwd_split": "pppppppppp" + "pl" + "iiii" + "ffu",
+    "fs_attention_bwd_dq_split": "ppppppp" + "pl" + "iiii" + "ffu",
 }
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 
@@ -86,7 +88,7 @@ _lib = None
 # declared in the header, host-side only (no stream argument)
 HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice",
              "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes", "fs_conv2d_bwd_data_bnsum_slabs",
-             "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes")
+             "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes", "fs_attention_bwd_split_ws_bytes")
 
 
 class HipLibraryError(RuntimeError):
@@ -129,6 +131,8 @@ def load():
     lib.fs_linear_bwd_weight_bias_ok.argtypes = [_L, _I, _I]
     lib.fs_attention_split_ws_bytes.restype = _L
     lib.fs_attention_split_ws_bytes.argtypes = [_I] * 3
+    lib.fs_attention_bwd_split_ws_bytes.restype = _L
+    lib.fs_attention_bwd_split_ws_bytes.argtypes = [_I] * 3
     _lib = lib
     global _default_mode
     _default_mode = ("f32", "bf16x3", "f16x2")[lib.fs_get_conv_precision()]
@@ -175,9 +179,10 @@ def conv_stats_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_byte
     return v
 
 
-def attention_split_ws_bytes(B, Nk, heads):
-    """Scratch bytes of the split-precision attention entry points (packed K / V^T planes)."""
-    return int(load().fs_attention_split_ws_bytes(B, Nk, heads))
+def attention_split_ws_bytes(B, Nk, heads, backward=False):
+    """Scratch bytes of the split-precision attention entry points (packed K / V planes)."""
+    lib = load()
+    return int(lib.fs_attention_bwd_split_ws_bytes(B, Nk, heads) if backward else lib.fs_attention_split_ws_bytes(B, Nk, heads))
 
 
 def linear_bwd_weight_bias_ok(rows, Cin, Cout):

@@ -1136,6 +1136,13 @@ class Attention(Function):
         Nk = k.shape[1]
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         scratch = torch.empty(B * heads * N, device=q.device, dtype=torch.float32)
-        _launch("attn_bwd", 14.0 * B * heads * N * Nk * 64, "fs_attention_bwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o),
-                hip.ptr(go.contiguous()), hip.ptr(lse), hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), hip.ptr(scratch), B, N, Nk, heads, 0.125, p, key)
+        if ATTN_SPLIT and hip.get_conv_precision() == "bf16x3":
+            nb = hip.attention_split_ws_bytes(B, Nk, heads, backward=True)
+            ws = torch.empty(nb, device=q.device, dtype=torch.uint8)
+            _launch("attn_bwd", 14.0 * B * heads * N * Nk * 64, "fs_attention_bwd_split", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o),
+                    hip.ptr(go.contiguous()), hip.ptr(lse), hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), hip.ptr(scratch), hip.ptr(ws), nb,
+                    B, N, Nk, heads, 0.125, p, key)
+        else:
+            _launch("attn_bwd", 14.0 * B * heads * N * Nk * 64, "fs_attention_bwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o),
+                    hip.ptr(go.contiguous()), hip.ptr(lse), hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), hip.ptr(scratch), B, N, Nk, heads, 0.125, p, key)
         return dq, dk, dv, None, None, None
