@@ -362,6 +362,153 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_dq_kernel(const float* 
           f32x4{dQ[dt][4 * g], dQ[dt][4 * g + 1], dQ[dt][4 * g + 2], dQ[dt][4 * g + 3]} * scale;
 }
 
+// ---- backward, dK and dV: the key on the lane -------------------------------------------------------------------------------------
+//     S[q][key] = (q*scale) K^T,  dP~[q][key] = dO V^T      A = rows of the Q / dO slice image, B = the lane's K / V row as planes (registers)
+//     P~ = dropout(exp(S - lse[q])),  dS = P o (mask * dP~ * drop_scale - D[q])     (q is the REGISTER index: lse and D come from LDS)
+//     dV^T[d][key] += dO^T P~,   dK^T[d][key] += (q*scale)^T dS      A = the slice image read TRANSPOSED (ds_read_b64_tr_b16, q in register
+//                                                                     order), B = P~ / dS planes straight from the registers
+// A wave owns one 32-key tile for the whole sweep over its query range (accumulators in registers, no sum across waves); a workgroup = four
+// tiles sharing the 32-query slice images [Q*scale][dO]: 3 planes x 32 rows x 144 B each, written once (split in the kernel) and read by
+// rows for S / dP and transposed for the two output products.  Holding K and V planes (96 registers) plus both accumulators (64) plus
+// the S and dP tiles does not fit 256 registers without spills, so the two outputs are two instantiations: DK = false computes S -> dV,
+// DK = true computes S, dP -> dK (5 tile products per (slice, tile) where a fused kernel would need 4).
+constexpr int QS = 32;                                     // queries per slice
+constexpr int SPL = QS * KPITCH;                           // one plane of a slice image: 4 608
+constexpr int L3_Q = 0, L3_G = 3 * SPL, L3_L = 6 * SPL;    // images, then lse[32], D[32]
+constexpr int LDS3_BYTES = 6 * SPL + 2 * QS * 4;           // 27 904
+
+template <bool DK>
+__global__ __launch_bounds__(256, 2) void attn_split_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, const float* __restrict__ go,
+                                                                const float* __restrict__ lse, const float* __restrict__ D,
+                                                                float* __restrict__ dout, int N, int Nk, int heads, float scale,
+                                                                float drop_scale, uint32_t thresh, uint32_t key, int slices_per_split,
+                                                                int atomics) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS3_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int C = heads * HD;
+  const int krow = (blockIdx.x * 4 + wave) * 32 + r;          // this lane's key
+  const bool kok = krow < Nk;
+  const float* qb = q + (long)b * N * C + hd * HD;
+  const float* gb = go + (long)b * N * C + hd * HD;
+
+  // B operands: the lane's K row (and V row for dK) as planes, [16 ks + 8 h .. + 7]
+  X8 kf[4][3], vf[DK ? 4 : 1][3];
+  {
+    const long off = ((long)b * Nk + (kok ? krow : 0)) * C + hd * HD + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, a2 = a, g = a, g2 = a;
+      if (kok) {
+        a = *reinterpret_cast<const f32x4*>(k + off + 16 * ks); a2 = *reinterpret_cast<const f32x4*>(k + off + 16 * ks + 4);
+        if (DK) { g = *reinterpret_cast<const f32x4*>(v + off + 16 * ks); g2 = *reinterpret_cast<const f32x4*>(v + off + 16 * ks + 4); }
+      }
+      split8(a, a2, kf[ks]);
+      if (DK) split8(g, g2, vf[ks]);
+    }
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+
+  // staging: item = (row tid >> 4 (+16), channel quad tid & 15) of the slice, Q*scale and dO
+  const int srow = tid >> 4, c4 = (tid & 15) * 4;
+  // transposed-read lane constants (conv_wgrad.hip): lane 4 q' + p of a 16-lane group addresses row q', columns 4 p .. 4 p + 3 of the
+  // group's 16 columns cb .. cb + 15; the lane then holds column cb + (lane & 15) of the four rows
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, cb = 16 * ((lane >> 4) & 1);
+  const int tr_ofs = tq * KPITCH + (cb + 4 * tp) * 2;          // + row base * KPITCH + 64 dt + plane
+  const int nslice = (N + QS - 1) / QS;
+  const int s_begin = blockIdx.z * slices_per_split;
+  const int s_end = s_begin + slices_per_split < nslice ? s_begin + slices_per_split : nslice;
+  const float* lsel = reinterpret_cast<const float*>(lds + L3_L);
+
+  for (int sl = s_begin; sl < s_end; ++sl) {
+    const int q0 = sl * QS;
+    __syncthreads();                       // every wave is done with the previous slice
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = srow + 16 * it, qr = q0 + row;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, g = a;
+      if (qr < N) {
+        a = *reinterpret_cast<const f32x4*>(qb + (long)qr * C + c4) * scale;
+        g = *reinterpret_cast<const f32x4*>(gb + (long)qr * C + c4);
+      }
+      X4 pa[3], pg[3];
+      P::split4(a, pa);
+      P::split4(g, pg);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        *reinterpret_cast<X4*>(lds + L3_Q + pl * SPL + row * KPITCH + c4 * 2) = pa[pl];
+        *reinterpret_cast<X4*>(lds + L3_G + pl * SPL + row * KPITCH + c4 * 2) = pg[pl];
+      }
+    }
+    if (tid < 2 * QS) {                    // lse (+inf past the end: p = 0) and D of the slice's queries
+      const int qr = q0 + (tid & 31);
+      const bool ok = qr < N;
+      reinterpret_cast<float*>(lds + L3_L)[tid] = tid < QS ? (ok ? lse[(long)bh * N + qr] : INFINITY) : (ok ? D[(long)bh * N + qr] : 0.f);
+    }
+    __syncthreads();
+
+    f32x16 S, dP;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      X8 qa[3], ga[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        qa[pl] = *reinterpret_cast<const X8*>(lds + L3_Q + pl * SPL + r * KPITCH + (16 * ks + 8 * h) * 2);
+        if (DK) ga[pl] = *reinterpret_cast<const X8*>(lds + L3_G + pl * SPL + r * KPITCH + (16 * ks + 8 * h) * 2);
+      }
+#pragma unroll
+      for (int tm = 0; tm < P::NTERM; ++tm) {
+        S = P::mfma(qa[P::ta(tm)], kf[ks][P::tb(tm)], S);
+        if (DK) dP = P::mfma(ga[P::ta(tm)], vf[ks][P::tb(tm)], dP);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ql = acc_row(i, h);
+      const float p = kok ? expf(S[i] - lsel[ql]) : 0.f;
+      float mk = 1.f;
+      if (thresh != 0u) mk = fs_dropout_keep((uint32_t)(((long)bh * N + q0 + ql) * Nk) + (uint32_t)krow, key, thresh) ? drop_scale : 0.f;
+      S[i] = DK ? p * (mk * dP[i] - lsel[QS + ql]) : p * mk;
+    }
+    // output product: A = the dO (dV) or Q*scale (dK) image read transposed, rows d, k = queries in register order
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      X8 bf[3];
+      split8(f32x4{S[8 * s2], S[8 * s2 + 1], S[8 * s2 + 2], S[8 * s2 + 3]}, f32x4{S[8 * s2 + 4], S[8 * s2 + 5], S[8 * s2 + 6], S[8 * s2 + 7]}, bf);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        X8 af[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const unsigned char* a0 = lds + (DK ? L3_Q : L3_G) + pl * SPL + (16 * s2 + 4 * h) * KPITCH + 64 * dt + tr_ofs;
+          af[pl] = cat(P::tr_read(a0), P::tr_read(a0 + 8 * KPITCH));
+        }
+#pragma unroll
+        for (int tm = 0; tm < P::NTERM; ++tm) acc[dt] = P::mfma(af[P::ta(tm)], bf[P::tb(tm)], acc[dt]);
+      }
+    }
+  }
+  if (!kok || s_begin >= s_end) return;
+  float* drow = dout + ((long)b * Nk + krow) * C + hd * HD;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float* d4 = drow + 32 * dt + 8 * g + 4 * h;
+      if (atomics) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(d4 + e, acc[dt][4 * g + e]);
+      } else {
+        *reinterpret_cast<f32x4*>(d4) = f32x4{acc[dt][4 * g], acc[dt][4 * g + 1], acc[dt][4 * g + 2], acc[dt][4 * g + 3]};
+      }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -406,6 +553,38 @@ int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, co
   FS_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_split_bwd_dq_kernel, dim3((N + 127) / 128, B * heads), dim3(256), 0, stream, q, go,
                      reinterpret_cast<const unsigned char*>(ws), lse, D, dq, N, Nk, heads, scale, ds, thresh, key);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// dK and dV of the attention backward in split precision (no scratch: K / V rows are split into registers, the query slices in the kernel).
+// D = rowsum(dO * O).  dk / dv are overwritten.
+int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D, float* dk,
+                               float* dv, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key, hipStream_t stream) {
+  FS_REQUIRE(q && k && v && go && lse && D && dk && dv && B > 0 && N > 0 && Nk > 0 && heads > 0 && drop_p >= 0.f && drop_p < 1.f);
+  FS_REQUIRE((long)B * heads * N * Nk < 4294967296L && (long)B * heads < 65536);
+  float ds = 1.f; uint32_t thresh = 0u;
+  if (drop_p > 0.f) { ds = 1.0f / (float)(1.0 - (double)drop_p); thresh = (uint32_t)((double)drop_p * 4294967296.0); }
+  // key tiles x (batch, head) workgroups; when that does not fill the chip the query range is split too (atomics into zeroed dk / dv)
+  const int nkb = (Nk + 127) / 128, nslice = (N + QS - 1) / QS;
+  int nsplit = (int)((512 + (long)nkb * B * heads - 1) / ((long)nkb * B * heads));
+  if (nsplit > nslice) nsplit = nslice;
+  if (nsplit > 64) nsplit = 64;
+  const int sps = (nslice + nsplit - 1) / nsplit;
+  nsplit = (nslice + sps - 1) / sps;
+  if (nsplit > 1) {
+    const size_t kvbytes = (size_t)B * Nk * heads * HD * sizeof(float);
+    hipError_t e = hipMemsetAsync(dk, 0, kvbytes, stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(dv, 0, kvbytes, stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  const dim3 grid(nkb, B * heads, nsplit);
+  hipLaunchKernelGGL(attn_split_bwd_kv_kernel<false>, grid, dim3(256), 0, stream, q, k, v, go, lse, D, dv, N, Nk, heads, scale, ds, thresh, key,
+                     sps, nsplit > 1 ? 1 : 0);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_split_bwd_kv_kernel<true>, grid, dim3(256), 0, stream, q, k, v, go, lse, D, dk, N, Nk, heads, scale, ds, thresh, key,
+                     sps, nsplit > 1 ? 1 : 0);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -869,6 +869,8 @@ int fs_attention_fwd(const float* q, const float* k, const float* v, float* o, f
 int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D, float* dq,
                               void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key,
                               hipStream_t stream);       // attention_split.hip
+int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D, float* dk,
+                               float* dv, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key, hipStream_t stream);
 
 static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse, float* dq,
                               float* dk, float* dv, float* scratch, void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale,
@@ -880,9 +882,10 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
   const long rows = (long)B * heads * N;
   hipLaunchKernelGGL(attn_rowdot_kernel, dim3(cdiv(rows * 16, 256)), dim3(256), 0, stream, go, o, scratch, B, N, heads);
   FS_LAUNCH_CHECK();
-  if (ws != nullptr) {          // split precision: dQ by attention_split.hip (dK / dV below stay on the exact kernel)
+  if (ws != nullptr) {          // split precision: all three gradients by attention_split.hip
     const int e = fs_attention_bwd_dq_split(q, k, v, go, lse, scratch, dq, ws, ws_bytes, B, N, Nk, heads, scale, drop_p, key, stream);
     if (e != FS_OK) return e;
+    return fs_attention_bwd_dkv_split(q, k, v, go, lse, scratch, dk, dv, B, N, Nk, heads, scale, drop_p, key, stream);
   } else {
     hipLaunchKernelGGL(attn_mfma_bwd_dq_kernel, dim3(cdiv(N, 128), B * heads), dim3(256), 0, stream, q, k, v, go, lse, scratch, dq, N, Nk,
                        heads, scale, ds, thresh, key);

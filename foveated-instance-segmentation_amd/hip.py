@@ -81,6 +81,7 @@ SIGNATURES = {
     "fs_attention_bwd": "ppppppppppiiiiffu",
     "fs_attention_bwd_split": "pppppppppp" + "pl" + "iiii" + "ffu",
     "fs_attention_bwd_dq_split": "ppppppp" + "pl" + "iiii" + "ffu",
+    "fs_attention_bwd_dkv_split": "pppppppp" + "iiii" + "ffu",
 }
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 

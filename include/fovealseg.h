@@ -288,13 +288,16 @@ int fs_attention_fwd_split(const float* q, const float* k, const float* v, float
 int fs_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse, float* dq,
                      float* dk, float* dv, float* scratch, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key,
                      fs_stream_t stream);
-/* The backward with the split-precision (bf16x3) kernels where they exist (round 3: dQ -- transposed score tile, query on the lane, no
- * LDS round trip for dS; dK / dV still on the exact kernel).  ws = fs_attention_bwd_split_ws_bytes(B, Nk, heads) bytes of scratch.
- * fs_attention_bwd_dq_split is the dQ part alone (D = rowsum(dO * O), B*heads*N floats). */
+/* The backward in split precision (bf16x3): dQ with the query on the MFMA lane (transposed score tile, dS fed to the K^T product from
+ * registers), dK and dV with the key on the lane (P~ / dS fed to the dO^T / Q^T products from registers, the query-slice images read by rows
+ * and transposed), no LDS round trip for P or dS.  ws = fs_attention_bwd_split_ws_bytes(B, Nk, heads) bytes of scratch (the dQ kernel's
+ * K / V / K^T planes).  fs_attention_bwd_dq_split / _dkv_split are the two parts alone (D = rowsum(dO * O), B*heads*N floats). */
 long fs_attention_bwd_split_ws_bytes(int B, int Nk, int heads);
 int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D, float* dq,
                               void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key,
                               fs_stream_t stream);
+int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D, float* dk,
+                               float* dv, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key, fs_stream_t stream);
 int fs_attention_bwd_split(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse, float* dq,
                            float* dk, float* dv, float* scratch, void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale,
                            float drop_p, uint32_t key, fs_stream_t stream);
