@@ -101,8 +101,9 @@ __device__ __forceinline__ void stage_block(const unsigned char* __restrict__ bl
 }
 
 __global__ __launch_bounds__(256, 2) void attn_split_fwd_kernel(const float* __restrict__ q, const unsigned char* __restrict__ ws,
-                                                             float* __restrict__ o, float* __restrict__ lse, int N, int Nk, int heads,
-                                                             float scale, float drop_scale, uint32_t thresh, uint32_t key) {
+                                                             float* __restrict__ o, float* __restrict__ lse, unsigned* __restrict__ mask,
+                                                             int N, int Nk, int heads, float scale, float drop_scale, uint32_t thresh,
+                                                             uint32_t key) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
@@ -112,14 +113,16 @@ __global__ __launch_bounds__(256, 2) void attn_split_fwd_kernel(const float* __r
   const int nchunk = (Nk + KC - 1) / KC;
   const unsigned char* blk0 = ws + (long)bh * nchunk * BLOCK_BYTES;
 
-  // B operand of S^T: (q * scale)[qrow][16 ks + 8 h .. + 7] as planes
+  // B operand of S^T: (q * scale * log2 e)[qrow][16 ks + 8 h .. + 7] as planes: the scores come out in base-2 units, so every
+  // exponential below is one v_exp_f32 (the softmax is VALU-bound here: 32 probabilities per lane and chunk against 96 MFMAs)
   X8 qf[4][3];
   {
     const float* qp = q + ((long)b * N + (qok ? qrow : 0)) * C + hd * HD + 8 * h;
+    const float sc2 = scale * 1.44269504088896340736f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f}, c2 = {0.f, 0.f, 0.f, 0.f};
-      if (qok) { a = *reinterpret_cast<const f32x4*>(qp + 16 * ks) * scale; c2 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4) * scale; }
+      if (qok) { a = *reinterpret_cast<const f32x4*>(qp + 16 * ks) * sc2; c2 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4) * sc2; }
       split8(a, c2, qf[ks]);
     }
   }
@@ -160,18 +163,30 @@ __global__ __launch_bounds__(256, 2) void attn_split_fwd_kernel(const float* __r
       }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float mn = fmaxf(m, mloc);
-    const float alpha = expf(m - mn);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
     m = mn;
     float psum = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      unsigned bits = 0u;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float p = expf(S[t][i] - mn);            // exp(-inf) = 0 for the excluded keys
+        float p = __builtin_amdgcn_exp2f(S[t][i] - mn);            // 2^(-inf) = 0 for the excluded keys
         psum += p;
-        if (thresh != 0u) p = fs_dropout_keep(ebase + (uint32_t)(c * KC + 32 * t + acc_row(i, h)), key, thresh) ? p * drop_scale : 0.f;
+        if (thresh != 0u) {
+          const bool keep = fs_dropout_keep(ebase + (uint32_t)(c * KC + 32 * t + acc_row(i, h)), key, thresh);
+          p = keep ? p * drop_scale : 0.f;
+          bits |= keep ? (1u << acc_row(i, h)) : 0u;
+        }
         S[t][i] = p;
       }
+      // the keep decisions of (query, keys 64 c + 32 t .. + 31) as one word for the backward kernels, which then never hash
+      if (thresh != 0u && mask != nullptr) {
+        bits |= __shfl_xor(bits, 32, 64);
+        const int nword = (Nk + 31) >> 5;
+        if (qok && h == t && 2 * c + t < nword) mask[((long)bh * N + qrow) * nword + 2 * c + t] = bits;
+      }
+    }
     l = l * alpha + psum;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { O[0][i] *= alpha; O[1][i] *= alpha; }
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_fwd_kernel(const float* __r
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * h) =
           f32x4{O[dt][4 * g], O[dt][4 * g + 1], O[dt][4 * g + 2], O[dt][4 * g + 3]} * inv;
-  if (h == 0) lse[(long)bh * N + qrow] = m + logf(l);
+  if (h == 0) lse[(long)bh * N + qrow] = (m + log2f(l)) * 0.69314718055994530942f;      // natural log-sum-exp of the scores
 }
 
 // ---- backward, dQ: the same transposed tiles with the query on the lane -----------------------------------------------------------
@@ -274,8 +289,9 @@ __device__ __forceinline__ void stage_block_bwd(const unsigned char* __restrict_
 
 __global__ __launch_bounds__(256, 2) void attn_split_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ go,
                                                                 const unsigned char* __restrict__ ws, const float* __restrict__ lse,
-                                                                const float* __restrict__ D, float* __restrict__ dq, int N, int Nk, int heads,
-                                                                float scale, float drop_scale, uint32_t thresh, uint32_t key) {
+                                                                const float* __restrict__ D, const unsigned* __restrict__ mask,
+                                                                float* __restrict__ dq, int N, int Nk, int heads, float scale,
+                                                                float drop_scale, uint32_t thresh, uint32_t key) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS2_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
@@ -299,8 +315,12 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_dq_kernel(const float* 
       split8(g, g2, gf[ks]);
     }
   }
-  const float L = qok ? lse[(long)bh * N + qrow] : INFINITY;       // p = exp(s - inf) = 0 for lanes past the end
+  const float L2e = 1.44269504088896340736f;
+  const float Lb = (qok ? lse[(long)bh * N + qrow] : INFINITY) * L2e;       // p = 2^(s log2 e - inf) = 0 for lanes past the end
   const float Dq = qok ? D[(long)bh * N + qrow] : 0.f;
+  const int nword = (Nk + 31) >> 5;                 // the forward's keep words of this query (chunk c = word c), when it left them
+  const unsigned* mrow = mask != nullptr && qok && thresh != 0u ? mask + ((long)bh * N + qrow) * nword : nullptr;
+  unsigned mword = mrow != nullptr ? mrow[0] : 0u;
   const uint32_t ebase = (uint32_t)(((long)bh * N + qrow) * Nk);
   f32x16 dQ[2];
 #pragma unroll
@@ -327,12 +347,17 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_dq_kernel(const float* 
         dP = P::mfma(vf[P::ta(tm)], gf[ks][P::tb(tm)], dP);
       }
     }
+    const unsigned mw = mword;
+    if (mrow != nullptr && c + 1 < nchunk) mword = mrow[c + 1];          // (for the next chunk: in flight behind this one's products)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int keyi = c * KC2 + acc_row(i, h);
-      const float p = keyi < Nk ? expf(S[i] - L) : 0.f;
+      const float p = keyi < Nk ? __builtin_amdgcn_exp2f(fmaf(S[i], L2e, -Lb)) : 0.f;
       float mk = 1.f;
-      if (thresh != 0u) mk = fs_dropout_keep(ebase + (uint32_t)keyi, key, thresh) ? drop_scale : 0.f;
+      if (thresh != 0u) {
+        const bool keep = mask != nullptr ? ((mw >> acc_row(i, h)) & 1u) != 0u : fs_dropout_keep(ebase + (uint32_t)keyi, key, thresh);
+        mk = keep ? drop_scale : 0.f;
+      }
       S[i] = p * (mk * dP[i] - Dq);
     }
 #pragma unroll
@@ -374,14 +399,15 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_dq_kernel(const float* 
 // DK = true computes S, dP -> dK (5 tile products per (slice, tile) where a fused kernel would need 4).
 constexpr int QS = 32;                                     // queries per slice
 constexpr int SPL = QS * KPITCH;                           // one plane of a slice image: 4 608
-constexpr int L3_Q = 0, L3_G = 3 * SPL, L3_L = 6 * SPL;    // images, then lse[32], D[32]
-constexpr int LDS3_BYTES = 6 * SPL + 2 * QS * 4;           // 27 904
+constexpr int L3_Q = 0, L3_G = 3 * SPL, L3_L = 6 * SPL;    // images, then lse[32] (base-2 units), D[32], keep words [4 key tiles][32]
+constexpr int LDS3_BYTES = 6 * SPL + 6 * QS * 4;           // 28 416
 
 template <bool DK>
 __global__ __launch_bounds__(256, 2) void attn_split_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                 const float* __restrict__ v, const float* __restrict__ go,
                                                                 const float* __restrict__ lse, const float* __restrict__ D,
-                                                                float* __restrict__ dout, int N, int Nk, int heads, float scale,
+                                                                const unsigned* __restrict__ mask, float* __restrict__ dout, int N, int Nk,
+                                                                int heads, float scale,
                                                                 float drop_scale, uint32_t thresh, uint32_t key, int slices_per_split,
                                                                 int atomics) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS3_BYTES];
@@ -423,32 +449,51 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_kv_kernel(const float* 
   const int s_end = s_begin + slices_per_split < nslice ? s_begin + slices_per_split : nslice;
   const float* lsel = reinterpret_cast<const float*>(lds + L3_L);
 
+  // the next slice's rows travel from HBM while the current slice is computed: two Q and two dO float4s and one lse / D word per thread
+  f32x4 nq[2], ng[2];
+  float nl = 0.f;
+  const int nword = (Nk + 31) >> 5;
+  auto fetch = [&](int sl_) {
+    const int q0_ = sl_ * QS;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int qr = q0_ + srow + 16 * it;
+      nq[it] = f32x4{0.f, 0.f, 0.f, 0.f}; ng[it] = nq[it];
+      if (qr < N) {
+        nq[it] = *reinterpret_cast<const f32x4*>(qb + (long)qr * C + c4);
+        ng[it] = *reinterpret_cast<const f32x4*>(gb + (long)qr * C + c4);
+      }
+    }
+    if (tid < 2 * QS) {                    // lse (+inf past the end: p = 0) and D of the slice's queries
+      const int qr = q0_ + (tid & 31);
+      const bool ok = qr < N;
+      nl = tid < QS ? (ok ? lse[(long)bh * N + qr] * 1.44269504088896340736f : INFINITY) : (ok ? D[(long)bh * N + qr] : 0.f);
+    } else if (tid < 6 * QS && mask != nullptr) {      // the forward's keep words: (query, this workgroup's key tile (tid >> 5) - 2)
+      const int qr = q0_ + (tid & 31), tile = blockIdx.x * 4 + (tid >> 5) - 2;
+      nl = 0.f;
+      if (qr < N && tile < nword) nl = __builtin_bit_cast(float, mask[((long)bh * N + qr) * nword + tile]);
+    }
+  };
+  if (s_begin < s_end) fetch(s_begin);
+
   for (int sl = s_begin; sl < s_end; ++sl) {
     const int q0 = sl * QS;
     __syncthreads();                       // every wave is done with the previous slice
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int row = srow + 16 * it, qr = q0 + row;
-      f32x4 a = {0.f, 0.f, 0.f, 0.f}, g = a;
-      if (qr < N) {
-        a = *reinterpret_cast<const f32x4*>(qb + (long)qr * C + c4) * scale;
-        g = *reinterpret_cast<const f32x4*>(gb + (long)qr * C + c4);
-      }
+      const int row = srow + 16 * it;
       X4 pa[3], pg[3];
-      P::split4(a, pa);
-      P::split4(g, pg);
+      P::split4(nq[it] * scale, pa);
+      P::split4(ng[it], pg);
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
         *reinterpret_cast<X4*>(lds + L3_Q + pl * SPL + row * KPITCH + c4 * 2) = pa[pl];
         *reinterpret_cast<X4*>(lds + L3_G + pl * SPL + row * KPITCH + c4 * 2) = pg[pl];
       }
     }
-    if (tid < 2 * QS) {                    // lse (+inf past the end: p = 0) and D of the slice's queries
-      const int qr = q0 + (tid & 31);
-      const bool ok = qr < N;
-      reinterpret_cast<float*>(lds + L3_L)[tid] = tid < QS ? (ok ? lse[(long)bh * N + qr] : INFINITY) : (ok ? D[(long)bh * N + qr] : 0.f);
-    }
+    if (tid < 6 * QS) reinterpret_cast<float*>(lds + L3_L)[tid] = nl;
     __syncthreads();
+    if (sl + 1 < s_end) fetch(sl + 1);
 
     f32x16 S, dP;
 #pragma unroll
@@ -470,9 +515,13 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_kv_kernel(const float* 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int ql = acc_row(i, h);
-      const float p = kok ? expf(S[i] - lsel[ql]) : 0.f;
+      const float p = kok ? __builtin_amdgcn_exp2f(fmaf(S[i], 1.44269504088896340736f, -lsel[ql])) : 0.f;
       float mk = 1.f;
-      if (thresh != 0u) mk = fs_dropout_keep((uint32_t)(((long)bh * N + q0 + ql) * Nk) + (uint32_t)krow, key, thresh) ? drop_scale : 0.f;
+      if (thresh != 0u) {
+        const bool keep = mask != nullptr ? ((__builtin_bit_cast(unsigned, lsel[(2 + wave) * QS + ql]) >> r) & 1u) != 0u
+                                          : fs_dropout_keep((uint32_t)(((long)bh * N + q0 + ql) * Nk) + (uint32_t)krow, key, thresh);
+        mk = keep ? drop_scale : 0.f;
+      }
       S[i] = DK ? p * (mk * dP[i] - lsel[QS + ql]) : p * mk;
     }
     // output product: A = the dO (dV) or Q*scale (dK) image read transposed, rows d, k = queries in register order
@@ -513,14 +562,20 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_kv_kernel(const float* 
 
 extern "C" {
 
+// include/fovealseg.h: words of the dropout keep mask the forward can leave for the backward: B*heads*N rows of ceil(Nk / 32)
+long fs_attention_mask_words(int B, int N, int Nk, int heads) {
+  if (B <= 0 || N <= 0 || Nk <= 0 || heads <= 0) return 0;
+  return (long)B * heads * N * ((Nk + 31) >> 5);
+}
+
 // include/fovealseg.h: scratch of the split-precision attention entry points (the packed K / V^T planes)
 long fs_attention_split_ws_bytes(int B, int Nk, int heads) {
   if (B <= 0 || Nk <= 0 || heads <= 0) return 0;
   return (long)B * heads * ((Nk + KC - 1) / KC) * BLOCK_BYTES;
 }
 
-int fs_attention_fwd_split(const float* q, const float* k, const float* v, float* o, float* lse, void* ws, long ws_bytes, int B, int N, int Nk,
-                           int heads, float scale, float drop_p, uint32_t key, hipStream_t stream) {
+int fs_attention_fwd_split(const float* q, const float* k, const float* v, float* o, float* lse, unsigned* mask, void* ws, long ws_bytes, int B,
+                           int N, int Nk, int heads, float scale, float drop_p, uint32_t key, hipStream_t stream) {
   FS_REQUIRE(q && k && v && o && lse && ws && B > 0 && N > 0 && Nk > 0 && heads > 0 && drop_p >= 0.f && drop_p < 1.f);
   FS_REQUIRE((long)B * heads * N * Nk < 4294967296L && (long)B * heads < 65536 && ws_bytes >= fs_attention_split_ws_bytes(B, Nk, heads));
   float ds = 1.f; uint32_t thresh = 0u;
@@ -529,7 +584,7 @@ int fs_attention_fwd_split(const float* q, const float* k, const float* v, float
   hipLaunchKernelGGL(attn_pack_kv_kernel, dim3(nchunk, B * heads), dim3(256), 0, stream, k, v, reinterpret_cast<unsigned char*>(ws), Nk, heads, nchunk);
   FS_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_split_fwd_kernel, dim3((N + 127) / 128, B * heads), dim3(256), 0, stream, q, reinterpret_cast<const unsigned char*>(ws), o,
-                     lse, N, Nk, heads, scale, ds, thresh, key);
+                     lse, mask, N, Nk, heads, scale, ds, thresh, key);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -541,9 +596,9 @@ long fs_attention_bwd_split_ws_bytes(int B, int Nk, int heads) {
 }
 
 // dQ of the attention backward in split precision; D = B*heads*N floats holding rowsum(dO * O) (fs_attention_bwd computes them into its scratch)
-int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D, float* dq,
-                              void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key,
-                              hipStream_t stream) {
+int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D,
+                              const unsigned* mask, float* dq, void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale,
+                              float drop_p, uint32_t key, hipStream_t stream) {
   FS_REQUIRE(q && k && v && go && lse && D && dq && ws && B > 0 && N > 0 && Nk > 0 && heads > 0 && drop_p >= 0.f && drop_p < 1.f);
   FS_REQUIRE((long)B * heads * N * Nk < 4294967296L && (long)B * heads < 65536 && ws_bytes >= fs_attention_bwd_split_ws_bytes(B, Nk, heads));
   float ds = 1.f; uint32_t thresh = 0u;
@@ -552,15 +607,16 @@ int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, co
   hipLaunchKernelGGL(attn_pack_bwd_kernel, dim3(nchunk, B * heads), dim3(256), 0, stream, k, v, reinterpret_cast<unsigned char*>(ws), Nk, heads, nchunk);
   FS_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_split_bwd_dq_kernel, dim3((N + 127) / 128, B * heads), dim3(256), 0, stream, q, go,
-                     reinterpret_cast<const unsigned char*>(ws), lse, D, dq, N, Nk, heads, scale, ds, thresh, key);
+                     reinterpret_cast<const unsigned char*>(ws), lse, D, mask, dq, N, Nk, heads, scale, ds, thresh, key);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
 
 // dK and dV of the attention backward in split precision (no scratch: K / V rows are split into registers, the query slices in the kernel).
 // D = rowsum(dO * O).  dk / dv are overwritten.
-int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D, float* dk,
-                               float* dv, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key, hipStream_t stream) {
+int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D,
+                               const unsigned* mask, float* dk, float* dv, int B, int N, int Nk, int heads, float scale, float drop_p,
+                               uint32_t key, hipStream_t stream) {
   FS_REQUIRE(q && k && v && go && lse && D && dk && dv && B > 0 && N > 0 && Nk > 0 && heads > 0 && drop_p >= 0.f && drop_p < 1.f);
   FS_REQUIRE((long)B * heads * N * Nk < 4294967296L && (long)B * heads < 65536);
   float ds = 1.f; uint32_t thresh = 0u;
@@ -580,10 +636,10 @@ int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, c
     if (e != hipSuccess) return (int)e;
   }
   const dim3 grid(nkb, B * heads, nsplit);
-  hipLaunchKernelGGL(attn_split_bwd_kv_kernel<false>, grid, dim3(256), 0, stream, q, k, v, go, lse, D, dv, N, Nk, heads, scale, ds, thresh, key,
+  hipLaunchKernelGGL(attn_split_bwd_kv_kernel<false>, grid, dim3(256), 0, stream, q, k, v, go, lse, D, mask, dv, N, Nk, heads, scale, ds, thresh, key,
                      sps, nsplit > 1 ? 1 : 0);
   FS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_split_bwd_kv_kernel<true>, grid, dim3(256), 0, stream, q, k, v, go, lse, D, dk, N, Nk, heads, scale, ds, thresh, key,
+  hipLaunchKernelGGL(attn_split_bwd_kv_kernel<true>, grid, dim3(256), 0, stream, q, k, v, go, lse, D, mask, dk, N, Nk, heads, scale, ds, thresh, key,
                      sps, nsplit > 1 ? 1 : 0);
   FS_LAUNCH_CHECK();
   return FS_OK;

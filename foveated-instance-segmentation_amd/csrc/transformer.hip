@@ -866,15 +866,16 @@ int fs_attention_fwd(const float* q, const float* k, const float* v, float* o, f
   return FS_OK;
 }
 
-int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D, float* dq,
-                              void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key,
-                              hipStream_t stream);       // attention_split.hip
-int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D, float* dk,
-                               float* dv, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key, hipStream_t stream);
+int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D,
+                              const unsigned* mask, float* dq, void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale,
+                              float drop_p, uint32_t key, hipStream_t stream);       // attention_split.hip
+int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D,
+                               const unsigned* mask, float* dk, float* dv, int B, int N, int Nk, int heads, float scale, float drop_p,
+                               uint32_t key, hipStream_t stream);
 
 static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse, float* dq,
-                              float* dk, float* dv, float* scratch, void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale,
-                              float drop_p, uint32_t key, hipStream_t stream) {
+                              float* dk, float* dv, float* scratch, const unsigned* mask, void* ws, long ws_bytes, int B, int N, int Nk,
+                              int heads, float scale, float drop_p, uint32_t key, hipStream_t stream) {
   FS_REQUIRE(q && k && v && o && go && lse && dq && dk && dv && scratch && B > 0 && N > 0 && Nk > 0 && heads > 0);
   FS_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (long)B * heads * N * Nk < 4294967296L && (long)B * heads < 65536);
   float ds = 1.f; uint32_t thresh = 0u;
@@ -883,9 +884,9 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
   hipLaunchKernelGGL(attn_rowdot_kernel, dim3(cdiv(rows * 16, 256)), dim3(256), 0, stream, go, o, scratch, B, N, heads);
   FS_LAUNCH_CHECK();
   if (ws != nullptr) {          // split precision: all three gradients by attention_split.hip
-    const int e = fs_attention_bwd_dq_split(q, k, v, go, lse, scratch, dq, ws, ws_bytes, B, N, Nk, heads, scale, drop_p, key, stream);
+    const int e = fs_attention_bwd_dq_split(q, k, v, go, lse, scratch, mask, dq, ws, ws_bytes, B, N, Nk, heads, scale, drop_p, key, stream);
     if (e != FS_OK) return e;
-    return fs_attention_bwd_dkv_split(q, k, v, go, lse, scratch, dk, dv, B, N, Nk, heads, scale, drop_p, key, stream);
+    return fs_attention_bwd_dkv_split(q, k, v, go, lse, scratch, mask, dk, dv, B, N, Nk, heads, scale, drop_p, key, stream);
   } else {
     hipLaunchKernelGGL(attn_mfma_bwd_dq_kernel, dim3(cdiv(N, 128), B * heads), dim3(256), 0, stream, q, k, v, go, lse, scratch, dq, N, Nk,
                        heads, scale, ds, thresh, key);
@@ -915,15 +916,16 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
 int fs_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse, float* dq,
                      float* dk, float* dv, float* scratch, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key,
                      hipStream_t stream) {
-  return attention_bwd_impl(q, k, v, o, go, lse, dq, dk, dv, scratch, nullptr, 0, B, N, Nk, heads, scale, drop_p, key, stream);
+  return attention_bwd_impl(q, k, v, o, go, lse, dq, dk, dv, scratch, nullptr, nullptr, 0, B, N, Nk, heads, scale, drop_p, key, stream);
 }
 
-// the same with the split-precision (bf16x3) kernels where they exist; ws = fs_attention_bwd_split_ws_bytes(B, Nk, heads) bytes
-int fs_attention_bwd_split(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse, float* dq,
-                           float* dk, float* dv, float* scratch, void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale,
-                           float drop_p, uint32_t key, hipStream_t stream) {
+// the same with the split-precision (bf16x3) kernels; ws = fs_attention_bwd_split_ws_bytes(B, Nk, heads) bytes; mask = the keep words
+// fs_attention_fwd_split left (nullable: the kernels then hash again)
+int fs_attention_bwd_split(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse,
+                           const unsigned* mask, float* dq, float* dk, float* dv, float* scratch, void* ws, long ws_bytes, int B, int N, int Nk,
+                           int heads, float scale, float drop_p, uint32_t key, hipStream_t stream) {
   FS_REQUIRE(ws != nullptr);
-  return attention_bwd_impl(q, k, v, o, go, lse, dq, dk, dv, scratch, ws, ws_bytes, B, N, Nk, heads, scale, drop_p, key, stream);
+  return attention_bwd_impl(q, k, v, o, go, lse, dq, dk, dv, scratch, mask, ws, ws_bytes, B, N, Nk, heads, scale, drop_p, key, stream);
 }
 
 }  // extern "C"

@@ -77,11 +77,11 @@ SIGNATURES = {
     "fs_dwconv3_bwd_weight": "ppppiiiii",
     "fs_residual_droppath": "pppllfu",
     "fs_attention_fwd": "pppppiiiiffu",
-    "fs_attention_fwd_split": "pppppp" + "l" + "iiii" + "ffu",
+    "fs_attention_fwd_split": "ppppppp" + "l" + "iiii" + "ffu",
     "fs_attention_bwd": "ppppppppppiiiiffu",
-    "fs_attention_bwd_split": "pppppppppp" + "pl" + "iiii" + "ffu",
-    "fs_attention_bwd_dq_split": "ppppppp" + "pl" + "iiii" + "ffu",
-    "fs_attention_bwd_dkv_split": "pppppppp" + "iiii" + "ffu",
+    "fs_attention_bwd_split": "ppppppppppp" + "pl" + "iiii" + "ffu",
+    "fs_attention_bwd_dq_split": "pppppppp" + "pl" + "iiii" + "ffu",
+    "fs_attention_bwd_dkv_split": "ppppppppp" + "iiii" + "ffu",
 }
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 
@@ -89,7 +89,7 @@ _lib = None
 # declared in the header, host-side only (no stream argument)
 HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice",
              "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes", "fs_conv2d_bwd_data_bnsum_slabs",
-             "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes", "fs_attention_bwd_split_ws_bytes")
+             "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes", "fs_attention_bwd_split_ws_bytes", "fs_attention_mask_words")
 
 
 class HipLibraryError(RuntimeError):
@@ -134,6 +134,8 @@ def load():
     lib.fs_attention_split_ws_bytes.argtypes = [_I] * 3
     lib.fs_attention_bwd_split_ws_bytes.restype = _L
     lib.fs_attention_bwd_split_ws_bytes.argtypes = [_I] * 3
+    lib.fs_attention_mask_words.restype = _L
+    lib.fs_attention_mask_words.argtypes = [_I] * 4
     _lib = lib
     global _default_mode
     _default_mode = ("f32", "bf16x3", "f16x2")[lib.fs_get_conv_precision()]

@@ -1115,17 +1115,22 @@ class Attention(Function):
         assert C == heads * 64, "head_dim must be 64"
         o = torch.empty_like(q)
         lse = torch.empty(B * heads * N, device=q.device, dtype=torch.float32)
+        mask = None
         if ATTN_SPLIT and hip.get_conv_precision() == "bf16x3":
             # the headline arithmetic (24-bit operands as three bf16 planes, fp32 accumulation) on the attention products as well
             nb = hip.attention_split_ws_bytes(B, Nk, heads)
             ws = torch.empty(nb, device=q.device, dtype=torch.uint8)
+            if p > 0 and torch.is_grad_enabled():
+                # one keep bit per (query, key), left by the forward so that the three backward kernels do not hash every element again
+                mask = torch.empty(int(hip.load().fs_attention_mask_words(B, N, Nk, heads)), device=q.device, dtype=torch.int32)
             _launch("attn_fwd", 4.0 * B * heads * N * Nk * 64, "fs_attention_fwd_split", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o),
-                    hip.ptr(lse), hip.ptr(ws), nb, B, N, Nk, heads, 0.125, float(p), int(key))
+                    hip.ptr(lse), hip.ptr(mask) if mask is not None else None, hip.ptr(ws), nb, B, N, Nk, heads, 0.125, float(p), int(key))
         else:
             _launch("attn_fwd", 4.0 * B * heads * N * Nk * 64, "fs_attention_fwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o), hip.ptr(lse),
                     B, N, Nk, heads, 0.125, float(p), int(key))
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.cfg = (heads, float(p), int(key))
+        ctx.keep_mask = mask
         return o
 
     @staticmethod
@@ -1139,9 +1144,10 @@ class Attention(Function):
         if ATTN_SPLIT and hip.get_conv_precision() == "bf16x3":
             nb = hip.attention_split_ws_bytes(B, Nk, heads, backward=True)
             ws = torch.empty(nb, device=q.device, dtype=torch.uint8)
+            mask = ctx.keep_mask
             _launch("attn_bwd", 14.0 * B * heads * N * Nk * 64, "fs_attention_bwd_split", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o),
-                    hip.ptr(go.contiguous()), hip.ptr(lse), hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), hip.ptr(scratch), hip.ptr(ws), nb,
-                    B, N, Nk, heads, 0.125, p, key)
+                    hip.ptr(go.contiguous()), hip.ptr(lse), hip.ptr(mask) if mask is not None else None, hip.ptr(dq), hip.ptr(dk), hip.ptr(dv),
+                    hip.ptr(scratch), hip.ptr(ws), nb, B, N, Nk, heads, 0.125, p, key)
         else:
             _launch("attn_bwd", 14.0 * B * heads * N * Nk * 64, "fs_attention_bwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o),
                     hip.ptr(go.contiguous()), hip.ptr(lse), hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), hip.ptr(scratch), B, N, Nk, heads, 0.125, p, key)

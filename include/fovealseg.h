@@ -282,8 +282,11 @@ int fs_attention_fwd(const float* q, const float* k, const float* v, float* o, f
  * matrix-pipe time of the exact kernel.  ws = fs_attention_split_ws_bytes(B, Nk, heads) bytes of scratch (K / V^T planes, written by a
  * pre-pass inside the call).  Same dropout hash and element index as fs_attention_fwd.  csrc/attention_split.hip. */
 long fs_attention_split_ws_bytes(int B, int Nk, int heads);
-int fs_attention_fwd_split(const float* q, const float* k, const float* v, float* o, float* lse, void* ws, long ws_bytes, int B, int N,
-                           int Nk, int heads, float scale, float drop_p, uint32_t key, fs_stream_t stream);
+/* mask (nullable) = fs_attention_mask_words(B, N, Nk, heads) words: with drop_p > 0 the forward leaves the keep decisions there, one bit per
+ * (query, key) -- row (b*heads + head)*N + q, word key >> 5, bit key & 31 -- and the split backward reads them instead of hashing again. */
+long fs_attention_mask_words(int B, int N, int Nk, int heads);
+int fs_attention_fwd_split(const float* q, const float* k, const float* v, float* o, float* lse, unsigned* mask, void* ws, long ws_bytes,
+                           int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key, fs_stream_t stream);
 /* Backward of the above: dq, dk, dv overwritten.  o = the forward's output, go = its gradient, scratch = B*heads*N floats. */
 int fs_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse, float* dq,
                      float* dk, float* dv, float* scratch, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key,
@@ -291,16 +294,18 @@ int fs_attention_bwd(const float* q, const float* k, const float* v, const float
 /* The backward in split precision (bf16x3): dQ with the query on the MFMA lane (transposed score tile, dS fed to the K^T product from
  * registers), dK and dV with the key on the lane (P~ / dS fed to the dO^T / Q^T products from registers, the query-slice images read by rows
  * and transposed), no LDS round trip for P or dS.  ws = fs_attention_bwd_split_ws_bytes(B, Nk, heads) bytes of scratch (the dQ kernel's
- * K / V / K^T planes).  fs_attention_bwd_dq_split / _dkv_split are the two parts alone (D = rowsum(dO * O), B*heads*N floats). */
+ * K / V / K^T planes); mask = the forward's keep words or NULL (the kernels then hash again).  fs_attention_bwd_dq_split / _dkv_split are
+ * the two parts alone (D = rowsum(dO * O), B*heads*N floats). */
 long fs_attention_bwd_split_ws_bytes(int B, int Nk, int heads);
-int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D, float* dq,
-                              void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key,
-                              fs_stream_t stream);
-int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D, float* dk,
-                               float* dv, int B, int N, int Nk, int heads, float scale, float drop_p, uint32_t key, fs_stream_t stream);
-int fs_attention_bwd_split(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse, float* dq,
-                           float* dk, float* dv, float* scratch, void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale,
-                           float drop_p, uint32_t key, fs_stream_t stream);
+int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D,
+                              const unsigned* mask, float* dq, void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale,
+                              float drop_p, uint32_t key, fs_stream_t stream);
+int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D,
+                               const unsigned* mask, float* dk, float* dv, int B, int N, int Nk, int heads, float scale, float drop_p,
+                               uint32_t key, fs_stream_t stream);
+int fs_attention_bwd_split(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse,
+                           const unsigned* mask, float* dq, float* dk, float* dv, float* scratch, void* ws, long ws_bytes, int B, int N,
+                           int Nk, int heads, float scale, float drop_p, uint32_t key, fs_stream_t stream);
 
 /* ---- optimiser ------------------------------------------------------------------------------- */
 /* torch.optim.Adam(weight_decay) step over a flat fp32 arena of n (multiple of 4) elements; step >= 1;

@@ -1457,6 +1457,44 @@ def _attention_vs_torch(heads, N, Nk, p):
     assert relerr(vd.grad.cpu(), vr.grad) <= 1e-4
 
 
+def test_attention_keep_words_match_the_hash():
+    """The split forward leaves one keep bit per (query, key); the split backward must give the same gradients from those words as from
+    hashing the element indices again (mask = NULL), and the words must equal the oracle's replay mask."""
+    H = fovealseg.hip
+    H.set_conv_precision("bf16x3")
+    try:
+        B, heads, N, Nk, p = 2, 2, 203, 77, 0.2
+        C = heads * 64
+        g = torch.Generator().manual_seed(5)
+        q, k, v, go = (torch.randn(B, n, C, generator=g).to(DEV) for n in (N, Nk, Nk, N))
+        key = ops.layer_key(3, 30)
+        o, lse = torch.empty_like(q), torch.empty(B * heads * N, device=DEV)
+        nw = int(H.load().fs_attention_mask_words(B, N, Nk, heads))
+        assert nw == B * heads * N * 3
+        mask = torch.zeros(nw, device=DEV, dtype=torch.int32)
+        nb = H.attention_split_ws_bytes(B, Nk, heads)
+        ws = torch.empty(nb, device=DEV, dtype=torch.uint8)
+        H.call("fs_attention_fwd_split", H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(o), H.ptr(lse), H.ptr(mask), H.ptr(ws), nb, B, N, Nk, heads, 0.125, p, key)
+        keep = torch.from_numpy(O.dropout_keep_mask_nhwc(B * heads * N * Nk, key, p)).view(B * heads * N, Nk)
+        words = mask.view(B * heads * N, 3).cpu().numpy().astype(np.uint32)
+        bits = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).reshape(B * heads * N, 96)[:, :Nk]
+        assert np.array_equal(bits.astype(bool), keep.numpy().astype(bool))
+        nbb = H.attention_split_ws_bytes(B, Nk, heads, backward=True)
+        wsb = torch.empty(nbb, device=DEV, dtype=torch.uint8)
+        outs = []
+        for m in (mask, None):
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            scratch = torch.empty(B * heads * N, device=DEV)
+            H.call("fs_attention_bwd_split", H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(o), H.ptr(go), H.ptr(lse), H.ptr(m), H.ptr(dq), H.ptr(dk),
+                   H.ptr(dv), H.ptr(scratch), H.ptr(wsb), nbb, B, N, Nk, heads, 0.125, p, key)
+            outs.append((dq, dk, dv))
+        assert torch.equal(outs[0][0], outs[1][0])                       # dq: no atomics, the same arithmetic
+        for a, b_ in zip(outs[0][1:], outs[1][1:]):                      # dk / dv: split-q partial sums meet in atomics
+            assert relerr(a, b_) <= 1e-6
+    finally:
+        H.set_conv_precision(H.default_conv_precision())
+
+
 def _segformer_pair():
     import segformer_oracle as SO
     from fovealseg import segformer as S
