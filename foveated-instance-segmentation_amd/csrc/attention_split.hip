@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_kv_kernel(const float* 
     for (int it = 0; it < 2; ++it) {
       const int row = srow + 16 * it;
       X4 pa[3], pg[3];
-      P::split4(nq[it] * scale, pa);
+      P::split4(nq[it] * (scale * 1.44269504088896340736f), pa);      // base-2 units: dK = acc * ln 2 at the end
       P::split4(ng[it], pg);
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
@@ -495,9 +495,21 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_kv_kernel(const float* 
     __syncthreads();
     if (sl + 1 < s_end) fetch(sl + 1);
 
-    f32x16 S, dP;
+    // the per-query constants of this lane's 16 score rows, requested from LDS BEFORE the product chains so that their latency hides
+    // behind the MFMAs (read at their uses they were 48 exposed LDS round trips per slice); -lse is the chain's initial accumulator
+    f32x16 S, dP, Dv;
+    unsigned mwv[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { S[i] = -lsel[acc_row(i, h)]; dP[i] = 0.f; }
+    auto row_consts = [&]() {       // one batch of LDS reads: D[q] and the keep word of each of the lane's 16 score rows
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ql = acc_row(i, h);
+        Dv[i] = DK ? lsel[QS + ql] : 0.f;
+        mwv[i] = mask != nullptr ? __builtin_bit_cast(unsigned, lsel[(2 + wave) * QS + ql]) : 0u;
+      }
+    };
+    if (!DK) row_consts();          // (the dK instantiation has no registers to spare during the chains: it batches them behind)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       X8 qa[3], ga[3];
@@ -512,17 +524,18 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_kv_kernel(const float* 
         if (DK) dP = P::mfma(ga[P::ta(tm)], vf[ks][P::tb(tm)], dP);
       }
     }
+    if (DK) row_consts();
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int ql = acc_row(i, h);
-      const float p = kok ? __builtin_amdgcn_exp2f(fmaf(S[i], 1.44269504088896340736f, -lsel[ql])) : 0.f;
+      const float p = kok ? __builtin_amdgcn_exp2f(S[i]) : 0.f;          // S = (q k) log2 e - lse log2 e
       float mk = 1.f;
       if (thresh != 0u) {
-        const bool keep = mask != nullptr ? ((__builtin_bit_cast(unsigned, lsel[(2 + wave) * QS + ql]) >> r) & 1u) != 0u
+        const bool keep = mask != nullptr ? ((mwv[i] >> r) & 1u) != 0u
                                           : fs_dropout_keep((uint32_t)(((long)bh * N + q0 + ql) * Nk) + (uint32_t)krow, key, thresh);
         mk = keep ? drop_scale : 0.f;
       }
-      S[i] = DK ? p * (mk * dP[i] - lsel[QS + ql]) : p * mk;
+      S[i] = DK ? p * (mk * dP[i] - Dv[i]) : p * mk;
     }
     // output product: A = the dO (dV) or Q*scale (dK) image read transposed, rows d, k = queries in register order
 #pragma unroll
@@ -543,6 +556,10 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_kv_kernel(const float* 
     }
   }
   if (!kok || s_begin >= s_end) return;
+  if (DK) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[0][i] *= 0.69314718055994530942f; acc[1][i] *= 0.69314718055994530942f; }
+  }
   float* drow = dout + ((long)b * Nk + krow) * C + hd * HD;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -623,9 +640,19 @@ int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, c
   if (drop_p > 0.f) { ds = 1.0f / (float)(1.0 - (double)drop_p); thresh = (uint32_t)((double)drop_p * 4294967296.0); }
   // key tiles x (batch, head) workgroups; when that does not fill the chip the query range is split too (atomics into zeroed dk / dv)
   const int nkb = (Nk + 127) / 128, nslice = (N + QS - 1) / QS;
-  int nsplit = (int)((512 + (long)nkb * B * heads - 1) / ((long)nkb * B * heads));
-  if (nsplit > nslice) nsplit = nslice;
-  if (nsplit > 64) nsplit = 64;
+  // split of the query range: 512 workgroups are resident at once (two per CU), so the launch runs in ceil(workgroups / 512) rounds of
+  // ceil(nslice / nsplit) slices each -- pick the split with the fewest slice-times (320 x 2 = 640 workgroups was 2 rounds x 25 slices
+  // with the second round a quarter full; 320 x 3 is 2 x 17), with a small charge per split for its share of the atomics
+  const long base = (long)nkb * B * heads;
+  int nsplit = 1;
+  {
+    double best = 1e30;
+    for (int c = 1; c <= 16 && c <= nslice; ++c) {
+      const long rounds = (base * c + 511) / 512;
+      const double cost = (double)rounds * ((nslice + c - 1) / c) + 0.25 * c;
+      if (cost < best) { best = cost; nsplit = c; }
+    }
+  }
   const int sps = (nslice + nsplit - 1) / nsplit;
   nsplit = (nslice + sps - 1) / sps;
   if (nsplit > 1) {
