@@ -213,16 +213,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd16_kernel(const float* __res
 // ------------------------------------------------------------------------------------------
 // exact GELU
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n4) {
+// thresh != 0: the nn.Dropout that follows the activation (MixFFN) in the same pass -- element hash of fs_dropout on the output's index
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, float drop_scale,
+                                                       uint32_t thresh, uint32_t key) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752440f));
+    for (int j = 0; j < 4; ++j) {
+      v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752440f));
+      if (thresh != 0u) v[j] = fs_dropout_keep((uint32_t)(4 * i + j), key, thresh) ? v[j] * drop_scale : 0.f;
+    }
     reinterpret_cast<f32x4*>(y)[i] = v;
   }
 }
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
-                                                       float* __restrict__ dx, long n4) {
+                                                       float* __restrict__ dx, long n4, float drop_scale, uint32_t thresh, uint32_t key) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
     f32x4 d = reinterpret_cast<const f32x4*>(g)[i];
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
     for (int j = 0; j < 4; ++j) {
       const float cdf = 0.5f * (1.f + erff(v[j] * 0.70710678118654752440f));
       const float pdf = 0.39894228040143267794f * expf(-0.5f * v[j] * v[j]);
+      if (thresh != 0u) d[j] = fs_dropout_keep((uint32_t)(4 * i + j), key, thresh) ? d[j] * drop_scale : 0.f;
       d[j] *= cdf + v[j] * pdf;
     }
     reinterpret_cast<f32x4*>(dx)[i] = d;
@@ -794,14 +800,32 @@ int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const f
 int fs_gelu_fwd(const float* x, float* y, long n, hipStream_t stream) {
   FS_REQUIRE(x && y && n > 0 && n % 4 == 0);
   int blocks = cdiv(n / 4, 256); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, y, n / 4);
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, y, n / 4, 1.f, 0u, 0u);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
 int fs_gelu_bwd(const float* g, const float* x, float* dx, long n, hipStream_t stream) {
   FS_REQUIRE(g && x && dx && n > 0 && n % 4 == 0);
   int blocks = cdiv(n / 4, 256); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(blocks), dim3(256), 0, stream, g, x, dx, n / 4);
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(blocks), dim3(256), 0, stream, g, x, dx, n / 4, 1.f, 0u, 0u);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+// y = dropout_p(gelu(x)) and its backward dx = g * mask / (1-p) * gelu'(x) in one pass each (the mask of fs_dropout with the same key on
+// the same element index); n < 2^32
+int fs_gelu_dropout_fwd(const float* x, float* y, long n, float drop_p, uint32_t key, hipStream_t stream) {
+  FS_REQUIRE(x && y && n > 0 && n % 4 == 0 && n < 4294967296L && drop_p > 0.f && drop_p < 1.f);
+  int blocks = cdiv(n / 4, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, y, n / 4, 1.0f / (float)(1.0 - (double)drop_p),
+                     (uint32_t)((double)drop_p * 4294967296.0), key);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+int fs_gelu_dropout_bwd(const float* g, const float* x, float* dx, long n, float drop_p, uint32_t key, hipStream_t stream) {
+  FS_REQUIRE(g && x && dx && n > 0 && n % 4 == 0 && n < 4294967296L && drop_p > 0.f && drop_p < 1.f);
+  int blocks = cdiv(n / 4, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(blocks), dim3(256), 0, stream, g, x, dx, n / 4, 1.0f / (float)(1.0 - (double)drop_p),
+                     (uint32_t)((double)drop_p * 4294967296.0), key);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -73,6 +73,8 @@ SIGNATURES = {
     "fs_layernorm_bwd": "pppppppplii",
     "fs_gelu_fwd": "ppl",
     "fs_gelu_bwd": "pppl",
+    "fs_gelu_dropout_fwd": "pplfu",
+    "fs_gelu_dropout_bwd": "ppplfu",
     "fs_dwconv3_fwd": "ppppiiiii",
     "fs_dwconv3_bwd_weight": "ppppiiiii",
     "fs_residual_droppath": "pppllfu",

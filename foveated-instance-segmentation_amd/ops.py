@@ -1049,6 +1049,26 @@ class Gelu(Function):
         return dx
 
 
+class GeluDropout(Function):
+    """dropout_p(gelu(x)) in one pass each way (MixFFN's activation + hidden dropout); the mask is Dropout's for the same key."""
+
+    @staticmethod
+    def forward(ctx, x, p, key):
+        y = torch.empty_like(x)
+        hip.call("fs_gelu_dropout_fwd", hip.ptr(x), hip.ptr(y), x.numel(), float(p), int(key))
+        ctx.save_for_backward(x)
+        ctx.pk = (float(p), int(key))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        p, key = ctx.pk
+        dx = torch.empty_like(x)
+        hip.call("fs_gelu_dropout_bwd", hip.ptr(g.contiguous()), hip.ptr(x), hip.ptr(dx), x.numel(), p, key)
+        return dx, None, None
+
+
 class DwConv3(Function):
     """Depthwise Conv2d(C,C,3,1,1,groups=C) + bias on NHWC; w logical (C,1,3,3)."""
 

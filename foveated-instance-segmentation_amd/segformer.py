@@ -135,8 +135,11 @@ class MixFFN(nn.Module):
         self._path = ""
 
     def forward(self, x):
-        y = ops.Gelu.apply(self.dwconv(self.dense1(x)))
-        y = _drop(y, HIDDEN_DROPOUT, self.training, self._path + ".dropout1")
+        y = self.dwconv(self.dense1(x))
+        if self.training and HIDDEN_DROPOUT > 0 and y.numel() < 2 ** 32:
+            y = ops.GeluDropout.apply(y, HIDDEN_DROPOUT, ops.DropoutState.key(ops.layer_id_from_name(self._path + ".dropout1")))
+        else:
+            y = _drop(ops.Gelu.apply(y), HIDDEN_DROPOUT, self.training, self._path + ".dropout1")
         return self.dense2(y, HIDDEN_DROPOUT if self.training else 0.0, self._path + ".dropout2")
 
 

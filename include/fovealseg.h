@@ -260,6 +260,10 @@ int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const f
 /* exact (erf) GELU. */
 int fs_gelu_fwd(const float* x, float* y, long n, fs_stream_t stream);
 int fs_gelu_bwd(const float* g, const float* x, float* dx, long n, fs_stream_t stream);
+/* nn.GELU followed by nn.Dropout(p) (SegformerMixFFN: intermediate_act_fn, dropout; transformers 4.46.2, models/segformer.py:2,88-100) in
+ * one pass, and the backward of the pair in one pass: the mask of fs_dropout with the same key on the same element index.  n < 2^32. */
+int fs_gelu_dropout_fwd(const float* x, float* y, long n, float drop_p, uint32_t key, fs_stream_t stream);
+int fs_gelu_dropout_bwd(const float* g, const float* x, float* dx, long n, float drop_p, uint32_t key, fs_stream_t stream);
 /* depthwise Conv2d(C, C, 3, 1, 1, groups=C) on NHWC, weight (C,1,3,3); flip=1 gives the input gradient. */
 int fs_dwconv3_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int flip,
                    fs_stream_t stream);

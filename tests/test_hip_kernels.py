@@ -1397,6 +1397,17 @@ def test_layernorm_gelu_dwconv_droppath():
     out = ops.Gelu.apply(xd)
     out.backward(cot.to(DEV))
     assert relerr(out.detach().cpu(), ref.detach()) <= 1e-6 and relerr(xd.grad.cpu(), xr.grad) <= 1e-5
+    # GELU + the Dropout behind it in one pass each way: bit-identical to the two separate ops (same mask, same arithmetic order)
+    key = ops.layer_key(11, 5)
+    xa, xb = x.to(DEV).requires_grad_(True), x.to(DEV).requires_grad_(True)
+    ya = ops.GeluDropout.apply(xa, 0.3, key)
+    yb = ops.Dropout.apply(ops.Gelu.apply(xb), 0.3, key)
+    ya.backward(cot.to(DEV))
+    yb.backward(cot.to(DEV))
+    assert torch.equal(ya.detach(), yb.detach())
+    assert relerr(xa.grad, xb.grad) <= 1e-7
+    keep = torch.from_numpy(O.dropout_keep_mask_nhwc(x.numel(), key, 0.3)).view(x.shape)
+    assert torch.equal(ya.detach().cpu() != 0, keep & (F.gelu(x) != 0))
     # depthwise 3x3
     C = 256
     xi = torch.randn(2, C, 11, 13, generator=g)
