@@ -25,6 +25,7 @@
 // sites models/segformer.py:9-11,33-37).  Dropout keeps the element hash of transformer.hip (index (bh*N + q)*Nk + key), so a replayed
 // mask is the same in both kernel families.
 #include "conv_split.h"
+#include <cstdlib>
 
 namespace {
 
@@ -397,6 +398,9 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_dq_kernel(const float* 
 // rows for S / dP and transposed for the two output products.  Holding K and V planes (96 registers) plus both accumulators (64) plus
 // the S and dP tiles does not fit 256 registers without spills, so the two outputs are two instantiations: DK = false computes S -> dV,
 // DK = true computes S, dP -> dK (5 tile products per (slice, tile) where a fused kernel would need 4).
+// (Measured and rejected: ONE launch of wave pairs sharing a key tile -- wave A: S -> p -> P~ -> dV^T, wave B: dP -> dS -> dK^T, p handed over
+// through LDS; 48 MFMAs per wave and slice, 192 registers, no S recompute -- 497 us against 439 us: the time of these kernels follows the number
+// of (wave, slice) rounds, not their MFMA count, and the pair form has as many rounds plus a third barrier.)
 constexpr int QS = 32;                                     // queries per slice
 constexpr int SPL = QS * KPITCH;                           // one plane of a slice image: 4 608
 constexpr int L3_Q = 0, L3_G = 3 * SPL, L3_L = 6 * SPL;    // images, then lse[32] (base-2 units), D[32], keep words [4 key tiles][32]
@@ -640,19 +644,13 @@ int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, c
   if (drop_p > 0.f) { ds = 1.0f / (float)(1.0 - (double)drop_p); thresh = (uint32_t)((double)drop_p * 4294967296.0); }
   // key tiles x (batch, head) workgroups; when that does not fill the chip the query range is split too (atomics into zeroed dk / dv)
   const int nkb = (Nk + 127) / 128, nslice = (N + QS - 1) / QS;
-  // split of the query range: 512 workgroups are resident at once (two per CU), so the launch runs in ceil(workgroups / 512) rounds of
-  // ceil(nslice / nsplit) slices each -- pick the split with the fewest slice-times (320 x 2 = 640 workgroups was 2 rounds x 25 slices
-  // with the second round a quarter full; 320 x 3 is 2 x 17), with a small charge per split for its share of the atomics
+  // split of the query range only while the key tiles x (batch, head) leave CUs without a workgroup: every split pays the K / V prologue
+  // again and turns the final stores into atomics (stage 3 of configs[3], 320 workgroups: 1 split 439 us, 2-3 splits 540 us for dK + dV)
   const long base = (long)nkb * B * heads;
-  int nsplit = 1;
-  {
-    double best = 1e30;
-    for (int c = 1; c <= 16 && c <= nslice; ++c) {
-      const long rounds = (base * c + 511) / 512;
-      const double cost = (double)rounds * ((nslice + c - 1) / c) + 0.25 * c;
-      if (cost < best) { best = cost; nsplit = c; }
-    }
-  }
+  int nsplit = (int)(512 / base);
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > nslice) nsplit = nslice;
+  if (nsplit > 64) nsplit = 64;
   const int sps = (nslice + nsplit - 1) / nsplit;
   nsplit = (nslice + sps - 1) / sps;
   if (nsplit > 1) {
