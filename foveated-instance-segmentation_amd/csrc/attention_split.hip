@@ -226,18 +226,16 @@ __global__ __launch_bounds__(256, 2) void attn_split_fwd_kernel(const float* __r
 }
 
 // ---- backward, dQ: the same transposed tiles with the query on the lane -----------------------------------------------------------
-//     S^T = K (q*scale)^T,  dP~^T = V dO^T   (A = K / V rows of a 32-key chunk, B = the lane's q / dO row as planes, held in registers)
+//     S^T = K (q*scale)^T,  dP~^T = V dO^T   (A = K / V rows of a key tile, B = the lane's q / dO row as planes, held in registers)
 //     dS^T = P^T o (mask * dP~^T * drop_scale - D)     per lane: lse and D of the lane's query are scalars
-//     dQ^T[d][q] += K^T dS^T                 (A = K^T rows, keys in register order; B = dS^T planes straight from the registers)
-// No atomics (a workgroup owns its 128 queries), no LDS round trip for dS.  Packed per (bh, 32-key chunk): [K][V] row-major planes and
-// K^T planes, 36 KB; LDS pitches 144 B (rows of 64 d) / 72 B (rows of 32 keys).
-constexpr int KC2 = 32;
-constexpr int BW_ROWS = 3 * KC2 * HD * 2;                  // bytes of one tensor's three planes in a packed block: 12 288
-constexpr int BW_BLOCK = 3 * BW_ROWS;                      // K rm, V rm, K^T: 36 864
-constexpr int KPL2 = KC2 * KPITCH;                         // 4 608
-constexpr int TPITCH = 72, TPL = HD * TPITCH;              // K^T rows: 32 keys + 8 B; 4 608
-constexpr int L2_K = 0, L2_V = 3 * KPL2, L2_T = 6 * KPL2;
-constexpr int LDS2_BYTES = 6 * KPL2 + 3 * TPL;             // 41 472
+//     dQ^T[d][q] += K^T dS^T                 (A = the K image read TRANSPOSED, keys in register order; B = dS^T planes from the registers)
+// No atomics (a workgroup owns its 128 queries), no LDS round trip for dS.  Packed per (bh, 64-key chunk): [K][V] row-major planes, 48 KB,
+// one LDS image each at a 144-byte pitch; the two 32-key tiles of a chunk are processed one after the other between the same pair of
+// barriers (the time of these kernels follows the number of barrier rounds: 32-key chunks with a separate K^T image took 171 us per stage-3
+// launch, this form [see DESIGN.md 4b]).
+constexpr int BW_BLOCK = 6 * KC * HD * 2;                  // K rm, V rm: 49 152
+constexpr int L2_K = 0, L2_V = 3 * KPL;
+constexpr int LDS2_BYTES = 6 * KPL;                        // 55 296
 
 __global__ __launch_bounds__(256) void attn_pack_bwd_kernel(const float* __restrict__ k, const float* __restrict__ v, unsigned char* __restrict__ ws,
                                                             int Nk, int heads, int nchunk) {
@@ -247,10 +245,10 @@ __global__ __launch_bounds__(256) void attn_pack_bwd_kernel(const float* __restr
   const float* vb = v + (long)b * Nk * C + hd * HD;
   unsigned char* blk = ws + ((long)bh * nchunk + c) * BW_BLOCK;
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int item = threadIdx.x + 256 * it;       // (key row, channel quad): 32 x 16
+  for (int it = 0; it < 4; ++it) {
+    const int item = threadIdx.x + 256 * it;       // (key row, channel quad): 64 x 16
     const int key = item >> 4, c4 = (item & 15) * 4;
-    const int gk = c * KC2 + key;
+    const int gk = c * KC + key;
     f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
     if (gk < Nk) {
       kv = *reinterpret_cast<const f32x4*>(kb + (long)gk * C + c4);
@@ -261,30 +259,19 @@ __global__ __launch_bounds__(256) void attn_pack_bwd_kernel(const float* __restr
     P::split4(vv, pv);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
-      *reinterpret_cast<X4*>(blk + (pl * KC2 + key) * (HD * 2) + c4 * 2) = pk[pl];
-      *reinterpret_cast<X4*>(blk + BW_ROWS + (pl * KC2 + key) * (HD * 2) + c4 * 2) = pv[pl];
-      __bf16* kt = reinterpret_cast<__bf16*>(blk + 2 * BW_ROWS + pl * HD * KC2 * 2);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) kt[(c4 + e) * KC2 + key] = pk[pl][e];
+      *reinterpret_cast<X4*>(blk + (pl * KC + key) * (HD * 2) + c4 * 2) = pk[pl];
+      *reinterpret_cast<X4*>(blk + 3 * KC * HD * 2 + (pl * KC + key) * (HD * 2) + c4 * 2) = pv[pl];
     }
   }
 }
 
 __device__ __forceinline__ void stage_block_bwd(const unsigned char* __restrict__ blk, unsigned char* lds, int tid) {
-  typedef unsigned u2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int it = 0; it < 9; ++it) {
-    const int piece = tid + 256 * it;               // 2304 pieces of 16 bytes: 768 K, 768 V, 768 K^T (uniform per `it`)
+  for (int it = 0; it < 12; ++it) {
+    const int piece = tid + 256 * it;               // 3072 pieces of 16 bytes: 1536 K, 1536 V (uniform per `it`)
     const u32x4 d = *reinterpret_cast<const u32x4*>(blk + piece * 16);
-    if (it < 6) {
-      const int rem = it < 3 ? piece : piece - 768, pl = rem >> 8, row = (rem >> 3) & 31, seg = rem & 7;
-      *reinterpret_cast<u32x4*>(lds + (it < 3 ? L2_K : L2_V) + pl * KPL2 + row * KPITCH + seg * 16) = d;
-    } else {
-      const int rem = piece - 1536, pl = rem >> 8, row = (rem >> 2) & 63, seg = rem & 3;
-      unsigned char* dst = lds + L2_T + pl * TPL + row * TPITCH + seg * 16;
-      *reinterpret_cast<u2*>(dst) = u2{d.x, d.y};
-      *reinterpret_cast<u2*>(dst + 8) = u2{d.z, d.w};
-    }
+    const int rem = it < 6 ? piece : piece - 1536, pl = rem >> 9, row = (rem >> 3) & 63, seg = rem & 7;
+    *reinterpret_cast<u32x4*>(lds + (it < 6 ? L2_K : L2_V) + pl * KPL + row * KPITCH + seg * 16) = d;
   }
 }
 
@@ -299,82 +286,93 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_dq_kernel(const float* 
   const int C = heads * HD;
   const int qrow = blockIdx.x * 128 + wave * 32 + r;
   const bool qok = qrow < N;
-  const int nchunk = (Nk + KC2 - 1) / KC2;
+  const int nchunk = (Nk + KC - 1) / KC;
   const unsigned char* blk0 = ws + (long)bh * nchunk * BW_BLOCK;
 
-  X8 qf[4][3], gf[4][3];          // B operands: (q*scale) and dO rows of this lane's query
+  const float L2e = 1.44269504088896340736f;
+  X8 qf[4][3], gf[4][3];          // B operands: (q*scale*log2 e) and dO rows of this lane's query
   {
     const long off = ((long)b * N + (qok ? qrow : 0)) * C + hd * HD + 8 * h;
+    const float sc2 = scale * L2e;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f}, a2 = a, g = a, g2 = a;
       if (qok) {
-        a = *reinterpret_cast<const f32x4*>(q + off + 16 * ks) * scale; a2 = *reinterpret_cast<const f32x4*>(q + off + 16 * ks + 4) * scale;
+        a = *reinterpret_cast<const f32x4*>(q + off + 16 * ks) * sc2; a2 = *reinterpret_cast<const f32x4*>(q + off + 16 * ks + 4) * sc2;
         g = *reinterpret_cast<const f32x4*>(go + off + 16 * ks); g2 = *reinterpret_cast<const f32x4*>(go + off + 16 * ks + 4);
       }
       split8(a, a2, qf[ks]);
       split8(g, g2, gf[ks]);
     }
   }
-  const float L2e = 1.44269504088896340736f;
-  const float Lb = (qok ? lse[(long)bh * N + qrow] : INFINITY) * L2e;       // p = 2^(s log2 e - inf) = 0 for lanes past the end
+  const float Lb = (qok ? lse[(long)bh * N + qrow] : INFINITY) * L2e;       // -Lb starts the score chain: p = 2^S, 0 for lanes past the end
   const float Dq = qok ? D[(long)bh * N + qrow] : 0.f;
-  const int nword = (Nk + 31) >> 5;                 // the forward's keep words of this query (chunk c = word c), when it left them
+  const int nword = (Nk + 31) >> 5;                 // the forward's keep words of this query (key tile = word), when it left them
   const unsigned* mrow = mask != nullptr && qok && thresh != 0u ? mask + ((long)bh * N + qrow) * nword : nullptr;
-  unsigned mword = mrow != nullptr ? mrow[0] : 0u;
+  unsigned mword[2] = {mrow != nullptr ? mrow[0] : 0u, mrow != nullptr && nword > 1 ? mrow[1] : 0u};
   const uint32_t ebase = (uint32_t)(((long)bh * N + qrow) * Nk);
   f32x16 dQ[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dQ[0][i] = 0.f; dQ[1][i] = 0.f; }
+  // transposed-read lane constants (conv_wgrad.hip): lane 4 q' + p of a 16-lane group addresses row q', columns 4 p .. 4 p + 3
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, cb = 16 * ((lane >> 4) & 1);
+  const int tr_ofs = tq * KPITCH + (cb + 4 * tp) * 2;
 
   for (int c = 0; c < nchunk; ++c) {
     __syncthreads();
     stage_block_bwd(blk0 + (long)c * BW_BLOCK, lds, tid);
     __syncthreads();
-    f32x16 S, dP;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { S[i] = 0.f; dP[i] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      X8 kf[3], vf[3];
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        kf[pl] = *reinterpret_cast<const X8*>(lds + L2_K + pl * KPL2 + r * KPITCH + (16 * ks + 8 * h) * 2);
-        vf[pl] = *reinterpret_cast<const X8*>(lds + L2_V + pl * KPL2 + r * KPITCH + (16 * ks + 8 * h) * 2);
-      }
-#pragma unroll
-      for (int tm = 0; tm < P::NTERM; ++tm) {
-        S = P::mfma(kf[P::ta(tm)], qf[ks][P::tb(tm)], S);
-        dP = P::mfma(vf[P::ta(tm)], gf[ks][P::tb(tm)], dP);
-      }
-    }
-    const unsigned mw = mword;
-    if (mrow != nullptr && c + 1 < nchunk) mword = mrow[c + 1];          // (for the next chunk: in flight behind this one's products)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int keyi = c * KC2 + acc_row(i, h);
-      const float p = keyi < Nk ? __builtin_amdgcn_exp2f(fmaf(S[i], L2e, -Lb)) : 0.f;
-      float mk = 1.f;
-      if (thresh != 0u) {
-        const bool keep = mask != nullptr ? ((mw >> acc_row(i, h)) & 1u) != 0u : fs_dropout_keep(ebase + (uint32_t)keyi, key, thresh);
-        mk = keep ? drop_scale : 0.f;
-      }
-      S[i] = p * (mk * dP[i] - Dq);
+    const unsigned mw0 = mword[0], mw1 = mword[1];
+    if (mrow != nullptr) {                        // (for the next chunk: in flight behind this one's products)
+      mword[0] = 2 * c + 2 < nword ? mrow[2 * c + 2] : 0u;
+      mword[1] = 2 * c + 3 < nword ? mrow[2 * c + 3] : 0u;
     }
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      X8 df[3];
-      split8(f32x4{S[8 * s2], S[8 * s2 + 1], S[8 * s2 + 2], S[8 * s2 + 3]}, f32x4{S[8 * s2 + 4], S[8 * s2 + 5], S[8 * s2 + 6], S[8 * s2 + 7]}, df);
+    for (int t = 0; t < 2; ++t) {
+      f32x16 S, dP;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        X8 tf[3];
+      for (int i = 0; i < 16; ++i) { S[i] = -Lb; dP[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        X8 kf[3], vf[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-          const unsigned char* a0 = lds + L2_T + pl * TPL + (32 * dt + r) * TPITCH + (16 * s2 + 4 * h) * 2;
-          tf[pl] = cat(*reinterpret_cast<const X4*>(a0), *reinterpret_cast<const X4*>(a0 + 16));
+          kf[pl] = *reinterpret_cast<const X8*>(lds + L2_K + pl * KPL + (32 * t + r) * KPITCH + (16 * ks + 8 * h) * 2);
+          vf[pl] = *reinterpret_cast<const X8*>(lds + L2_V + pl * KPL + (32 * t + r) * KPITCH + (16 * ks + 8 * h) * 2);
         }
 #pragma unroll
-        for (int tm = 0; tm < P::NTERM; ++tm) dQ[dt] = P::mfma(tf[P::ta(tm)], df[P::tb(tm)], dQ[dt]);
+        for (int tm = 0; tm < P::NTERM; ++tm) {
+          S = P::mfma(kf[P::ta(tm)], qf[ks][P::tb(tm)], S);
+          dP = P::mfma(vf[P::ta(tm)], gf[ks][P::tb(tm)], dP);
+        }
+      }
+      const unsigned mw = t == 0 ? mw0 : mw1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int keyi = c * KC + 32 * t + acc_row(i, h);
+        const float p = keyi < Nk ? __builtin_amdgcn_exp2f(S[i]) : 0.f;
+        float mk = 1.f;
+        if (thresh != 0u) {
+          const bool keep = mask != nullptr ? ((mw >> acc_row(i, h)) & 1u) != 0u : fs_dropout_keep(ebase + (uint32_t)keyi, key, thresh);
+          mk = keep ? drop_scale : 0.f;
+        }
+        S[i] = p * (mk * dP[i] - Dq);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        X8 df[3];
+        split8(f32x4{S[8 * s2], S[8 * s2 + 1], S[8 * s2 + 2], S[8 * s2 + 3]}, f32x4{S[8 * s2 + 4], S[8 * s2 + 5], S[8 * s2 + 6], S[8 * s2 + 7]}, df);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          X8 tf[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            const unsigned char* a0 = lds + L2_K + pl * KPL + (32 * t + 16 * s2 + 4 * h) * KPITCH + 64 * dt + tr_ofs;
+            tf[pl] = cat(P::tr_read(a0), P::tr_read(a0 + 8 * KPITCH));
+          }
+#pragma unroll
+          for (int tm = 0; tm < P::NTERM; ++tm) dQ[dt] = P::mfma(tf[P::ta(tm)], df[P::tb(tm)], dQ[dt]);
+        }
       }
     }
   }
@@ -610,10 +608,10 @@ int fs_attention_fwd_split(const float* q, const float* k, const float* v, float
   return FS_OK;
 }
 
-// include/fovealseg.h: scratch of fs_attention_bwd_dq_split (K, V, K^T planes per 32-key chunk)
+// include/fovealseg.h: scratch of fs_attention_bwd_dq_split (K and V planes per 64-key chunk)
 long fs_attention_bwd_split_ws_bytes(int B, int Nk, int heads) {
   if (B <= 0 || Nk <= 0 || heads <= 0) return 0;
-  return (long)B * heads * ((Nk + KC2 - 1) / KC2) * BW_BLOCK;
+  return (long)B * heads * ((Nk + KC - 1) / KC) * BW_BLOCK;
 }
 
 // dQ of the attention backward in split precision; D = B*heads*N floats holding rowsum(dO * O) (fs_attention_bwd computes them into its scratch)
@@ -624,7 +622,7 @@ int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, co
   FS_REQUIRE((long)B * heads * N * Nk < 4294967296L && (long)B * heads < 65536 && ws_bytes >= fs_attention_bwd_split_ws_bytes(B, Nk, heads));
   float ds = 1.f; uint32_t thresh = 0u;
   if (drop_p > 0.f) { ds = 1.0f / (float)(1.0 - (double)drop_p); thresh = (uint32_t)((double)drop_p * 4294967296.0); }
-  const int nchunk = (Nk + KC2 - 1) / KC2;
+  const int nchunk = (Nk + KC - 1) / KC;
   hipLaunchKernelGGL(attn_pack_bwd_kernel, dim3(nchunk, B * heads), dim3(256), 0, stream, k, v, reinterpret_cast<unsigned char*>(ws), Nk, heads, nchunk);
   FS_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_split_bwd_dq_kernel, dim3((N + 127) / 128, B * heads), dim3(256), 0, stream, q, go,
