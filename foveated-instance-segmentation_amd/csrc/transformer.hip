@@ -392,6 +392,57 @@ __global__ __launch_bounds__(256) void residual_droppath_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// unfold / fold: a convolution whose filter has more taps than the aligned conv kernels take (7x7 patch embedding on 3 channels, the 8x8
+// stride-8 sequence-reduction conv) as rows of patches [B*Ho*Wo][Kp], Kp = k*k*C padded to a multiple of 4 (>= 16), element order (r, s, c)
+// = the RSCK weight's row order -- the layer is then ONE linear layer on the split-precision GEMM kernels (forward, input gradient, weight
+// gradient) instead of the generic fp32 kernels (configs[3]: 13 ms of a 228 ms step).  fold is the adjoint (input gradient of unfold).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unfold_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int H, int W, int C, int k,
+                                                     int stride, int pad, int Ho, int Wo, int Kp, long total4) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total4; t += (long)gridDim.x * 256) {
+    const int kq = Kp >> 2;
+    const long row = t / kq;
+    const int e0 = (int)(t - row * kq) * 4;
+    const int ox = (int)(row % Wo), oy = (int)((row / Wo) % Ho), b = (int)(row / ((long)Wo * Ho));
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = e0 + j;
+      if (e < k * k * C) {
+        const int c = e % C, rs = e / C, s_ = rs % k, r_ = rs / k;
+        const int iy = oy * stride - pad + r_, ix = ox * stride - pad + s_;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[j] = x[(((long)b * H + iy) * W + ix) * C + c];
+      }
+    }
+    reinterpret_cast<f32x4*>(col)[t] = v;
+  }
+}
+// dx[b][y][x][c] = sum over the taps (r, s) whose output pixel exists of col[(b, oy, ox)][(r, s, c)]
+__global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ col, float* __restrict__ dx, int B, int H, int W, int C, int k,
+                                                   int stride, int pad, int Ho, int Wo, int Kp, long total) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int c = (int)(t % C);
+    const long pix = t / C;
+    const int ix = (int)(pix % W), iy = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+    float acc = 0.f;
+    for (int r_ = 0; r_ < k; ++r_) {
+      const int ny = iy + pad - r_;
+      if (ny < 0 || ny % stride) continue;
+      const int oy = ny / stride;
+      if (oy >= Ho) continue;
+      for (int s_ = 0; s_ < k; ++s_) {
+        const int nx = ix + pad - s_;
+        if (nx < 0 || nx % stride) continue;
+        const int ox = nx / stride;
+        if (ox >= Wo) continue;
+        acc += col[(((long)b * Ho + oy) * Wo + ox) * Kp + (r_ * k + s_) * C + c];
+      }
+    }
+    dx[t] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Attention on the matrix cores, exact fp32: S = (q*scale) K^T, P = softmax(S), P~ = dropout(P), O = P~ V per (batch, head),
 // head_dim 64, any key count (the sequence-reduced keys of SegFormer: 100 at 80x80, 400 at 160x160), keys streamed through
 // LDS in chunks of 64 with an online softmax.  Products run on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: bit-for-bit
@@ -874,6 +925,28 @@ int fs_residual_droppath(const float* x, const float* y, float* out, long n, lon
   int blocks = cdiv(n / 4, 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(residual_droppath_kernel, dim3(blocks), dim3(256), 0, stream, x, y, out, n / 4, per_sample / 4, scale, thresh,
                      key);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// col[B*Ho*Wo][Kp] <- patches of x (B,H,W,C): element (r, s, c) of a k x k patch, zero where the patch leaves the image and in the padding
+// columns k*k*C .. Kp-1.  Kp % 4 == 0, Kp >= k*k*C.
+int fs_unfold(const float* x, float* col, int B, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, int Kp, hipStream_t stream) {
+  FS_REQUIRE(x && col && B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && Kp % 4 == 0 && Kp >= k * k * C);
+  FS_REQUIRE(Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1);
+  const long total4 = (long)B * Ho * Wo * (Kp / 4);
+  long blocks = (total4 + 255) / 256; if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(unfold_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, col, B, H, W, C, k, stride, pad, Ho, Wo, Kp, total4);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+// the adjoint: dx (B,H,W,C) overwritten with the sum of every patch element that came from it
+int fs_fold(const float* col, float* dx, int B, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, int Kp, hipStream_t stream) {
+  FS_REQUIRE(col && dx && B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && Kp % 4 == 0 && Kp >= k * k * C);
+  FS_REQUIRE(Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1);
+  const long total = (long)B * H * W * C;
+  long blocks = (total + 255) / 256; if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(fold_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, col, dx, B, H, W, C, k, stride, pad, Ho, Wo, Kp, total);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

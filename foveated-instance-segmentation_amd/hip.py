@@ -73,6 +73,8 @@ SIGNATURES = {
     "fs_layernorm_bwd": "pppppppplii",
     "fs_gelu_fwd": "ppl",
     "fs_gelu_bwd": "pppl",
+    "fs_unfold": "pp" + "iiiiiiiiii",
+    "fs_fold": "pp" + "iiiiiiiiii",
     "fs_gelu_dropout_fwd": "pplfu",
     "fs_gelu_dropout_bwd": "ppplfu",
     "fs_dwconv3_fwd": "ppppiiiii",

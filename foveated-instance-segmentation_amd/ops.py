@@ -1049,6 +1049,47 @@ class Gelu(Function):
         return dx
 
 
+class Unfold(Function):
+    """(B,H,W,C) -> (1, B*Ho*Wo, 1, Kp): k x k patches as rows, element order (r, s, c), zero-padded to Kp columns; backward folds."""
+
+    @staticmethod
+    def forward(ctx, x, k, stride, pad, kp):
+        B, H, W, C = x.shape
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        col = torch.empty(1, B * Ho * Wo, 1, kp, device=x.device, dtype=torch.float32)
+        hip.call("fs_unfold", hip.ptr(x), hip.ptr(col), B, H, W, C, k, stride, pad, Ho, Wo, kp)
+        ctx.geom = (B, H, W, C, k, stride, pad, Ho, Wo, kp)
+        return col
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, C, k, stride, pad, Ho, Wo, kp = ctx.geom
+        dx = torch.empty(B, H, W, C, device=g.device, dtype=torch.float32)
+        hip.call("fs_fold", hip.ptr(g.contiguous()), hip.ptr(dx), B, H, W, C, k, stride, pad, Ho, Wo, kp)
+        return dx, None, None, None, None
+
+
+UNFOLD_BIG_FILTERS = os.environ.get("FS_UNFOLD_CONV", "1") != "0"
+
+
+def conv_bias_any(x, w, bias, stride, pad):
+    """ConvBias, with filters of more than 32 taps (which the aligned split-precision kernels do not take: they would run on the generic fp32
+    kernels) unfolded into patch rows and computed as one linear layer.  The weight's RSCK storage [r][s][c][k] IS the (k*k*C, Cout) matrix
+    of that layer: a view, no copy, and its gradient lands in the same storage."""
+    cout, cin, r, s = w.shape
+    if not UNFOLD_BIG_FILTERS or r != s or r * s <= 32 or hip.get_conv_precision() != "bf16x3" or cout % 4 or cout < 16:
+        return ConvBias.apply(x, w, bias, stride, pad)
+    B, H, W, _ = x.shape
+    Ho, Wo = _out_hw(H, W, r, s, stride, pad)
+    kk = r * s * cin
+    kp = max(16, (kk + 3) // 4 * 4)
+    w2 = w.permute(2, 3, 1, 0).reshape(1, 1, kk, cout).permute(3, 2, 0, 1)      # logical (Cout, kk, 1, 1) over the same RSCK storage
+    if kp != kk:
+        w2 = PadWeightChannels.apply(w2, kp)
+    y = ConvBias.apply(Unfold.apply(x, r, stride, pad, kp), w2, bias, 1, 0)
+    return y.view(B, Ho, Wo, cout)
+
+
 class GeluDropout(Function):
     """dropout_p(gelu(x)) in one pass each way (MixFFN's activation + hidden dropout); the mask is Dropout's for the same key."""
 

@@ -68,7 +68,7 @@ class OverlapPatchEmbeddings(nn.Module):
         self.layer_norm = nn.LayerNorm(cout, eps=LN_EPS)
 
     def forward(self, x):                                   # (B,H,W,Cin) -> (B,h,w,C)
-        y = ops.ConvBias.apply(x, self.proj.weight, self.proj.bias, self.proj.stride, self.proj.padding)
+        y = ops.conv_bias_any(x, self.proj.weight, self.proj.bias, self.proj.stride, self.proj.padding)
         return _ln(self.layer_norm, y)
 
 
@@ -87,7 +87,7 @@ class EfficientSelfAttention(nn.Module):
         q = self.query(x).view(B, h * w, C)
         kv = x
         if self.sr_ratio > 1:
-            kv = ops.ConvBias.apply(x, self.sr.weight, self.sr.bias, self.sr_ratio, 0)
+            kv = ops.conv_bias_any(x, self.sr.weight, self.sr.bias, self.sr_ratio, 0)
             kv = _ln(self.layer_norm, kv)
         Nk = kv.shape[1] * kv.shape[2]
         k = self.key(kv).view(B, Nk, C)

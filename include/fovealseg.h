@@ -275,6 +275,12 @@ int fs_dwconv3_bwd_weight(const float* x, const float* dy, float* dw, float* ws,
 /* out = x + DropPath_p(y) (per-sample keep, hash keyed); x NULL -> out = scaled y (the backward of the y branch). */
 int fs_residual_droppath(const float* x, const float* y, float* out, long n, long per_sample, float drop_p, uint32_t key,
                          fs_stream_t stream);
+/* A convolution whose filter has more taps than the aligned kernels take (SegFormer's 7x7 patch embedding on 3 channels and 8x8 stride-8
+ * sequence-reduction conv: transformers 4.46.2 SegformerOverlapPatchEmbeddings / SegformerEfficientSelfAttention.sr, models/segformer.py:
+ * 9-11,33-37) as patch rows: col[B*Ho*Wo][Kp], element (r, s, c) of the k x k patch in the RSCK weight's row order, zeros outside the image
+ * and in the padding columns (Kp % 4 == 0) -- the layer is then one linear layer.  fs_fold is the adjoint (dx overwritten). */
+int fs_unfold(const float* x, float* col, int B, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, int Kp, fs_stream_t stream);
+int fs_fold(const float* col, float* dx, int B, int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, int Kp, fs_stream_t stream);
 /* softmax(q k^T * scale) (dropout p) v per head on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32
  * accumulate); head_dim 64, any number Nk of sequence-reduced key/value tokens (streamed in chunks of 64, online softmax);
  * q/o (B,N,heads*64), k/v (B,Nk,heads*64); lse = B*heads*N floats (log-sum-exp per query row, kept for the backward).

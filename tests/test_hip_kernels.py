@@ -1506,6 +1506,41 @@ def test_attention_keep_words_match_the_hash():
         H.set_conv_precision(H.default_conv_precision())
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co,k,stride,pad", [(2, 23, 17, 3, 64, 7, 1, 3), (2, 24, 16, 64, 64, 8, 8, 0), (1, 29, 31, 3, 32, 7, 4, 3),
+                                                      (2, 16, 16, 32, 48, 8, 8, 0)])
+def test_big_filter_conv_as_unfolded_linear(B, H, W, Ci, Co, k, stride, pad):
+    """Filters of more than 32 taps (SegFormer's 7x7 patch embedding, 8x8 stride-8 sequence reduction) run as unfold + one linear layer in
+    bf16x3 (ops.conv_bias_any): forward, input gradient (fold), weight and bias gradients against torch in fp64."""
+    fovealseg.hip.set_conv_precision("bf16x3")
+    try:
+        g = torch.Generator().manual_seed(B + H + Ci + k)
+        x = torch.randn(B, Ci, H, W, generator=g)
+        w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+        b = torch.randn(Co, generator=g)
+        x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+        ref = F.conv2d(x64, w64, b64, stride, pad)
+        cot = torch.randn(ref.shape, generator=g)
+        ref.backward(cot.double())
+        xd = nhwc(x).requires_grad_(True)
+        wd = rsck_param(w).requires_grad_(True)
+        bd = b.to(DEV).requires_grad_(True)
+        calls = []
+        real = fovealseg.hip.call
+        fovealseg.hip.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        try:
+            y = ops.conv_bias_any(xd, wd, bd, stride, pad)
+            y.backward(nhwc(cot))
+        finally:
+            fovealseg.hip.call = real
+        assert "fs_unfold" in calls and "fs_fold" in calls and "fs_linear_bwd_weight_bias" in calls
+        assert relerr(nchw(y.detach()), ref.detach()) <= 1e-5
+        assert relerr(nchw(xd.grad), x64.grad) <= 1e-5
+        assert relerr(wd.grad.cpu(), w64.grad) <= 2e-5
+        assert relerr(bd.grad.cpu(), b64.grad) <= 1e-5
+    finally:
+        fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
+
+
 def _segformer_pair():
     import segformer_oracle as SO
     from fovealseg import segformer as S
