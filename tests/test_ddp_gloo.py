@@ -323,7 +323,9 @@ def test_train_step_through_one_rank_rccl_group():
                 os.environ[k] = v
     assert scales == [1.0] * 4
     for a, b in zip(base_losses, losses):
-        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (base_losses, losses)       # bwd-weight float atomics reorder: not bit-identical
+        # bwd-weight float atomics reorder: not bit-identical.  The first loss is (measured: bit-equal), the second sits behind one Adam
+        # update whose +-lr steps on near-zero gradients can flip with the summation order: run-to-run spread up to 2.2e-5 relative
+        assert abs(a - b) <= 6e-5 * max(1.0, abs(a)), (base_losses, losses)
     # Adam moves an element by at most lr (= 1e-4 here) per step whatever the size of its gradient, so where a gradient is within the
     # atomics' rounding of zero the two runs can step in opposite directions: the worst element differs by <= 2 steps x 2 lr, while the
     # arena as a whole stays at the rounding level
