@@ -141,11 +141,31 @@ def weight_amax(w):
     return word
 
 
+# The conv kernels address a tensor with 32-bit byte offsets: an activation or gradient tensor of 4 GB or more (configs[3] at B = 64: the C1
+# head's 1024-channel input at 160 x 160 is 6.7 GB) is processed in batch ranges that fit -- the images of a batch are independent in all
+# three convolutions, BatchNorm partial-sum slabs simply concatenate, weight gradients accumulate.  Only the fused extras of the bwd-data
+# epilogue (BatchNorm sums, residual addend) are given up on that path.  Dropout masks hash the element index of the FULL tensor, which
+# the library cannot reproduce from a sub-range: such calls are not split (and fail loudly in the library, as before).
+MAX_TENSOR_BYTES = 4294967000
+
+
+def _batch_ranges(B, *per_image_elems):
+    """[(b0, b1), ...] with every listed per-image element count x (b1 - b0) x 4 bytes under MAX_TENSOR_BYTES; one range = no split."""
+    per = max(per_image_elems) * 4
+    if B * per < MAX_TENSOR_BYTES or B == 1:
+        return [(0, B)]
+    step = max(1, int((MAX_TENSOR_BYTES - 1) // per))
+    return [(b, min(B, b + step)) for b in range(0, B, step)]
+
+
 def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1, w_amax=None):
     B, H, W, Cin = x.shape
     Cout, Cin2, R, S = w.shape
     assert Cin == Cin2, (x.shape, w.shape)
     Ho, Wo = _out_hw(H, W, R, S, stride, pad, dil)
+    ranges = _batch_ranges(B, H * W * Cin, Ho * Wo * Cout) if drop_p == 0.0 else [(0, B)]
+    if len(ranges) > 1:
+        return torch.cat([conv2d_fwd(x[b0:b1], w, bias, stride, pad, 0.0, 0, dil, w_amax) for b0, b1 in ranges])
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
     kind = _conv_kind(Cin, Cout, R, S, stride, pad, dil)
     ws, ws_bytes = _conv_workspace(x.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0)
@@ -176,6 +196,10 @@ def conv2d_fwd_stats(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1, w_a
     Cout, Cin2, R, S = w.shape
     assert Cin == Cin2, (x.shape, w.shape)
     Ho, Wo = _out_hw(H, W, R, S, stride, pad, dil)
+    ranges = _batch_ranges(B, H * W * Cin, Ho * Wo * Cout) if drop_p == 0.0 else [(0, B)]
+    if len(ranges) > 1:          # slab rows of the ranges concatenate: the finalize pass sums over all of them
+        parts = [conv2d_fwd_stats(x[b0:b1], w, bias, stride, pad, 0.0, 0, dil, w_amax) for b0, b1 in ranges]
+        return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]), sum(p[2] for p in parts)
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
     ws, ws_bytes = _conv_workspace(x.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0)
     nwg = hip.conv_stats_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes)
@@ -202,6 +226,13 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1, w_amax=None, src_bn=None
     B, H, W, Cin = x_shape
     Cout, _, R, S = w.shape
     _, Ho, Wo, _ = dy.shape
+    ranges = _batch_ranges(B, H * W * Cin, Ho * Wo * Cout)
+    if len(ranges) > 1:          # without the fused extras; the addend joins afterwards
+        dx = torch.cat([conv2d_bwd_data(dy[b0:b1], w, (b1 - b0, H, W, Cin), stride, pad, dil, w_amax) for b0, b1 in ranges])
+        if addend is not None:
+            a_src, a_mask = addend
+            dx += a_src if a_mask is None else a_src * _unmask_bits(a_mask, a_src)
+        return dx
     dx = torch.empty(B, H, W, Cin, device=dy.device, dtype=torch.float32)
     kind = _conv_kind(Cout, Cin, R, S, stride, pad, dil)
     ws, ws_bytes = _conv_workspace(dy.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 1)
@@ -267,6 +298,12 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None, dil=1, accumulate=F
     B, H, W, Cin = x.shape
     Cout, _, R, S = w_shape
     _, Ho, Wo, _ = dy.shape
+    ranges = _batch_ranges(B, H * W * Cin, Ho * Wo * Cout)
+    if len(ranges) > 1:          # the ranges' gradients accumulate in one buffer
+        buf = out if out is not None else new_rsck_weight(Cout, Cin, R, S, device=x.device)
+        for i, (b0, b1) in enumerate(ranges):
+            conv2d_bwd_weight(x[b0:b1], dy[b0:b1], w_shape, stride, pad, out=buf, dil=dil, accumulate=accumulate or i > 0)
+        return buf
     dw = rsck(out) if out is not None else torch.empty(R, S, Cin, Cout, device=x.device, dtype=torch.float32)
     k3 = R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 16 and Cout >= 16
     _launch("wgrad3x3" if (k3 and hip.get_conv_precision() != "f32") else "conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin,

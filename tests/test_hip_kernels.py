@@ -391,6 +391,51 @@ def test_conv_bn_act(training, act, use_res, drop, prec):
 # ------------------------------------------------------------------------------------------------
 # front-end
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k,Ci,Co", [(3, 64, 64), (1, 64, 128)])
+def test_conv_batch_ranges_for_tensors_beyond_4gb(k, Ci, Co, monkeypatch):
+    """Tensors of 4 GB or more are convolved in batch ranges (ops._batch_ranges: the kernels address with 32-bit byte offsets).  With the
+    limit lowered so that B = 7 splits into ranges of 2, conv + BatchNorm forward and all gradients must equal the unsplit call: outputs
+    bit for bit (an output element's sum does not depend on its image's position in the batch), statistics / weight gradient to the
+    reordering of their sums."""
+    fovealseg.hip.set_conv_precision("bf16x3")
+    try:
+        B, H, W = 7, 12, 10
+        g = torch.Generator().manual_seed(k + Ci)
+        x = torch.randn(B, H, W, Ci, generator=g).to(DEV)
+        w = rsck_param(torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5)
+        gamma, beta = (1 + 0.1 * torch.randn(Co, generator=g)).to(DEV), (0.1 * torch.randn(Co, generator=g)).to(DEV)
+        cot = torch.randn(B, H, W, Co, generator=g).to(DEV)
+
+        class Cnt:
+            def add_(self, n):
+                pass
+
+        def run():
+            xd, wd, gd, bd = (t.clone().requires_grad_(True) for t in (x, w, gamma, beta))
+            meta = dict(stride=1, pad=k // 2, act=1, training=True, momentum=0.1, drop_p=0.0, drop_key=0,
+                        running_mean=torch.zeros(Co, device=DEV), running_var=torch.ones(Co, device=DEV), num_batches_tracked=Cnt())
+            z = ops.ConvBnAct.apply(xd, wd, None, gd, bd, None, meta)
+            z.backward(cot)
+            return z.detach(), xd.grad, wd.grad, gd.grad, bd.grad, meta["running_mean"], meta["running_var"]
+        whole = run()
+        per_image = max(H * W * Ci, H * W * Co) * 4
+        monkeypatch.setattr(ops, "MAX_TENSOR_BYTES", 2 * per_image + 1)
+        assert ops._batch_ranges(B, H * W * Ci, H * W * Co) == [(0, 2), (2, 4), (4, 6), (6, 7)]
+        split = run()
+        assert relerr(split[0], whole[0]) <= 1e-6          # z: the batch statistics differ in the last bits (slab order)
+        assert relerr(split[1], whole[1]) <= 1e-5
+        for a, b_ in zip(split[2:], whole[2:]):
+            assert relerr(a, b_) <= 1e-5
+        # the three convolutions themselves: bit-identical outputs, range by range
+        y_w = ops.conv2d_fwd(x, w, None, 1, k // 2)
+        dx_w = ops.conv2d_bwd_data(cot, w, x.shape, 1, k // 2)
+        monkeypatch.setattr(ops, "MAX_TENSOR_BYTES", 4294967000)
+        assert torch.equal(y_w, ops.conv2d_fwd(x, w, None, 1, k // 2))
+        assert torch.equal(dx_w, ops.conv2d_bwd_data(cot, w, x.shape, 1, k // 2))
+    finally:
+        fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
+
+
 def test_gaze_lowres_g2(golden):
     g = golden("g2_lowres_128")
     out = ops.gaze_lowres(T(g["x"]).to(DEV), T(g["focus"]).to(DEV), 80, 80)

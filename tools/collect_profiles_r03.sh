@@ -35,7 +35,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -- python3 $R/tool
 cp $(ls $O/c3/*/*kernel_stats.csv | tail -1) $O/config3_kernel_stats_bf16x3_b16.csv
 rm -rf $O/c3
 cd $R
-{ python3 tools/config_bench.py config3 16 4 bf16x3 2>/dev/null | tail -1; python3 tools/config_bench.py config3 32 3 bf16x3 2>/dev/null | tail -1;
+{ python3 tools/config_bench.py config3 16 4 bf16x3 2>/dev/null | tail -1; python3 tools/config_bench.py config3 64 3 bf16x3 2>/dev/null | tail -1;
   python3 tools/config_bench.py config2 32 4 bf16x3 2>/dev/null | tail -1; python3 tools/config_bench.py config4 16 4 bf16x3 2>/dev/null | tail -1; } > $O/config_bench.txt
 echo "[profiles] configs done"
 ls -la $O
