@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_kv_kernel(const float* 
                                                                 const unsigned* __restrict__ mask, float* __restrict__ dout, int N, int Nk,
                                                                 int heads, float scale,
                                                                 float drop_scale, uint32_t thresh, uint32_t key, int slices_per_split,
-                                                                int atomics) {
+                                                                long part_stride) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS3_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
@@ -557,24 +557,32 @@ __global__ __launch_bounds__(256, 2) void attn_split_bwd_kv_kernel(const float* 
       }
     }
   }
-  if (!kok || s_begin >= s_end) return;
+  if (!kok) return;                  // (a split always has slices; its accumulators are zero otherwise, and every split writes its rows)
   if (DK) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] *= 0.69314718055994530942f; acc[1][i] *= 0.69314718055994530942f; }
   }
-  float* drow = dout + ((long)b * Nk + krow) * C + hd * HD;
+  // one split: the gradient itself; several: this split's partial tensor (summed by attn_sum_parts_kernel -- plain 16-byte stores where
+  // fp32 atomics scattered over 64 rows per instruction cost more than the whole sweep)
+  float* drow = dout + (long)blockIdx.z * part_stride + ((long)b * Nk + krow) * C + hd * HD;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float* d4 = drow + 32 * dt + 8 * g + 4 * h;
-      if (atomics) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(d4 + e, acc[dt][4 * g + e]);
-      } else {
-        *reinterpret_cast<f32x4*>(d4) = f32x4{acc[dt][4 * g], acc[dt][4 * g + 1], acc[dt][4 * g + 2], acc[dt][4 * g + 3]};
-      }
-    }
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4*>(drow + 32 * dt + 8 * g + 4 * h) = f32x4{acc[dt][4 * g], acc[dt][4 * g + 1], acc[dt][4 * g + 2], acc[dt][4 * g + 3]};
+}
+
+// dk / dv = sum over the query splits of their partial tensors (rows a split did not reach are never read: every split writes every key row)
+__global__ __launch_bounds__(256) void attn_sum_parts_kernel(const float* __restrict__ parts, float* __restrict__ dk, float* __restrict__ dv,
+                                                             long n4, int nsplit) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * n4) return;
+  const bool second = i >= n4;
+  const long j = second ? i - n4 : i;
+  const f32x4* src = reinterpret_cast<const f32x4*>(parts) + (second ? (long)nsplit * n4 : 0) + j;
+  f32x4 a = src[0];
+  for (int s_ = 1; s_ < nsplit; ++s_) a += src[(long)s_ * n4];
+  reinterpret_cast<f32x4*>(second ? dv : dk)[j] = a;
 }
 
 }  // namespace
@@ -609,17 +617,20 @@ int fs_attention_fwd_split(const float* q, const float* k, const float* v, float
 }
 
 // include/fovealseg.h: scratch of fs_attention_bwd_dq_split (K and V planes per 64-key chunk)
+static long attn_dq_pack_bytes(int B, int Nk, int heads) { return (long)B * heads * ((Nk + KC - 1) / KC) * BW_BLOCK; }
 long fs_attention_bwd_split_ws_bytes(int B, int Nk, int heads) {
   if (B <= 0 || Nk <= 0 || heads <= 0) return 0;
-  return (long)B * heads * ((Nk + KC - 1) / KC) * BW_BLOCK;
+  return attn_dq_pack_bytes(B, Nk, heads) + 2L * 8 * B * Nk * heads * HD * 4;      // + the dK / dV partial tensors of up to 8 query splits
 }
+// offset of the partial tensors inside that scratch (fs_attention_bwd_split hands them to fs_attention_bwd_dkv_split)
+long fs_attention_bwd_split_parts_offset(int B, int Nk, int heads) { return attn_dq_pack_bytes(B, Nk, heads); }
 
 // dQ of the attention backward in split precision; D = B*heads*N floats holding rowsum(dO * O) (fs_attention_bwd computes them into its scratch)
 int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D,
                               const unsigned* mask, float* dq, void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale,
                               float drop_p, uint32_t key, hipStream_t stream) {
   FS_REQUIRE(q && k && v && go && lse && D && dq && ws && B > 0 && N > 0 && Nk > 0 && heads > 0 && drop_p >= 0.f && drop_p < 1.f);
-  FS_REQUIRE((long)B * heads * N * Nk < 4294967296L && (long)B * heads < 65536 && ws_bytes >= fs_attention_bwd_split_ws_bytes(B, Nk, heads));
+  FS_REQUIRE((long)B * heads * N * Nk < 4294967296L && (long)B * heads < 65536 && ws_bytes >= attn_dq_pack_bytes(B, Nk, heads));
   float ds = 1.f; uint32_t thresh = 0u;
   if (drop_p > 0.f) { ds = 1.0f / (float)(1.0 - (double)drop_p); thresh = (uint32_t)((double)drop_p * 4294967296.0); }
   const int nchunk = (Nk + KC - 1) / KC;
@@ -631,40 +642,50 @@ int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, co
   return FS_OK;
 }
 
-// dK and dV of the attention backward in split precision (no scratch: K / V rows are split into registers, the query slices in the kernel).
-// D = rowsum(dO * O).  dk / dv are overwritten.
+// split count of the dK / dV sweep over the query range: 512 workgroups are resident at once (two per CU), the launch runs in
+// ceil(workgroups / 512) rounds of ceil(nslice / nsplit) slices; fewest slice-times wins, a split costing a quarter slice (its K / V
+// prologue and its partial tensor).  Stage 3 of configs[3] (320 workgroups per split): 3 splits = 2 rounds x 17 slices instead of 1 x 50.
+static int attn_kv_splits(int B, int N, int Nk, int heads) {
+  const long base = (long)((Nk + 127) / 128) * B * heads;
+  const int nslice = (N + QS - 1) / QS;
+  int nsplit = 1;
+  double best = 1e30;
+  for (int c = 1; c <= 8 && c <= nslice; ++c) {
+    const long rounds = (base * c + 511) / 512;
+    const double cost = (double)rounds * ((nslice + c - 1) / c) + 0.25 * c;
+    if (cost < best) { best = cost; nsplit = c; }
+  }
+  const int sps = (nslice + nsplit - 1) / nsplit;
+  return (nslice + sps - 1) / sps;
+}
+
+// dK and dV of the attention backward in split precision.  D = rowsum(dO * O).  dk / dv are overwritten.  parts (nullable) = 2 * 8 * B * Nk *
+// heads * 64 floats of scratch for the per-split partial tensors; without it the query range is not split.
 int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D,
-                               const unsigned* mask, float* dk, float* dv, int B, int N, int Nk, int heads, float scale, float drop_p,
-                               uint32_t key, hipStream_t stream) {
+                               const unsigned* mask, float* dk, float* dv, float* parts, int B, int N, int Nk, int heads, float scale,
+                               float drop_p, uint32_t key, hipStream_t stream) {
   FS_REQUIRE(q && k && v && go && lse && D && dk && dv && B > 0 && N > 0 && Nk > 0 && heads > 0 && drop_p >= 0.f && drop_p < 1.f);
   FS_REQUIRE((long)B * heads * N * Nk < 4294967296L && (long)B * heads < 65536);
   float ds = 1.f; uint32_t thresh = 0u;
   if (drop_p > 0.f) { ds = 1.0f / (float)(1.0 - (double)drop_p); thresh = (uint32_t)((double)drop_p * 4294967296.0); }
-  // key tiles x (batch, head) workgroups; when that does not fill the chip the query range is split too (atomics into zeroed dk / dv)
   const int nkb = (Nk + 127) / 128, nslice = (N + QS - 1) / QS;
-  // split of the query range only while the key tiles x (batch, head) leave CUs without a workgroup: every split pays the K / V prologue
-  // again and turns the final stores into atomics (stage 3 of configs[3], 320 workgroups: 1 split 439 us, 2-3 splits 540 us for dK + dV)
-  const long base = (long)nkb * B * heads;
-  int nsplit = (int)(512 / base);
-  if (nsplit < 1) nsplit = 1;
-  if (nsplit > nslice) nsplit = nslice;
-  if (nsplit > 64) nsplit = 64;
+  const int nsplit = parts != nullptr ? attn_kv_splits(B, N, Nk, heads) : 1;
   const int sps = (nslice + nsplit - 1) / nsplit;
-  nsplit = (nslice + sps - 1) / sps;
-  if (nsplit > 1) {
-    const size_t kvbytes = (size_t)B * Nk * heads * HD * sizeof(float);
-    hipError_t e = hipMemsetAsync(dk, 0, kvbytes, stream);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(dv, 0, kvbytes, stream);
-    if (e != hipSuccess) return (int)e;
-  }
+  const long elems = (long)B * Nk * heads * HD;
   const dim3 grid(nkb, B * heads, nsplit);
-  hipLaunchKernelGGL(attn_split_bwd_kv_kernel<false>, grid, dim3(256), 0, stream, q, k, v, go, lse, D, mask, dv, N, Nk, heads, scale, ds, thresh, key,
-                     sps, nsplit > 1 ? 1 : 0);
+  float* out_v = nsplit > 1 ? parts + (long)nsplit * elems : dv;
+  float* out_k = nsplit > 1 ? parts : dk;
+  hipLaunchKernelGGL(attn_split_bwd_kv_kernel<false>, grid, dim3(256), 0, stream, q, k, v, go, lse, D, mask, out_v, N, Nk, heads, scale, ds, thresh,
+                     key, sps, nsplit > 1 ? elems : 0L);
   FS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_split_bwd_kv_kernel<true>, grid, dim3(256), 0, stream, q, k, v, go, lse, D, mask, dk, N, Nk, heads, scale, ds, thresh, key,
-                     sps, nsplit > 1 ? 1 : 0);
+  hipLaunchKernelGGL(attn_split_bwd_kv_kernel<true>, grid, dim3(256), 0, stream, q, k, v, go, lse, D, mask, out_k, N, Nk, heads, scale, ds, thresh,
+                     key, sps, nsplit > 1 ? elems : 0L);
   FS_LAUNCH_CHECK();
+  if (nsplit > 1) {
+    const long n4 = elems / 4;
+    hipLaunchKernelGGL(attn_sum_parts_kernel, dim3((unsigned)((2 * n4 + 255) / 256)), dim3(256), 0, stream, parts, dk, dv, n4, nsplit);
+    FS_LAUNCH_CHECK();
+  }
   return FS_OK;
 }
 

@@ -967,8 +967,10 @@ int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, co
                               const unsigned* mask, float* dq, void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale,
                               float drop_p, uint32_t key, hipStream_t stream);       // attention_split.hip
 int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D,
-                               const unsigned* mask, float* dk, float* dv, int B, int N, int Nk, int heads, float scale, float drop_p,
-                               uint32_t key, hipStream_t stream);
+                               const unsigned* mask, float* dk, float* dv, float* parts, int B, int N, int Nk, int heads, float scale,
+                               float drop_p, uint32_t key, hipStream_t stream);
+long fs_attention_bwd_split_ws_bytes(int B, int Nk, int heads);
+long fs_attention_bwd_split_parts_offset(int B, int Nk, int heads);
 
 static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse, float* dq,
                               float* dk, float* dv, float* scratch, const unsigned* mask, void* ws, long ws_bytes, int B, int N, int Nk,
@@ -983,7 +985,9 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
   if (ws != nullptr) {          // split precision: all three gradients by attention_split.hip
     const int e = fs_attention_bwd_dq_split(q, k, v, go, lse, scratch, mask, dq, ws, ws_bytes, B, N, Nk, heads, scale, drop_p, key, stream);
     if (e != FS_OK) return e;
-    return fs_attention_bwd_dkv_split(q, k, v, go, lse, scratch, mask, dk, dv, B, N, Nk, heads, scale, drop_p, key, stream);
+    float* parts = ws_bytes >= fs_attention_bwd_split_ws_bytes(B, Nk, heads)
+                       ? reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + fs_attention_bwd_split_parts_offset(B, Nk, heads)) : nullptr;
+    return fs_attention_bwd_dkv_split(q, k, v, go, lse, scratch, mask, dk, dv, parts, B, N, Nk, heads, scale, drop_p, key, stream);
   } else {
     hipLaunchKernelGGL(attn_mfma_bwd_dq_kernel, dim3(cdiv(N, 128), B * heads), dim3(256), 0, stream, q, k, v, go, lse, scratch, dq, N, Nk,
                        heads, scale, ds, thresh, key);

@@ -85,7 +85,7 @@ SIGNATURES = {
     "fs_attention_bwd": "ppppppppppiiiiffu",
     "fs_attention_bwd_split": "ppppppppppp" + "pl" + "iiii" + "ffu",
     "fs_attention_bwd_dq_split": "pppppppp" + "pl" + "iiii" + "ffu",
-    "fs_attention_bwd_dkv_split": "ppppppppp" + "iiii" + "ffu",
+    "fs_attention_bwd_dkv_split": "pppppppppp" + "iiii" + "ffu",
 }
 _CT = {"p": _P, "i": _I, "l": _L, "f": _F, "u": _U}
 
@@ -93,7 +93,7 @@ _lib = None
 # declared in the header, host-side only (no stream argument)
 HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice",
              "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes", "fs_conv2d_bwd_data_bnsum_slabs",
-             "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes", "fs_attention_bwd_split_ws_bytes", "fs_attention_mask_words")
+             "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes", "fs_attention_bwd_split_ws_bytes", "fs_attention_mask_words", "fs_attention_bwd_split_parts_offset")
 
 
 class HipLibraryError(RuntimeError):
@@ -138,6 +138,8 @@ def load():
     lib.fs_attention_split_ws_bytes.argtypes = [_I] * 3
     lib.fs_attention_bwd_split_ws_bytes.restype = _L
     lib.fs_attention_bwd_split_ws_bytes.argtypes = [_I] * 3
+    lib.fs_attention_bwd_split_parts_offset.restype = _L
+    lib.fs_attention_bwd_split_parts_offset.argtypes = [_I] * 3
     lib.fs_attention_mask_words.restype = _L
     lib.fs_attention_mask_words.argtypes = [_I] * 4
     _lib = lib

@@ -310,9 +310,12 @@ long fs_attention_bwd_split_ws_bytes(int B, int Nk, int heads);
 int fs_attention_bwd_dq_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D,
                               const unsigned* mask, float* dq, void* ws, long ws_bytes, int B, int N, int Nk, int heads, float scale,
                               float drop_p, uint32_t key, fs_stream_t stream);
+/* parts (nullable): 2 * 8 * B * Nk * heads * 64 floats for the partial dK / dV of up to 8 splits of the query range (summed by a small
+ * kernel; without it the range is not split).  fs_attention_bwd_split carves it from its ws at fs_attention_bwd_split_parts_offset. */
+long fs_attention_bwd_split_parts_offset(int B, int Nk, int heads);
 int fs_attention_bwd_dkv_split(const float* q, const float* k, const float* v, const float* go, const float* lse, const float* D,
-                               const unsigned* mask, float* dk, float* dv, int B, int N, int Nk, int heads, float scale, float drop_p,
-                               uint32_t key, fs_stream_t stream);
+                               const unsigned* mask, float* dk, float* dv, float* parts, int B, int N, int Nk, int heads, float scale,
+                               float drop_p, uint32_t key, fs_stream_t stream);
 int fs_attention_bwd_split(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse,
                            const unsigned* mask, float* dq, float* dk, float* dv, float* scratch, void* ws, long ws_bytes, int B, int N,
                            int Nk, int heads, float scale, float drop_p, uint32_t key, fs_stream_t stream);

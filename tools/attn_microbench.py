@@ -46,8 +46,9 @@ def main():
                                    B, N, Nk, heads, scale, p, key), reps)
         t_q = timed(lambda: H.call("fs_attention_bwd_dq_split", H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(go), H.ptr(lse), H.ptr(D), H.ptr(mask),
                                    H.ptr(dq), H.ptr(wsb), nbb, B, N, Nk, heads, scale, p, key), reps)
+        parts = torch.empty(2 * 8 * B * Nk * C, device=dev)
         t_kv = timed(lambda: H.call("fs_attention_bwd_dkv_split", H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(go), H.ptr(lse), H.ptr(D), H.ptr(mask),
-                                    H.ptr(dk), H.ptr(dv), B, N, Nk, heads, scale, p, key), reps)
+                                    H.ptr(dk), H.ptr(dv), H.ptr(parts), B, N, Nk, heads, scale, p, key), reps)
         print(f"B{B} h{heads} N{N} Nk{Nk}: fwd {t_f:7.1f} us {flops / t_f / 1e6:6.1f} TF | dq {t_q:7.1f} us {1.5 * flops / t_q / 1e6:6.1f} TF | "
               f"dkv {t_kv:7.1f} us {2.5 * flops / t_kv / 1e6:6.1f} TF", flush=True)
 
