@@ -6,6 +6,8 @@ models/model_utils.py:224-309 (ResidualBlock, ResNet, C1), lib/nn/modules/batchn
 Inside the encoder/decoder, activations are NHWC tensors (B,H,W,C); the plugin boundaries take and
 return the reference's logical NCHW shapes (as channels-last views, no copy).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -73,10 +75,36 @@ def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, act, res=None, drop_p=0.
                 running_mean=bn.running_mean, running_var=bn.running_var, num_batches_tracked=_NbtCounter(bn),
                 grad_enabled=torch.is_grad_enabled())
     x, w = ops.pad_in_channels(x, conv.weight)
-    z = ops.ConvBnAct.apply(x, w, conv.bias, bn.weight, bn.bias, res, meta)
+    d = meta["dil"]
+    if (SPACE_TO_BATCH_DILATED and d > 1 and w.shape[2] == 3 and w.shape[3] == 3 and meta["stride"] == 1 and meta["pad"] == d
+            and x.shape[1] % d == 0 and x.shape[2] % d == 0 and not (training and drop_p > 0)):
+        # An atrous 3x3 conv (DeepLab layer3 / layer4) = d*d ordinary 3x3 convs, pad 1, on the d*d sub-sampled phase images x[d i + a][d j + b]:
+        # the phases become batch entries, so the layer runs on the halo-tiled / F(2,3) kernels instead of the general one (configs[4]:
+        # 160 us per launch on 10x10 maps there).  BatchNorm sees the same set of elements; zero padding of a phase image is the
+        # dilated conv's zero padding.  The two re-orderings are plain views + one copy each way, and differentiable as such.
+        meta2 = dict(meta, dil=1, pad=1)
+        z = _batch_to_space(ops.ConvBnAct.apply(_space_to_batch(x, d), w, conv.bias, bn.weight, bn.bias,
+                                                None if res is None else _space_to_batch(res, d), meta2), d)
+    else:
+        z = ops.ConvBnAct.apply(x, w, conv.bias, bn.weight, bn.bias, res, meta)
     if ops.ACT_TRACE is not None and act != ACT_NONE:
         ops.ACT_TRACE.append((bn, act, z))
     return z
+
+
+SPACE_TO_BATCH_DILATED = os.environ.get("FS_S2B_DILATED", "1") != "0"      # A/B switch, read once
+
+
+def _space_to_batch(x, d):
+    """(B,H,W,C) -> (B*d*d, H/d, W/d, C): entry (b, a, bb) holds x[b][d i + a][d j + bb]."""
+    B, H, W, C = x.shape
+    return x.reshape(B, H // d, d, W // d, d, C).permute(0, 2, 4, 1, 3, 5).reshape(B * d * d, H // d, W // d, C)
+
+
+def _batch_to_space(y, d):
+    Bd, h, w, C = y.shape
+    B = Bd // (d * d)
+    return y.reshape(B, d, d, h, w, C).permute(0, 3, 1, 4, 2, 5).reshape(B, h * d, w * d, C)
 
 
 PARALLEL_BRANCHES = True
