@@ -77,6 +77,11 @@ def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, act, res=None, drop_p=0.
     x, w = ops.pad_in_channels(x, conv.weight)
     d = meta["dil"]
     if (SPACE_TO_BATCH_DILATED and d > 1 and w.shape[2] == 3 and w.shape[3] == 3 and meta["stride"] == 1 and meta["pad"] == d
+            and d >= x.shape[1] and d >= x.shape[2]):
+        # ASPP rates of 12 / 24 / 36 on a 10 x 10 map: every tap but the centre reads zero padding only, so the layer IS the 1 x 1 conv of its
+        # centre tap (and the other taps' gradients are exactly zero)
+        z = ops.ConvBnAct.apply(x, ops.CenterTap.apply(w), conv.bias, bn.weight, bn.bias, res, dict(meta, dil=1, pad=0))
+    elif (SPACE_TO_BATCH_DILATED and d > 1 and w.shape[2] == 3 and w.shape[3] == 3 and meta["stride"] == 1 and meta["pad"] == d
             and x.shape[1] % d == 0 and x.shape[2] % d == 0 and not (training and drop_p > 0)):
         # An atrous 3x3 conv (DeepLab layer3 / layer4) = d*d ordinary 3x3 convs, pad 1, on the d*d sub-sampled phase images x[d i + a][d j + b]:
         # the phases become batch entries, so the layer runs on the halo-tiled / F(2,3) kernels instead of the general one (configs[4]:

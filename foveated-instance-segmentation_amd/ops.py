@@ -352,6 +352,28 @@ class PadWeightChannels(Function):
         return g[:, :ctx.cin], None
 
 
+class CenterTap(Function):
+    """(Cout,Cin,3,3) RSCK weight -> its centre tap as a (Cout,Cin,1,1) RSCK weight; backward = zeros with the centre filled in."""
+
+    @staticmethod
+    def forward(ctx, w):
+        cout, cin, r, s = w.shape
+        wc = new_rsck_weight(cout, cin, 1, 1, device=w.device)
+        rsck(wc)[0, 0].copy_(rsck(w)[r // 2, s // 2])
+        ctx.rs = (r, s)
+        return wc
+
+    @staticmethod
+    def backward(ctx, g):
+        r, s = ctx.rs
+        cout, cin = g.shape[:2]
+        gw = new_rsck_weight(cout, cin, r, s, device=g.device)
+        v = rsck(gw)
+        v.zero_()
+        v[r // 2, s // 2].copy_(rsck(g)[0, 0])
+        return gw
+
+
 def pad_in_channels(x, w):
     """(x (B,H,W,Cin), w) -> (x padded with zero channels, w padded alike) when Cin is not a multiple of 4 and the split-precision
     kernels are on; exact: the extra products are 0 * 0."""

@@ -436,6 +436,40 @@ def test_conv_batch_ranges_for_tensors_beyond_4gb(k, Ci, Co, monkeypatch):
         fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
 
 
+def test_atrous_conv_as_phase_batches_and_centre_tap(prec):
+    """modules.conv_bn_act's two rewrites of an atrous 3x3 conv, against F.conv2d with the dilation in fp64: (a) dilation d, pad d on a map
+    divisible by d = ordinary 3x3 convs on the d*d phase images (space-to-batch), forward and both gradients; (b) a rate at least as large
+    as the map = the 1x1 conv of the centre tap, with zero gradient on the eight other taps."""
+    from fovealseg import modules as M
+    g = torch.Generator().manual_seed(77)
+    B, C, Co, H, W, d = 2, 32, 48, 12, 8, 2
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv2d(x64, w64, None, 1, d, d)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot.double())
+    xd, wd = nhwc(x).requires_grad_(True), rsck_param(w).requires_grad_(True)
+    y = M._batch_to_space(ops.ConvBias.apply(M._space_to_batch(xd, d), wd, None, 1, 1), d)
+    y.backward(nhwc(cot))
+    assert relerr(nchw(y), ref.detach()) <= 2e-5
+    assert relerr(nchw(xd.grad), x64.grad) <= 2e-5
+    assert relerr(wd.grad.cpu(), w64.grad) <= 5e-5
+    # (b) rate 12 on a 10 x 10 map
+    x = torch.randn(B, C, 10, 10, generator=g)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv2d(x64, w64, None, 1, 12, 12)
+    cot = torch.randn(ref.shape, generator=g)
+    ref.backward(cot.double())
+    xd, wd = nhwc(x).requires_grad_(True), rsck_param(w).requires_grad_(True)
+    y = ops.ConvBias.apply(xd, ops.CenterTap.apply(wd), None, 1, 0)
+    y.backward(nhwc(cot))
+    assert relerr(nchw(y), ref.detach()) <= 2e-5
+    assert relerr(nchw(xd.grad), x64.grad) <= 2e-5
+    assert relerr(wd.grad.cpu(), w64.grad) <= 5e-5
+    assert float(wd.grad[:, :, 0, 0].abs().max()) == 0.0 and float(w64.grad[:, :, 0, 0].abs().max()) == 0.0
+
+
 def test_gaze_lowres_g2(golden):
     g = golden("g2_lowres_128")
     out = ops.gaze_lowres(T(g["x"]).to(DEV), T(g["focus"]).to(DEV), 80, 80)
