@@ -17,6 +17,16 @@
     if (!(cond)) return FS_ERR_ARG; \
   } while (0)
 
+// Kernel-experiment switches (which of two measured variants a shape takes) exist only in builds made with -DFS_EXPERIMENTS
+// (`FS_BUILD_EXPERIMENTS=1 python build.py` -> ab/libfovealseg_experiments.so, loaded through FS_HIP_LIB for same-box A/B runs).
+// In the shipped library the macro is its default, a compile-time constant: no getenv, and the branch not taken is dead code.
+#ifdef FS_EXPERIMENTS
+#include <stdlib.h>
+#define FS_ENV_INT(name, dflt) ([] { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }())
+#else
+#define FS_ENV_INT(name, dflt) (dflt)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

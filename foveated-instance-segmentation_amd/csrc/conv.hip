@@ -1026,7 +1026,7 @@ bool use_tapset(const ConvArgs& c) {
 }
 
 // 1x1 / stride-1 layers go to the GEMM kernel with pre-split weights (conv_pointwise.hip) when the caller handed over its scratch.
-static const bool g_pointwise = [] { const char* e = getenv("FS_POINTWISE"); return !(e && e[0] == '0'); }();
+static const bool g_pointwise = FS_ENV_INT("FS_POINTWISE", 1) != 0;
 bool use_pointwise(const ConvArgs& c) {
   return g_pointwise && g_conv_precision >= 1 && c.ws_ != nullptr && fs_pointwise_eligible(c.Cs, c.Cd, c.R, c.S, c.stride, c.pad, c.dil) &&
          c.Hs == c.Hd && c.Ws == c.Wd && c.ws_bytes_ >= fs_pointwise_pack_bytes(g_conv_precision, c.Cs, c.Cd) &&

@@ -646,8 +646,8 @@ int launch_linear_wgrad(LwArgs a, int target, hipStream_t stream) {
 // take a 64-wide tile on their side; wide layers take 128 x 128 over 512 workgroups while a split still sees >= 512 rows (the row loop
 // dominates), otherwise 64 x 64 over 1024 (a quarter of the atomics per workgroup: the epilogue dominates).
 int run_linear_wgrad(LwArgs l, hipStream_t stream) {
-  static const int force = [] { const char* e = getenv("FS_LW_TILE"); return e ? atoi(e) : 0; }();       // kernel A/B only, read once
-  static const int force_wgs = [] { const char* e = getenv("FS_LW_WGS"); return e ? atoi(e) : 0; }();
+  static const int force = FS_ENV_INT("FS_LW_TILE", 0);       // kernel A/B builds only (common.h), read once
+  static const int force_wgs = FS_ENV_INT("FS_LW_WGS", 0);
   int tile, target = 512;
   if (l.Cin <= 64 && l.Cout <= 64) tile = 1;
   else if (l.Cin <= 64) tile = 2;
@@ -769,7 +769,7 @@ int fs_wgrad_split(int mode, const float* x, const float* dy, float* dw, int B, 
   a.x_bytes = (unsigned)((size_t)B * H * W * Cin * 4);
   a.dy_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * 4);
   const int ntile = a.tiles_ci * a.tiles_co;
-  static const int wino_pol = [] { const char* e = getenv("FS_WGRAD_WINO"); return e ? atoi(e) : 1; }();      // read once (kernel A/B): 0 never, 2 always
+  static const int wino_pol = FS_ENV_INT("FS_WGRAD_WINO", 1);      // kernel A/B builds only: 0 never, 2 always
   const bool wino_wgrad = wino_pol != 0, wino_wgrad_all = wino_pol == 2;
   if (mode == 1 && wino_wgrad && R == 3 && S == 3 && stride == 1 && pad == 1 && H == Ho && W == Wo && W % 2 == 0 && W >= 2) {
     // bf16x3, even width: the transform-domain kernel (2/3 of the MFMAs)
@@ -807,7 +807,7 @@ int fs_wgrad_split(int mode, const float* x, const float* dy, float* dw, int B, 
     return FS_OK;
   }
 direct:
-  static const bool linear_on = [] { const char* e = getenv("FS_WGRAD_LINEAR"); return e == nullptr || atoi(e) != 0; }();      // read once (kernel A/B)
+  static const bool linear_on = FS_ENV_INT("FS_WGRAD_LINEAR", 1) != 0;      // kernel A/B builds only
   if (mode == 1 && linear_on && R == 1 && S == 1 && stride == 1 && pad == 0 && H == Ho && W == Wo) {
     LwArgs l;
     l.x = x; l.dy = dy; l.dw = dw; l.dbias = nullptr; l.rows = B * H * W; l.Cin = Cin; l.Cout = Cout;

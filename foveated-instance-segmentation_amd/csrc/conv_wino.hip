@@ -24,6 +24,7 @@
 //   stores; round 3), bias / dropout / BatchNorm partial sums on those rows.
 #include "conv_split.h"
 #include "conv_kernels.h"
+#include "conv_wino_diag.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -53,19 +54,8 @@ struct WinoArgs {
   // the epilogue, so the separate normalise / activate pass over the conv output disappears (ep_scale NULL = off)
   const float* ep_scale; const float* ep_shift; const float* ep_res; int ep_act;
   float drop_scale; uint32_t drop_thresh, drop_key;
-#ifdef FS_WINO_TRACE
-  long long* dbg;                  // [workgroup][32] phase time stamps of wave 0 (tools/wino_trace.sh)
-#endif
-#ifdef FS_WINO_CLOCK
-  long long* clk;                  // [workgroup][2] kernel-long deltas of s_memtime and s_memrealtime (tools/wino_clock.sh)
-#endif
+  WINO_DIAG_FIELDS                 // empty in the shipped build (conv_wino_diag.h: diagnostic builds -DFS_WINO_TRACE / -DFS_WINO_CLOCK)
 };
-
-#ifdef FS_WINO_TRACE
-#define WINO_STAMP(i) do { if (tid == 0 && first_tile) a.dbg[(long)blockIdx.x * 32 + (i)] = clock64(); } while (0)
-#else
-#define WINO_STAMP(i) do { } while (0)
-#endif
 
 // Weight pack: Up[g4 = ((chunk*3 + ky)*4 + c)*2 + s][plane][n][j] = plane-th term of U_c of filter row ky at
 // (k = 32*chunk + 16*s + j, n), scaled by 2^(14-Ew) in f16x2 (|U| <= 1.5 max|w| stays inside fp16), behind a HDR-byte header.
@@ -144,12 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: cp selects the wave's B stream through the SGPR offset operand
   const int cp = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
-#ifdef FS_WINO_TRACE
-  bool first_tile = true;
-#endif
-#ifdef FS_WINO_CLOCK
-  const long long ck0 = clock64(), rt0 = wall_clock64();      // s_memtime (shader cycles), s_memrealtime (100 MHz)
-#endif
+  WINO_DIAG_KERNEL_BEGIN;
   WINO_STAMP(0);
   // ---- persistent schedule: XCD x owns a contiguous range of tiles (the column tiles of one pixel tile and neighbouring halos meet
   // in one 4 MB L2); its workgroups (blockIdx & 7 == x under round-robin placement -- speed only) take every L-th tile of it ----
@@ -531,15 +516,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     }
     WINO_STAMP(24);
     if (!has_next) break;
-#ifdef FS_WINO_TRACE
-    first_tile = false;
-#endif
+    WINO_DIAG_NEXT_TILE;
     wg = wg_next; mt = mt_n; n0 = n0_n; bvoff = bvoff_n; par ^= 1;
   }
-#ifdef FS_WINO_CLOCK
-  // in-kernel clock (MI355X_MICROARCH.md, DVFS give-back (6)): delta s_memtime / delta s_memrealtime x 100 MHz, to a buffer nothing else reads
-  if (tid == 0 && a.clk != nullptr) { a.clk[2 * blockIdx.x] = clock64() - ck0; a.clk[2 * blockIdx.x + 1] = wall_clock64() - rt0; }
-#endif
+  WINO_DIAG_KERNEL_END;
 }
 
 // ---- eight-wave variant with the split work INSIDE the MFMA phase (bf16x3, round 3) ----------------------------------------------
@@ -927,7 +907,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_kernel(WinoArgs a) {
   }
 }
 
-const bool g_wino = [] { const char* e = getenv("FS_WINOGRAD"); return !(e && e[0] == '0'); }();
+const bool g_wino = FS_ENV_INT("FS_WINOGRAD", 1) != 0;
 
 // Ph rows x PP pairs <= 64 pairs per workgroup, halo (Ph+2)*PP <= WNS; fewest tiles over the stacked batch, then smallest halo.
 void wino_plan(int B, int H, int W, int& Ph, int& PP, int& tiles_x, int& nx) {
@@ -960,17 +940,12 @@ int wino_grid_slots() {
   return slots[dev];
 }
 
-#ifdef FS_WINO_CLOCK
-long long* g_clk = nullptr;
-int g_clk_n = 0;
-#endif
-
 // Which 3x3 layers take the eight-wave kernel: bf16x3, more than 64 output channels (128-column workgroups) and at least 8 channel
 // chunks -- measured in one gpurun call against the persistent 4-wave kernel: 256 -> 256 @ 20x20 139 vs 150 us, 512 -> 512 @ 10x10
 // 150 vs 165 us, 960 -> 240 @ 80x80 5.81 vs 5.92 ms; 128 -> 128 @ 40x40 the same; its 64-column form (k-halves) 19 % slower on
 // 64 -> 64 @ 80x80 and not kept.  FS_WINO8=0 / 2: never / every layer above 64 output channels (kernel experiments; read once).
 bool wino_use8(int mode, int Cs, int Cd) {
-  static const int pol = [] { const char* e = getenv("FS_WINO8"); return e ? atoi(e) : 1; }();
+  static const int pol = FS_ENV_INT("FS_WINO8", 1);
   if (mode != 1 || Cd <= 64 || pol == 0) return false;
   return pol == 2 || Cs >= 256;
 }
@@ -1012,54 +987,14 @@ int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int 
     }
   }
   const unsigned grid = (unsigned)(ntile < slots ? ntile : slots);
-#ifdef FS_WINO_CLOCK
-  if (g_clk == nullptr && hipMalloc(&g_clk, sizeof(long long) * 2 * 4096) != hipSuccess) return FS_ERR_ARG;
-  a.clk = g_clk; g_clk_n = (int)grid;
-#endif
-#ifdef FS_WINO_TRACE
-  static long long* dbg = nullptr;
-  const long nwg = grid;
-  if (dbg == nullptr && hipMalloc(&dbg, sizeof(long long) * 32 * 65536) != hipSuccess) return FS_ERR_ARG;
-  a.dbg = dbg;
-  if (hipMemsetAsync(dbg, 0, sizeof(long long) * 32 * nwg, stream) != hipSuccess) return FS_ERR_ARG;
-#endif
+  WINO_DIAG_BEFORE_LAUNCH(a, grid, stream);
   hipLaunchKernelGGL((conv3x3_wino_kernel<P>), dim3(grid), dim3(256), lds, stream, a);
   FS_LAUNCH_CHECK();
-#ifdef FS_WINO_TRACE
-  {
-    static long long host[32 * 65536];
-    if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(host, dbg, sizeof(long long) * 32 * nwg, hipMemcpyDeviceToHost) != hipSuccess) return FS_ERR_ARG;
-    double sum[32] = {0};
-    for (long w_ = 0; w_ < nwg; ++w_)
-      for (int i = 1; i < 25; ++i) {
-        if (host[w_ * 32 + i] == 0) continue;
-        int prev = i - 1;
-        while (prev > 0 && host[w_ * 32 + prev] == 0) --prev;
-        sum[i] += (double)(host[w_ * 32 + i] - host[w_ * 32 + prev]);
-      }
-    fprintf(stderr, "wino trace (first tile of each workgroup) B%d %dx%d %d->%d nchunk %d tiles %ld grid %ld:", a.B, a.H, a.W, a.Cs, a.Cd, a.nchunk, ntile, nwg);
-    for (int i = 1; i < 25; ++i) if (sum[i] > 0) fprintf(stderr, " [%d]%.0f", i, sum[i] / nwg);
-    fprintf(stderr, "\n");
-  }
-#endif
+  WINO_DIAG_AFTER_LAUNCH(a, grid, ntile, stream);
   return FS_OK;
 }
 
 }  // namespace
-
-#ifdef FS_WINO_CLOCK
-// diagnostic build only (tools/wino_clock.sh): median over the workgroups of the LAST 4-wave launch of delta s_memtime / delta s_memrealtime
-extern "C" double fs_debug_wino_clock_ghz() {
-  if (g_clk == nullptr || g_clk_n <= 0) return 0.0;
-  static long long host[2 * 4096];
-  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, g_clk, sizeof(long long) * 2 * g_clk_n, hipMemcpyDeviceToHost) != hipSuccess) return 0.0;
-  double r[4096]; int n = 0;
-  for (int i = 0; i < g_clk_n; ++i) if (host[2 * i + 1] > 0) r[n++] = (double)host[2 * i] / (double)host[2 * i + 1] * 0.1;
-  if (n == 0) return 0.0;
-  for (int i = 1; i < n; ++i) { double v = r[i]; int j = i - 1; while (j >= 0 && r[j] > v) { r[j + 1] = r[j]; --j; } r[j + 1] = v; }
-  return r[n / 2];
-}
-#endif
 
 // f16x2 spends half the MFMAs per product, so the doubled split work of the transform only pays from 4 channel chunks up
 // (profiles/r02/winograd_kernel_times.txt: 64 -> 64 @ 80x80 103 us against 94 us, 128 -> 128 @ 40x40 90.6 against 93.7)

@@ -124,6 +124,60 @@ __global__ __launch_bounds__(1024) void compress_softmax_bwd_kernel(const float*
   if (threadIdx.x == 0) atomicAdd(db, dbl);
 }
 
+// CompressNet.forward on its own (models/models.py:360-372): logit[p] = w . relu(s[p]) + bias, one thread per pixel (C <= 32: the
+// pixel's channels are 1-2 cache lines); backward: ds = g * w * (s > 0), dw += sum g * relu(s), db += sum g (one workgroup per image).
+__global__ __launch_bounds__(256) void compress_fwd_kernel(const float* __restrict__ s, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, long n, int C) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float v = s[p * C + c];
+    acc += (v < 0.f ? 0.f : v) * w[c];
+  }
+  out[p] = acc + bias[0];
+}
+
+__global__ __launch_bounds__(1024) void compress_bwd_kernel(const float* __restrict__ g, const float* __restrict__ s,
+                                                            const float* __restrict__ w, float* __restrict__ ds,
+                                                            float* __restrict__ dw, float* __restrict__ db, int HW, int C) {
+  __shared__ float red[16];
+  __shared__ float dwacc[32];
+  const int b = blockIdx.x;
+  const float* gb = g + (long)b * HW;
+  const float* sb = s + (long)b * HW * C;
+  float* dsb = ds + (long)b * HW * C;
+  if (threadIdx.x < 32) dwacc[threadIdx.x] = 0.f;
+  float dbl = 0.f;
+  float dwl[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) dwl[c] = 0.f;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const float dl = gb[p];
+    dbl += dl;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      if (c < C) {
+        const float v = sb[(long)p * C + c];
+        dsb[(long)p * C + c] = v > 0.f ? dl * w[c] : 0.f;
+        dwl[c] += dl * (v < 0.f ? 0.f : v);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    if (c < C) {
+      const float v = wave_sum(dwl[c]);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&dwacc[c], v);
+    }
+  }
+  dbl = block_sum<float>(dbl, red);
+  __syncthreads();
+  if (threadIdx.x < C) atomicAdd(&dw[threadIdx.x], dwacc[threadIdx.x]);
+  if (threadIdx.x == 0) atomicAdd(db, dbl);
+}
+
 // ------------------------------------------------------------------------------------------
 // K11: area pool (adaptive average, windows [floor(o*H/h), ceil((o+1)*H/h)) ), one block per (b, oy)
 // ------------------------------------------------------------------------------------------
@@ -809,6 +863,26 @@ int fs_gaze_lowres_fwd(const float* x, const float* focus, float* out, int B, in
                        hipStream_t stream) {
   FS_REQUIRE(x && focus && out && B > 0 && H > 0 && W > 0 && hs > 1 && ws > 1);
   hipLaunchKernelGGL(gaze_lowres_kernel, dim3(cdiv((long)B * hs * ws, 256)), dim3(256), 0, stream, x, focus, out, B, H, W, hs, ws);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_compress_fwd(const float* s, const float* w, const float* bias, float* out, int B, int HW, int C, hipStream_t stream) {
+  FS_REQUIRE(s && w && bias && out && B > 0 && HW > 0 && C > 0 && C <= 32);
+  const long n = (long)B * HW;
+  hipLaunchKernelGGL(compress_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, s, w, bias, out, n, C);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+int fs_compress_bwd(const float* g, const float* s, const float* w, float* ds, float* dw, float* db, int B, int HW, int C,
+                    hipStream_t stream) {
+  FS_REQUIRE(g && s && w && ds && dw && db && B > 0 && HW > 0 && C > 0 && C <= 32);
+  hipError_t e = hipMemsetAsync(dw, 0, C * sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(db, 0, sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(compress_bwd_kernel, dim3(B), dim3(1024), 0, stream, g, s, w, ds, dw, db, HW, C);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

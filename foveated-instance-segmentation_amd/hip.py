@@ -18,6 +18,8 @@ _P, _I, _L, _F, _U = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_floa
 SIGNATURES = {
     "fs_ingest_sample": "ppppiiiiiiiii",
     "fs_gaze_lowres_fwd": "pppiiiii",
+    "fs_compress_fwd": "ppppiii",
+    "fs_compress_bwd": "ppppppiii",
     "fs_compress_softmax_fwd": "ppppiii",
     "fs_compress_softmax_bwd": "pppppppiii",
     "fs_area_pool_fwd": "ppiiiii",
@@ -101,7 +103,7 @@ class HipLibraryError(RuntimeError):
 
 
 def load():
-    """Load the library (building it first if the sources are newer and hipcc is present)."""
+    """Load the library.  Raises if it is missing or was built from other sources than the ones beside it; never builds, never falls back."""
     global _lib
     if _lib is not None:
         return _lib
@@ -109,6 +111,14 @@ def load():
         raise HipLibraryError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU/eager fallback for the fovealseg path.")
+    if not os.environ.get("FS_HIP_LIB"):
+        # a stale binary cannot load: the library carries the content hash of the sources it was built from (build.py)
+        from . import build as _build
+        have, want = _build.built_hash(LIB_PATH), _build.source_hash()
+        if have != want:
+            raise HipLibraryError(
+                f"{LIB_PATH} was built from other sources than the csrc/ beside it (stamp {str(have)[:12]}, sources {want[:12]}): "
+                "run `python -c 'import __graft_entry__ as g; g.build()'`")
     lib = ctypes.CDLL(LIB_PATH)
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch

@@ -190,9 +190,7 @@ class DeformSegmentationModule(nn.Module):
     def forward(self, feed_dict, *, writer=None, segSize=None, F_Xlr_acc_map=False, count=None, epoch=None,
                 feed_dict_info=None, feed_batch_count=None, cur_iter=None, is_inference=False, rank=None):
         self.check_nan()
-        ops.BN_SLABS.clear()
-        ops.FAN_GEOM.clear()
-        ops.PENDING_RES.clear()
+        ops.reset_step_state()
         ops.DDP_ACTIVE = ops.under_torch_ddp(self)      # wrapped by torch DDP: weight gradients go through AccumulateGrad (ops.py)
         if segSize is not None:
             raise NotImplementedError("segSize inference branch (models/models.py:621-631) is not on the default path")

@@ -179,7 +179,8 @@ class CompressNet(nn.Module):
         return ops.CompressSoftmax.apply(s, self.conv_last.weight, self.conv_last.bias)
 
     def forward(self, x):
-        raise NotImplementedError("CompressNet logits are fused with the spatial softmax; use softmax_nhwc()")
+        """(B,24,H,W) logical NCHW -> logits (B,1,H,W), as the reference calls it (models/models.py:713)."""
+        return ops.Compress.apply(to_nhwc(x), self.conv_last.weight, self.conv_last.bias)
 
 
 # ----------------------------------------------------------------------------------------------

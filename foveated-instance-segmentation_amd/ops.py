@@ -444,6 +444,19 @@ _FAN_IDS = [0]
 # materialising the residual gradient; the conv consumer's backward passes it on (conv2d_bwd_data) -- no n-ary add, no dres tensor.
 FAN_GEOM = {}
 PENDING_RES = {}
+FAN_DONE = set()        # fan ids whose conv consumer has run its backward
+
+
+def reset_step_state():
+    """Start of a module forward: drop the per-step records.  A residual gradient still waiting in PENDING_RES was never added to anything
+    -- a silently wrong gradient -- so that is an error, not something to clear."""
+    if PENDING_RES:
+        left = sorted(PENDING_RES)
+        PENDING_RES.clear()
+        raise hip.HipLibraryError(f"residual gradients of fan-outs {left} were stashed for a convolution's bwd-data epilogue that never ran")
+    BN_SLABS.clear()
+    FAN_GEOM.clear()
+    FAN_DONE.clear()
 
 
 def fan_out(x, n):
@@ -559,10 +572,18 @@ class ConvBnAct(Function):
         ctx.fan = getattr(x, "_fs_fan", None)         # x is one of the two aliases of a fan-out: this conv may absorb the other alias's gradient
         if ctx.fan is not None:
             FAN_GEOM[ctx.fan[0]] = (tuple(x.shape), tuple(w.shape), meta["stride"], meta["pad"], dil)
+        if ctx.fan is not None:
+            z._fs_after_fan = ctx.fan[0]              # z is computed FROM the fan-out's conv alias: a layer reading z runs its backward before this one
         rfan = getattr(res, "_fs_fan", None) if res is not None else None
-        ctx.res_fan = (rfan[0], FAN_GEOM.get(rfan[0])) if rfan is not None else None
-        if act_has_bwd(meta["act"], amask):
-            z._fs_bn = (y, amask, mean, invstd, meta["act"])     # for the producer of dz (FanOut.backward): this layer's BN-backward operands
+        # The residual gradient may only be left for the fan-out's conv consumer when that consumer's backward is certain to run AFTER this
+        # layer's: i.e. when this layer's own conv input was produced by it (BasicBlock: conv1 -> bn1 -> relu -> conv2 + x).  A residual
+        # consumer that does not depend on the conv consumer is unordered against it and materialises its gradient as usual.
+        ordered = rfan is not None and getattr(x, "_fs_after_fan", None) == rfan[0]
+        ctx.res_fan = (rfan[0], FAN_GEOM.get(rfan[0])) if ordered else None
+        if act_has_bwd(meta["act"], amask) and meta.get("grad_enabled", True) and any(ctx.needs_input_grad):
+            # for the producer of dz (FanOut.backward / a consumer's bwd-data epilogue): this layer's BN-backward operands.  Only when a
+            # backward will follow: the record keeps the pre-activation conv output alive as long as z lives
+            z._fs_bn = (y, amask, mean, invstd, meta["act"])
         return z
 
     @staticmethod
@@ -583,7 +604,7 @@ class ConvBnAct(Function):
                 fCout, _, fR, fS = wsh
                 fHo, fWo = _out_hw(fH, fW, fR, fS, st, pd, dl)
                 wsb = hip.conv_workspace_bytes(fH, fW, fCin, fHo, fWo, fCout, fR, fS, st, pd, dl, 1)
-                if hip.bwd_data_bnsum_slabs(fB, fH, fW, fCin, fHo, fWo, fCout, fR, fS, st, pd, dl, wsb) > 0:
+                if hip.bwd_data_bnsum_slabs(fB, fH, fW, fCin, fHo, fWo, fCout, fR, fS, st, pd, dl, wsb) > 0 and ctx.res_fan[0] not in FAN_DONE:
                     absorb = ctx.res_fan[0]
         dres = torch.empty_like(y) if (m["has_res"] and absorb is None) else None
         tg, tb = _direct_grad_target(gamma), _direct_grad_target(ctx.beta_ref)
@@ -613,6 +634,8 @@ class ConvBnAct(Function):
         # this conv's own input: the other alias's gradient (if a residual consumer stashed it) joins dx in the epilogue, and then dx is
         # the WHOLE gradient of the fan-out's input, so that tensor's producer record (fan tag) is the one the BatchNorm sums are for
         pend = PENDING_RES.pop(ctx.fan[0], None) if ctx.fan is not None else None
+        if ctx.fan is not None:
+            FAN_DONE.add(ctx.fan[0])          # from here on a residual consumer of this fan-out must materialise its own gradient
         src_bn = ctx.src_bn if ctx.fan is None else (ctx.fan[1] if pend is not None else None)
         if not WGRAD_FIRST:
             dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax, src_bn=src_bn, addend=pend) if ctx.needs_input_grad[0] else None
@@ -919,6 +942,28 @@ class CompressSoftmax(Function):
         db = torch.empty(1, device=s.device, dtype=torch.float32)
         hip.call("fs_compress_softmax_bwd", hip.ptr(g.contiguous()), hip.ptr(xs), hip.ptr(s), hip.ptr(w), hip.ptr(ds), hip.ptr(dw),
                  hip.ptr(db), B, H * W, C)
+        return ds, dw, db
+
+
+class Compress(Function):
+    """CompressNet.forward on its own (models/models.py:360-372): s (B,H,W,C) -> logits (B,1,H,W) = conv1x1(relu(s)) + b."""
+
+    @staticmethod
+    def forward(ctx, s, w, bias):
+        B, H, W, C = s.shape
+        out = torch.empty(B, 1, H, W, device=s.device, dtype=torch.float32)
+        hip.call("fs_compress_fwd", hip.ptr(s), hip.ptr(w), hip.ptr(bias), hip.ptr(out), B, H * W, C)
+        ctx.save_for_backward(s, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s, w = ctx.saved_tensors
+        B, H, W, C = s.shape
+        ds = torch.empty_like(s)
+        dw = torch.empty_like(w)
+        db = torch.empty(1, device=s.device, dtype=torch.float32)
+        hip.call("fs_compress_bwd", hip.ptr(g.contiguous()), hip.ptr(s), hip.ptr(w), hip.ptr(ds), hip.ptr(dw), hip.ptr(db), B, H * W, C)
         return ds, dw, db
 
 
@@ -1229,18 +1274,22 @@ class Attention(Function):
     """softmax(q k^T / sqrt(64)) (dropout p) v per head on the matrix cores; q (B,N,C), k/v (B,Nk,C), C = heads*64, any Nk."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, p, key):
+    def forward(ctx, q, k, v, heads, p, key, grad_enabled=None):
+        # grad_enabled: the grad mode of the CALL SITE (ops.attention records it) -- inside Function.forward grad mode is always off, and
+        # ctx.needs_input_grad mirrors requires_grad of the inputs even under no_grad; None (a direct .apply) = decide on needs_input_grad
+        will_backward = any(ctx.needs_input_grad[:3]) and (grad_enabled is None or grad_enabled)
         B, N, C = q.shape
         Nk = k.shape[1]
         assert C == heads * 64, "head_dim must be 64"
         o = torch.empty_like(q)
         lse = torch.empty(B * heads * N, device=q.device, dtype=torch.float32)
         mask = None
-        if ATTN_SPLIT and hip.get_conv_precision() == "bf16x3":
+        split = ATTN_SPLIT and hip.get_conv_precision() == "bf16x3"
+        if split:
             # the headline arithmetic (24-bit operands as three bf16 planes, fp32 accumulation) on the attention products as well
             nb = hip.attention_split_ws_bytes(B, Nk, heads)
             ws = torch.empty(nb, device=q.device, dtype=torch.uint8)
-            if p > 0 and torch.is_grad_enabled():
+            if p > 0 and will_backward:
                 # one keep bit per (query, key), left by the forward so that the three backward kernels do not hash every element again
                 mask = torch.empty(int(hip.load().fs_attention_mask_words(B, N, Nk, heads)), device=q.device, dtype=torch.int32)
             _launch("attn_fwd", 4.0 * B * heads * N * Nk * 64, "fs_attention_fwd_split", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o),
@@ -1251,6 +1300,7 @@ class Attention(Function):
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.cfg = (heads, float(p), int(key))
         ctx.keep_mask = mask
+        ctx.split = split          # the backward takes the kernel family (and workspace contract) the forward prepared for, whatever the mode is by then
         return o
 
     @staticmethod
@@ -1261,7 +1311,7 @@ class Attention(Function):
         Nk = k.shape[1]
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         scratch = torch.empty(B * heads * N, device=q.device, dtype=torch.float32)
-        if ATTN_SPLIT and hip.get_conv_precision() == "bf16x3":
+        if ctx.split:
             nb = hip.attention_split_ws_bytes(B, Nk, heads, backward=True)
             ws = torch.empty(nb, device=q.device, dtype=torch.uint8)
             mask = ctx.keep_mask
@@ -1271,4 +1321,9 @@ class Attention(Function):
         else:
             _launch("attn_bwd", 14.0 * B * heads * N * Nk * 64, "fs_attention_bwd", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o),
                     hip.ptr(go.contiguous()), hip.ptr(lse), hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), hip.ptr(scratch), B, N, Nk, heads, 0.125, p, key)
-        return dq, dk, dv, None, None, None
+        return dq, dk, dv, None, None, None, None
+
+
+def attention(q, k, v, heads, p, key):
+    """Attention.apply with the call site's grad mode (decides whether the forward leaves the dropout keep words for the backward)."""
+    return Attention.apply(q, k, v, heads, p, key, torch.is_grad_enabled())

@@ -94,7 +94,7 @@ class EfficientSelfAttention(nn.Module):
         v = self.value(kv).view(B, Nk, C)
         p = ATTN_DROPOUT if self.training else 0.0
         key = ops.DropoutState.key(ops.layer_id_from_name(self._path + ".dropout")) if p > 0 else 0
-        return ops.Attention.apply(q, k, v, self.heads, p, key).view(B, h, w, C)
+        return ops.attention(q, k, v, self.heads, p, key).view(B, h, w, C)
 
 
 class SelfOutput(nn.Module):

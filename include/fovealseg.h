@@ -35,6 +35,11 @@ int fs_ingest_sample(const unsigned char* img, const unsigned char* mask, float*
 /* x (B,3,H,W) NCHW, focus (B,2)=(row,col) -> out (B,hs,ws,5): bilinear RGB + 2x squared gaze distance.
  * models/models.py:684-705 (gen_grid_mtx_2xHxW, sqrt/square, b_imresize, 2x cat). */
 int fs_gaze_lowres_fwd(const float* x, const float* focus, float* out, int B, int H, int W, int hs, int ws, fs_stream_t stream);
+/* CompressNet.forward on its own: s (B,HW,C) -> out (B,HW) = w . relu(s) + bias (the logits; C <= 32), and its backward
+ * (ds, dw (C), db (1) overwritten).  models/models.py:360-372 (the plugin contract net_compress((B,24,.,.)) -> (B,1,.,.), call site :713). */
+int fs_compress_fwd(const float* s, const float* w, const float* bias, float* out, int B, int HW, int C, fs_stream_t stream);
+int fs_compress_bwd(const float* g, const float* s, const float* w, float* ds, float* dw, float* db, int B, int HW, int C,
+                    fs_stream_t stream);
 /* s (B,HW,C) -> xs (B,HW) = softmax_HW(w . relu(s) + bias).  models/models.py:369-372,715-723. */
 int fs_compress_softmax_fwd(const float* s, const float* w, const float* bias, float* xs, int B, int HW, int C, fs_stream_t stream);
 int fs_compress_softmax_bwd(const float* g, const float* xs, const float* s, const float* w, float* ds, float* dw, float* db,

@@ -501,6 +501,38 @@ def test_compress_softmax():
     assert abs(float(bd.grad) - float(br.grad)) <= 1e-6      # softmax is shift-invariant: d/db == 0
 
 
+def test_compress_net_forward_returns_logits_like_the_reference():
+    """CompressNet.forward as the reference calls it (models/models.py:713, 360-372): (B,24,H,W) -> (B,1,H,W) logits, forward and
+    every gradient against oracle.OracleCompress with the same weights; and softmax over it == the fused softmax_nhwc path."""
+    g = torch.Generator().manual_seed(11)
+    cfg = fovealseg.lvis50_cfg()
+    comp = fovealseg.ModelBuilder.build_net_compress(cfg)
+    fovealseg.weights.apply_name_keyed_init(comp, "net_compress.")
+    ref = O.OracleCompress(24)
+    ref.load_state_dict({k: v.detach().clone() for k, v in comp.state_dict().items()})
+    comp.to(DEV)
+    for shape in ((3, 24, 80, 80), (2, 24, 37, 53)):
+        x = torch.randn(*shape, generator=g)
+        cot = torch.randn(shape[0], 1, *shape[2:], generator=g)
+        xr = x.clone().requires_grad_(True)
+        ref.zero_grad()
+        out_ref = ref(xr)
+        out_ref.backward(cot)
+        xd = x.to(DEV).requires_grad_(True)
+        comp.zero_grad()
+        out = comp(xd)
+        assert out.shape == out_ref.shape
+        out.backward(cot.to(DEV))
+        assert np.abs(out.detach().cpu().numpy() - out_ref.detach().numpy()).max() <= 2e-6
+        assert relerr(xd.grad.cpu(), xr.grad) <= 1e-6
+        assert relerr(comp.conv_last.weight.grad.cpu(), ref.conv_last.weight.grad) <= 2e-5
+        assert relerr(comp.conv_last.bias.grad.cpu(), ref.conv_last.bias.grad) <= 2e-5
+        with torch.no_grad():
+            fused = comp.softmax_nhwc(nhwc(x))
+            plain = F.softmax(comp(x.to(DEV)).view(shape[0], -1), 1).view_as(fused)
+        assert float((fused - plain).abs().max()) <= 1e-7
+
+
 def test_g3_saliency_stack(golden):
     g = golden("g3_saliency")
     cfg = fovealseg.lvis50_cfg()
@@ -1585,6 +1617,60 @@ def test_attention_keep_words_match_the_hash():
         H.set_conv_precision(H.default_conv_precision())
 
 
+def test_attention_layer_leaves_keep_words_in_training():
+    """inside Function.forward grad mode is always off, so the decision "a backward will follow" must come from the call site.
+    Through the SegFormer layer in train mode the forward must leave the keep words (ctx.keep_mask) and the gradients must equal the ones
+    the hash path gives (mask dropped before the backward); under no_grad / in eval mode no words are allocated."""
+    from fovealseg import segformer as SF
+    H = fovealseg.hip
+    H.set_conv_precision("bf16x3")
+    try:
+        torch.manual_seed(0)
+        layer = SF.EfficientSelfAttention(128, 2, 4).to(DEV)
+        layer._path = "encoder.block.1.0.attention.self"
+        layer.train()
+        x = torch.randn(2, 20, 20, 128, device=DEV)
+        grads = []
+        for drop_mask in (False, True):
+            xd = x.clone().requires_grad_(True)
+            layer.zero_grad()
+            out = layer(xd)
+            node = out.grad_fn
+            while node is not None and type(node).__name__ != "AttentionBackward":
+                node = node.next_functions[0][0]
+            assert node is not None, "the layer's graph holds no Attention node"
+            assert node.keep_mask is not None and node.keep_mask.dtype == torch.int32 and node.split
+            if drop_mask:
+                node.keep_mask = None                       # the backward kernels hash every (query, key) element again
+            out.backward(torch.ones_like(out))
+            grads.append([xd.grad.clone()] + [p_.grad.clone() for p_ in layer.parameters()])
+        assert torch.equal(grads[0][0], grads[1][0]) or relerr(grads[0][0], grads[1][0]) <= 1e-6
+        for a, b_ in zip(grads[0][1:], grads[1][1:]):
+            assert relerr(a, b_) <= 1e-5
+        with torch.no_grad():
+            q, k, v = (torch.randn(2, n, 128, device=DEV).requires_grad_(True) for n in (50, 25, 25))
+        # requires_grad inputs, but grad mode off at the call site: no backward will follow, no words
+        class Spy:
+            words = 0
+        real = H.call
+
+        def spy(name, *args):
+            if name == "fs_attention_fwd_split" and args[5] is not None:
+                Spy.words += 1
+            return real(name, *args)
+        ops.hip.call = spy
+        try:
+            with torch.no_grad():
+                ops.attention(q, k, v, 2, 0.2, 5)
+            assert Spy.words == 0
+            ops.attention(q, k, v, 2, 0.2, 5)
+            assert Spy.words == 1
+        finally:
+            ops.hip.call = real
+    finally:
+        H.set_conv_precision(H.default_conv_precision())
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co,k,stride,pad", [(2, 23, 17, 3, 64, 7, 1, 3), (2, 24, 16, 64, 64, 8, 8, 0), (1, 29, 31, 3, 32, 7, 4, 3),
                                                       (2, 16, 16, 32, 48, 8, 8, 0)])
 def test_big_filter_conv_as_unfolded_linear(B, H, W, Ci, Co, k, stride, pad):
@@ -1990,9 +2076,7 @@ def test_bn_backward_sums_from_the_gradient_producer(C, hw, act_last):
 
     def run(fused):
         ops.FUSE_BN_BWD_SUMS = fused
-        ops.BN_SLABS.clear()
-        ops.FAN_GEOM.clear()
-        ops.PENDING_RES.clear()
+        ops.reset_step_state()
         for b in blocks:
             b.zero_grad()
         x = x0.clone().requires_grad_(True)
@@ -2033,6 +2117,52 @@ def test_bn_backward_sums_from_the_gradient_producer(C, hw, act_last):
     for a, b in zip(g_fused, g_plain):
         scale = float(b.abs().max()) + 1e-30
         assert float((a - b).abs().max()) <= 2e-5 * scale          # same sums, different summation order (and bwd-weight atomics)
+
+
+def test_residual_consumer_independent_of_the_conv_consumer_keeps_its_gradient():
+    """a two-way fan-out whose conv alias feeds an F(2,3)-eligible 3x3 conv and whose other alias is the `res` of a layer that
+    does NOT depend on that conv is unordered in the backward.  The residual layer must then materialise its gradient (never stash it for an
+    epilogue that may already have run): x.grad with the fused routes on == x.grad with them off, in both evaluation orders of the loss."""
+    from fovealseg import modules as M
+    H = fovealseg.hip
+    H.set_conv_precision("bf16x3")
+    try:
+        torch.manual_seed(3)
+        C, hw = 64, 20
+        convA, bnA = M.HipConv2d(C, C, 3, 1, 1).to(DEV), M.HipBatchNorm2d(C).to(DEV)
+        convB, bnB = M.HipConv2d(C, C, 3, 1, 1).to(DEV), M.HipBatchNorm2d(C).to(DEV)
+        x0 = torch.randn(2, hw, hw, C, device=DEV)
+        other = torch.randn(2, hw, hw, C, device=DEV)
+        cot_a, cot_b = torch.randn(2, hw, hw, C, device=DEV), torch.randn(2, hw, hw, C, device=DEV)
+
+        def run(fused, order):
+            ops.FUSE_BN_BWD_SUMS = fused
+            ops.reset_step_state()
+            x = x0.clone().requires_grad_(True)
+            y = other.clone().requires_grad_(True)
+            xa, xr = ops.fan_out(x * 1.0, 2)
+            a = M.conv_bn_act(xa, convA, bnA, ops.ACT_RELU)                    # the fan-out's conv consumer
+            b = M.conv_bn_act(y, convB, bnB, ops.ACT_RELU, res=xr)             # residual consumer, independent of `a`
+            terms = [(a * cot_a).sum(), (b * cot_b).sum()]
+            loss = terms[0] + terms[1] if order == 0 else terms[1] + terms[0]
+            loss.backward()
+            assert not ops.PENDING_RES
+            return x.grad.clone(), y.grad.clone()
+        try:
+            ref = run(False, 0)
+            for order in (0, 1):
+                got = run(True, order)
+                for g_, r_ in zip(got, ref):
+                    assert relerr(g_, r_) <= 2e-5
+        finally:
+            ops.FUSE_BN_BWD_SUMS = True
+        # a stash nobody consumed is an error at the next forward, not something that is cleared silently
+        ops.PENDING_RES[12345] = (x0, None)
+        with pytest.raises(H.HipLibraryError):
+            ops.reset_step_state()
+        assert not ops.PENDING_RES
+    finally:
+        H.set_conv_precision(H.default_conv_precision())
 
 
 @pytest.mark.parametrize("C,hw,act,use_res", [(64, 20, 1, True), (128, 12, 2, False), (96, 10, 0, False), (64, 9, 1, True)])

@@ -510,7 +510,8 @@ def test_training_trajectory_same_in_every_conv_mode():
         fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
     ref = curves["f32"]
     spread = float(((curves["f32_again"] - ref).abs() / ref.abs()).max())
-    bound = 3.0 * max(spread, 1.5e-2)
+    assert spread <= 3e-2, ("two f32 runs of the same 40 steps drifted apart by more than atomics-order noise explains", spread)
+    bound = min(3.0 * max(spread, 1.5e-2), 8e-2)
     for name, c in curves.items():
         assert torch.isfinite(c).all() and float(c[-3:].mean()) < (2.0 / 3.0) * float(c[:3].mean()), (name, c)
         assert abs(float(c[0]) - float(ref[0])) <= 1e-4 * float(ref[0]), (name, float(c[0]), float(ref[0]))      # same forward before any update
