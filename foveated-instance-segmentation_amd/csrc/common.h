@@ -93,3 +93,8 @@ __device__ __forceinline__ T block_sum(T v, T* red) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// out[i] = (accumulate ? out[i] : 0) + part[0][i] + part[1][i] + ... + part[nslab-1][i], in that order (elementwise.hip).  The second stage
+// of every cross-workgroup sum of the library: per-workgroup partials are written with plain stores and added here in index order, so
+// no result depends on the order in which workgroups finish.
+int fs_slab_reduce(const float* part, int nslab, long n, float* out, int accumulate, hipStream_t stream);

@@ -262,6 +262,10 @@ static int g_conv_precision = [] {
   return 1;                                            // bf16x3
 }();
 
+// Deterministic mode (fs_set_deterministic; FS_DETERMINISTIC=1 read once at load): every reduction whose order depends on workgroup
+// arrival -- the split-K atomics of the bwd-weight kernels -- is replaced by per-split partial tiles summed in index order.
+static int g_deterministic = [] { const char* e = getenv("FS_DETERMINISTIC"); return (e && e[0] == '1') ? 1 : 0; }();
+
 template <int MT>
 __global__ __launch_bounds__(256) void conv_igemm_affine_kernel(AffArgs a) {
   constexpr int TM = 128 * MT;                    // workgroup rows
@@ -759,6 +763,7 @@ struct WgradArgs {
   int R, S, stride, pad, dil;
   int pix_per_split;
   int tiles, ntap, nsplit;
+  FsPart part;       // deterministic mode (conv_kernels.h): slab `split` takes this workgroup's tile
 };
 
 template <bool VEC>
@@ -850,7 +855,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (ci < a.Cin) atomicAdd(&a.dw[((long)tap * a.Cin + ci) * a.Cout + co], acc[r]);
+      if (ci < a.Cin) fs_wgrad_out(a.dw, a.part, split, ((long)tap * a.Cin + ci) * a.Cout + co, acc[r]);
     }
   }
 }
@@ -962,7 +967,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_taps_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (ci < a.Cin) atomicAdd(&a.dw[((long)tap * a.Cin + ci) * a.Cout + co], acc[t][r]);
+        if (ci < a.Cin) fs_wgrad_out(a.dw, a.part, split, ((long)tap * a.Cin + ci) * a.Cout + co, acc[t][r]);
       }
     }
   }
@@ -1134,7 +1139,43 @@ int launch_affine(const ConvArgs& c, long M) {
 
 }  // namespace
 
+bool fs_deterministic() { return g_deterministic != 0; }
+
+int fs_wgrad_reduce(const float* part, int nslab, long n, float* dw, int accumulate, hipStream_t stream) {
+  return fs_slab_reduce(part, nslab, n, dw, accumulate, stream);
+}
+
+// slabs one bwd-weight call can need in deterministic mode: an upper bound of the split counts chosen below and in conv_wgrad.hip
+static long wgrad_slab_cap(int Cin, int Cout, int R, int S, int stride, int pad, int dil) {
+  const long tiles = (long)cdiv(Cin, 64) * cdiv(Cout, 64);
+  if (g_conv_precision >= 1 && fs_wgrad_split_eligible(Cin, Cout, R, S, stride, pad, dil)) {
+    if (R == 1 && S == 1 && stride == 1 && pad == 0) return 2048 / tiles + 2;      // linear_wgrad_kernel: up to 1024 workgroups of 64 x 64 tiles, 512 of wider ones
+    return 512 / tiles + 2;                                                      // class kernels: 512 workgroups; transform-domain kernel: 2 x 256
+  }
+  if (R == 3 && S == 3 && Cin % 4 == 0 && Cout % 4 == 0) return 1024 / tiles + 2;
+  return 2048 / (tiles * R * S) + 2;
+}
+
 extern "C" {
+
+// include/fovealseg.h: fs_set_deterministic / fs_get_deterministic (host-side switch, no launch)
+int fs_set_deterministic(int on) {
+  g_deterministic = on ? 1 : 0;
+  return FS_OK;
+}
+int fs_get_deterministic(void) { return g_deterministic; }
+
+// include/fovealseg.h: scratch fs_conv2d_bwd_weight needs for this layer (0 unless deterministic mode is on)
+long fs_conv2d_bwd_weight_ws_bytes(int Cin, int Cout, int R, int S, int stride, int pad, int dil) {
+  if (!g_deterministic || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0) return 0;
+  return wgrad_slab_cap(Cin, Cout, R, S, stride, pad, dil) * (long)R * S * Cin * Cout * 4;
+}
+// include/fovealseg.h: scratch of fs_linear_bwd_weight_bias (dW slabs, then 4 bias slabs per dW slab)
+long fs_linear_bwd_weight_bias_ws_bytes(int Cin, int Cout) {
+  if (!g_deterministic || Cin <= 0 || Cout <= 0) return 0;
+  const long cap = wgrad_slab_cap(Cin, Cout, 1, 1, 1, 0, 1);
+  return cap * ((long)Cin * Cout + 4L * Cout) * 4;
+}
 
 // include/fovealseg.h: fs_set_conv_precision / fs_get_conv_precision (host-side switch, no launch)
 int fs_set_conv_precision(int mode) {
@@ -1337,9 +1378,23 @@ int fs_linear_bwd_weight_bias_ok(long rows, int Cin, int Cout) { return fs_linea
 
 // include/fovealseg.h: fs_linear_bwd_weight_bias -- dW[Cin][Cout] = x^T dy and dbias[Cout] = column sums of dy in one launch
 int fs_linear_bwd_weight_bias(const float* x, const float* dy, float* dw, float* dbias, long rows, int Cin, int Cout, int accumulate_w,
-                              int accumulate_b, hipStream_t stream) {
+                              int accumulate_b, void* ws, long ws_bytes, hipStream_t stream) {
   FS_REQUIRE(x && dy && dw && dbias);
   FS_REQUIRE(fs_linear_bwd_weight_bias_ok(rows, Cin, Cout) == 1);
+  if (g_deterministic) {
+    // ordered split-K: partial dW tiles and partial bias sums in per-split slabs, summed in index order
+    const long n = (long)Cin * Cout, cap = wgrad_slab_cap(Cin, Cout, 1, 1, 1, 0, 1);
+    FS_REQUIRE(ws != nullptr && ws_bytes >= fs_linear_bwd_weight_bias_ws_bytes(Cin, Cout));
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)cap * (n + 4L * Cout) * 4, stream);
+    if (e != hipSuccess) return (int)e;
+    FsPartHost ph{static_cast<float*>(ws), n, cap, 0};
+    float* bpart = static_cast<float*>(ws) + cap * n;
+    const int r = fs_linear_wgrad(x, dy, dw, dbias, rows, Cin, Cout, &ph, bpart, stream);
+    if (r != FS_OK) return r;
+    const int r2 = fs_wgrad_reduce(ph.base, ph.used, n, dw, accumulate_w, stream);
+    if (r2 != FS_OK) return r2;
+    return fs_wgrad_reduce(bpart, 4 * ph.used, Cout, dbias, accumulate_b, stream);
+  }
   if (!accumulate_w) {
     const hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cin * Cout, stream);
     if (e != hipSuccess) return (int)e;
@@ -1348,21 +1403,50 @@ int fs_linear_bwd_weight_bias(const float* x, const float* dy, float* dw, float*
     const hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cout, stream);
     if (e != hipSuccess) return (int)e;
   }
-  return fs_linear_wgrad(x, dy, dw, dbias, rows, Cin, Cout, stream);
+  return fs_linear_wgrad(x, dy, dw, dbias, rows, Cin, Cout, nullptr, nullptr, stream);
 }
 
+static int conv2d_bwd_weight_impl(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo,
+                                  int Cout, int R, int S, int stride, int pad, int dil, FsPartHost* ph, hipStream_t stream);
+
 int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo,
-                         int Cout, int R, int S, int stride, int pad, int dil, int accumulate, hipStream_t stream) {
+                         int Cout, int R, int S, int stride, int pad, int dil, int accumulate, void* ws, long ws_bytes, hipStream_t stream) {
   FS_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0);
   FS_REQUIRE(dil >= 1 && Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
+  if (g_deterministic) {
+    // ordered split-K: every split's partial tile goes to its own slab of ws (zeroed: a split without pixels writes nothing), the slabs
+    // are summed in index order -- and dw itself is only touched by that sum, so no memset of it
+    const long n = (long)R * S * Cin * Cout, cap = wgrad_slab_cap(Cin, Cout, R, S, stride, pad, dil);
+    FS_REQUIRE(ws != nullptr && ws_bytes >= cap * n * 4);
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)cap * n * 4, stream);
+    if (e != hipSuccess) return (int)e;
+    FsPartHost ph{static_cast<float*>(ws), n, cap, 0};
+    const int r = conv2d_bwd_weight_impl(x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, &ph, stream);
+    if (r != FS_OK) return r;
+    return fs_wgrad_reduce(ph.base, ph.used, n, dw, accumulate, stream);
+  }
   if (!accumulate) {         // every kernel below adds its split-K partials atomically: dw = 0 first, unless the caller accumulates
     hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)R * S * Cin * Cout, stream);
     if (e != hipSuccess) return (int)e;
   }
+  return conv2d_bwd_weight_impl(x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, nullptr, stream);
+}
+
+static int part_of(FsPartHost* ph, long nslab, FsPart& out) {
+  out = FsPart{nullptr, 0};
+  if (ph == nullptr || ph->base == nullptr) return FS_OK;
+  if (nslab > ph->cap) return FS_ERR_ARG;
+  if (nslab > ph->used) ph->used = (int)nslab;
+  out = FsPart{ph->base, ph->stride};
+  return FS_OK;
+}
+
+static int conv2d_bwd_weight_impl(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo,
+                                  int Cout, int R, int S, int stride, int pad, int dil, FsPartHost* ph, hipStream_t stream) {
   const long P = (long)B * Ho * Wo;
   if (g_conv_precision >= 1 && fs_wgrad_split_eligible(Cin, Cout, R, S, stride, pad, dil) &&
       (size_t)B * H * W * Cin * 4 < 4294967000UL && (size_t)P * Cout * 4 < 4294967000UL)
-    return fs_wgrad_split(g_conv_precision, x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, stream);
+    return fs_wgrad_split(g_conv_precision, x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, ph, stream);
   const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);
   // one filter row per workgroup for narrow layers (more workgroups, fewer atomics each), the whole 3x3
   // filter per workgroup once there are >= 9 channel tiles (measured: 64^2/128^2 87-90 TF with 3,
@@ -1378,7 +1462,8 @@ int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
     long pp = (P + ns - 1) / ns;
     pp = ((pp + BK - 1) / BK) * BK;
     ns = (P + pp - 1) / pp;
-    WgradArgs a{x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, (int)pp, tiles, 9, (int)ns};
+    WgradArgs a{x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, (int)pp, tiles, 9, (int)ns, FsPart{nullptr, 0}};
+    if (part_of(ph, ns, a.part) != FS_OK) return FS_ERR_ARG;
     dim3 grid((unsigned)(tiles * ng * ns));
     if (wg_mode == 3) hipLaunchKernelGGL(conv_wgrad_taps_kernel<3>, grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(conv_wgrad_taps_kernel<9>, grid, dim3(256), 0, stream, a);
@@ -1392,7 +1477,8 @@ int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
   long pps = (P + nsplit - 1) / nsplit;
   pps = ((pps + BK - 1) / BK) * BK;
   nsplit = (P + pps - 1) / pps;
-  WgradArgs a{x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, (int)pps, tiles, R * S, (int)nsplit};
+  WgradArgs a{x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, (int)pps, tiles, R * S, (int)nsplit, FsPart{nullptr, 0}};
+  if (part_of(ph, nsplit, a.part) != FS_OK) return FS_ERR_ARG;
   dim3 grid((unsigned)(tiles * R * S * nsplit));
   if ((Cin % 4 == 0) && (Cout % 4 == 0))
     hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, stream, a);

@@ -44,13 +44,31 @@ int fs_pointwise_conv(int mode, const float* src, const float* w, const float* b
                       long M, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,
                       hipStream_t stream);
 
+// ---- deterministic split-K (include/fovealseg.h fs_set_deterministic) ----------------------------------------------------------
+// Every bwd-weight kernel ends by adding its workgroup's partial dW tile to the tiles of the other pixel splits.  By default that is an
+// fp32 atomic per element (order = arrival order: results differ in the last bits from run to run).  In deterministic mode each split
+// writes its partial tile with plain stores into ITS OWN slab (a full dW image) of the caller's workspace and fs_wgrad_reduce sums the
+// slabs in index order.  base == nullptr selects the atomics.
+struct FsPart { float* base; long stride; };
+__device__ __forceinline__ void fs_wgrad_out(float* dw, const FsPart p, int slab, long idx, float v) {
+  if (p.base != nullptr) p.base[(long)slab * p.stride + idx] = v;
+  else atomicAdd(dw + idx, v);
+}
+bool fs_deterministic();
+// dw[i] = (accumulate ? dw[i] : 0) + part[0][i] + part[1][i] + ... + part[nslab-1][i], in that order
+int fs_wgrad_reduce(const float* part, int nslab, long n, float* dw, int accumulate, hipStream_t stream);
+// host-side bookkeeping of one bwd-weight call in deterministic mode: slabs available / slabs the launches used
+struct FsPartHost { float* base; long stride; long cap; int used; };
+
 // ---- conv_wgrad.hip: split-precision weight gradient, one launch per tap class (dw zeroed by the caller or accumulated into) ----
 // any square filter / stride whose tap classes have at most 2 taps per dimension (3x3 s2/s4, 1x1 any stride), plus 3x3 s1
 bool fs_wgrad_split_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil);
 bool fs_linear_wgrad_eligible(int mode, long rows, int Cin, int Cout);
-int fs_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, long rows, int Cin, int Cout, hipStream_t stream);
+// part (nullable): deterministic mode.  fs_linear_wgrad: bpart (nullable) = slabs of Cout floats for the bias column sums, 4 per split.
+int fs_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, long rows, int Cin, int Cout, FsPartHost* part, float* bpart,
+                    hipStream_t stream);
 int fs_wgrad_split(int mode, const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S,
-                   int stride, int pad, hipStream_t stream);
+                   int stride, int pad, FsPartHost* part, hipStream_t stream);
 
 // conv_tapset.hip: general halo-tiled split-precision convolution over a list of tap classes.
 //   source row of (loop row oy, class tap tr) = sm*(oy + tr) + cy,  filter row r = rbase + rstep*tr  (columns alike)

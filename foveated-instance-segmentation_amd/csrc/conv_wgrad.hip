@@ -46,6 +46,7 @@ struct WgArgs {
   int tiles_ci, tiles_co;
   unsigned x_bytes, dy_bytes;
   unsigned magic_wh, magic_pw;      // 2^32 / (Pw + NS - 1) + 1, 2^32 / Pw + 1: slot / pixel index -> (row, column) without integer division
+  FsPart part;                      // deterministic mode: slab `split` takes this workgroup's tile (conv_kernels.h)
 };
 
 // 256 threads, two workgroups per CU.  (Measured and rejected, profiles/r02/wgrad_groups_*.txt: a 512-thread workgroup of two patch
@@ -251,7 +252,240 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const float v = acc[tap][r] * fo1 * fo2;
-        if (ci < a.Cin) atomicAdd(&a.dw[(ftap * a.Cin + ci) * a.Cout + co], v);
+        if (ci < a.Cin) fs_wgrad_out(a.dw, a.part, split, (ftap * a.Cin + ci) * a.Cout + co, v);
+      }
+    }
+  }
+}
+
+// ---- 3x3 filters with stride 2 or 3: all nine taps in ONE launch (round 4) -----------------------------------------------------------
+// One launch per tap class (above) loads and splits the same dY patch once per class -- four times for a 3x3 stride-2 layer -- and its
+// 1- and 2-tap classes run 24 / 48 MFMAs per wave between two barriers (SQ counters, profiles/r04/pmc: matrix pipe 13 % busy, 21 VALU
+// instructions per MFMA on the single-tap class).  Here a workgroup keeps nine accumulators like the stride-1 kernel and the X halo of
+// its dY patch lives in LDS as PARITY PLANES: tap (r, s) reads source pixel (st*py + r, st*px + s) relative to the halo origin, i.e.
+// plane (r mod st, s mod st) at in-plane position (py + r div st, px + s div st) -- dense in (py, px), so the transposed fragment reads
+// are the conflict-free ones of the class kernel, at a per-tap constant offset.  Every X pixel and every dY pixel is loaded and split
+// once.  Patch = Ph x Pw <= 32 dY pixels (two k-steps), <= 160 halo slots over all planes: 73.7 KB of LDS in bf16x3, two per CU.
+constexpr int MP_XS = 160;                 // X slots over all planes
+constexpr int MP_YP = 32;                  // dY pixels per patch
+constexpr int MP_XH = MP_XS * 64, MP_XPL = 2 * MP_XH;
+constexpr int MP_YH = MP_YP * 64, MP_YPL = 2 * MP_YH;
+constexpr int MP_NXI = MP_XS * 16 / 256;   // 10 float4 loads per thread for the X halo
+constexpr int MP_NYI = MP_YP * 16 / 256;   // 2 for the dY patch
+struct MpArgs {
+  const float* x; const float* dy; float* dw;
+  int B, H, W, Hx, Wx, Cin, Cout;          // dY (B,H,W,Cout), X (B,Hx,Wx,Cin)
+  int st, pad;
+  int Ph, Pw, tiles_y, tiles_x, npatch, patches_per_split, tiles_ci, tiles_co;
+  int nplanes, nslots;
+  int pl_base[9], pl_wcol[9], pl_pr[9], pl_pc[9];      // plane: first slot, row width, residue of its source rows / columns
+  unsigned pl_magic[9];                                // div_small1 magic of the row width
+  int tap_off[9];                                      // LDS byte offset of tap (r, s): (base + (r div st) * wcol + s div st) * 64
+  int tap_w[9];                                        // 1: the tap's plane has row width Pw + 1, 0: Pw
+  unsigned x_bytes, dy_bytes, magic_pw;
+  FsPart part;
+};
+
+template <class P>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_planes_kernel(MpArgs a) {
+  typedef typename P::x8 X8;
+  typedef typename P::x4 X4;
+  constexpr int NT = 9, NPL = P::NPL;
+  constexpr int LDS_BYTES = NPL * (MP_XPL + MP_YPL);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  __shared__ unsigned amax_cell[2][2];      // [patch parity][X, dY]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int gx = 0, gy = NPL * MP_XPL;
+  unsigned char* const Xl = lds;
+  unsigned char* const Yl = lds;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntile = a.tiles_ci * a.tiles_co;
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd = nwg >> 3, rmd = nwg & 7;
+  const int wg = (xcd < rmd ? xcd * (qd + 1) : rmd * (qd + 1) + (xcd - rmd) * qd) + loc;
+  const int split = wg / ntile, tile = wg - split * ntile;
+  const int tci = tile / a.tiles_co, tco = tile - tci * a.tiles_co;
+  const int ci0 = tci * 64, co0 = tco * 64;
+  const int p_begin = split * a.patches_per_split;
+  const int p_end = (p_begin + a.patches_per_split < a.npatch) ? p_begin + a.patches_per_split : a.npatch;
+  const int npix = a.Ph * a.Pw, nk = (npix + 15) >> 4;
+  const int tpi = a.tiles_y * a.tiles_x;
+
+  // ---- loader constants: item i of a thread = (slot (tid >> 4) + 16 i, channel quad cq); the slot's plane by a compare chain over the
+  // (wave-uniform) plane table, once per kernel ----
+  const int cq = tid & 15;
+  int xcode[MP_NXI], xdelta[MP_NXI];     // (source row << 16 | source column) relative to the halo origin, -1 = unused; byte offset
+#pragma unroll
+  for (int i = 0; i < MP_NXI; ++i) {
+    const int slot = (tid >> 4) + 16 * i;
+    int base = 0, wc = a.pl_wcol[0], pr = a.pl_pr[0], pc = a.pl_pc[0];
+    unsigned mg = a.pl_magic[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k)
+      if (k < a.nplanes && slot >= a.pl_base[k]) { base = a.pl_base[k]; wc = a.pl_wcol[k]; pr = a.pl_pr[k]; pc = a.pl_pc[k]; mg = a.pl_magic[k]; }
+    const int local = slot - base;
+    const int hy = div_small1(local, mg), hx = local - hy * wc;
+    const int ry = a.st * hy + pr, rx = a.st * hx + pc;
+    xcode[i] = (slot < a.nslots && ci0 + 4 * cq < a.Cin) ? ((ry << 16) | rx) : -1;
+    xdelta[i] = ((ry * a.Wx + rx) * a.Cin + ci0 + 4 * cq) * 4;
+  }
+  int ycode[MP_NYI], ydelta[MP_NYI];
+#pragma unroll
+  for (int i = 0; i < MP_NYI; ++i) {
+    const int p = (tid >> 4) + 16 * i;
+    const int py = div_small1(p, a.magic_pw), px = p - py * a.Pw;
+    ycode[i] = (p < npix && co0 + 4 * cq < a.Cout) ? ((py << 16) | px) : -1;
+    ydelta[i] = ((py * a.W + px) * a.Cout + co0 + 4 * cq) * 4;
+  }
+  const int xw = gx + (cq >> 3) * MP_XH + (tid >> 4) * 64 + (cq & 7) * 8;     // + i*1024 + plane*MP_XPL
+  const int yw = gy + (cq >> 3) * MP_YH + (tid >> 4) * 64 + (cq & 7) * 8;     // + i*1024 + plane*MP_YPL
+  const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.x, a.x_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(a.dy, a.dy_bytes);
+
+  // ---- transposed-read lane constants (class kernel): 16-lane group g reads k rows q = 0..3, columns cb + 4pp .. +3 ----
+  const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, g = lane >> 4, lh = g >> 1, cb = 16 * (g & 1);
+  int xb[2][2][2];                 // [row width Pw / Pw + 1][k-step][half]: byte offset of the lane's patch pixel in a plane of that width
+#pragma unroll
+  for (int w = 0; w < 2; ++w)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        int pidx = 16 * ks + 8 * lh + 4 * t + q;
+        if (pidx >= npix) pidx = 0;             // padded k: dY is zero there, any valid X address will do
+        const int py = div_small1(pidx, a.magic_pw), px = pidx - py * a.Pw;
+        xb[w][ks][t] = gx + wm * MP_XH + (py * (a.Pw + w) + px) * 64 + (cb + 4 * pp) * 2;
+      }
+  const int yb = gy + wn * MP_YH + (8 * lh + q) * 64 + (cb + 4 * pp) * 2;      // + ks*1024 + t*256 + plane*MP_YPL
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  auto tr = [&](const unsigned char* base, int off) -> X4 { return P::tr_read(base + off); };
+  auto cat = [](X4 lo, X4 hi) -> X8 { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); };
+  if (tid < 4) amax_cell[tid >> 1][tid & 1] = 0u;
+  __syncthreads();
+  int E = 2 * EMIN - 1, par = 0;
+
+  const int niter = p_end - p_begin;
+  int pb_, pty, ptx;
+  {
+    pb_ = p_begin / tpi;
+    const int trem = p_begin - pb_ * tpi;
+    pty = trem / a.tiles_x; ptx = trem - pty * a.tiles_x;
+  }
+  for (int it = 0; it < niter; ++it) {
+    const int b = pb_, ty = pty, tx = ptx;
+    const int y0 = ty * a.Ph, x0 = tx * a.Pw;
+    if (++ptx >= a.tiles_x) { ptx = 0; if (++pty >= a.tiles_y) { pty = 0; ++pb_; } }
+
+    f32x4 rx[MP_NXI], ry[MP_NYI];
+    const int iy0 = a.st * y0 - a.pad, ix0 = a.st * x0 - a.pad;                    // source pixel of the halo origin
+    const int xbase = ((b * a.Hx + iy0) * a.Wx + ix0) * a.Cin * 4;                  // may be negative (padding); base + delta is not, where valid
+    const int ybase = ((b * a.H + y0) * a.W + x0) * a.Cout * 4;
+#pragma unroll
+    for (int i = 0; i < MP_NXI; ++i) {
+      const int iy = iy0 + (xcode[i] >> 16), ix = ix0 + (xcode[i] & 0xffff);
+      const bool ok = xcode[i] >= 0 && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx;
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? xbase + xdelta[i] : (int)OOB, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < MP_NYI; ++i) {
+      const int y = y0 + (ycode[i] >> 16), x = x0 + (ycode[i] & 0xffff);
+      const bool ok = ycode[i] >= 0 && y < a.H && x < a.W;
+      ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, ok ? ybase + ydelta[i] : (int)OOB, 0, 0));
+    }
+    float sx = 1.f, sy = 1.f;
+    if (P::SCALED) {   // tile maxima -> LDS cells of this patch's parity (running exponents as in the class kernel)
+      float mx = 0.f, my = 0.f;
+#pragma unroll
+      for (int i = 0; i < MP_NXI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fabsf(rx[i][e]));
+#pragma unroll
+      for (int i = 0; i < MP_NYI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) my = fmaxf(my, fabsf(ry[i][e]));
+      mx = wave_max(mx); my = wave_max(my);
+      if (lane == 0) { atomicMax(&amax_cell[par][0], __builtin_bit_cast(unsigned, mx)); atomicMax(&amax_cell[par][1], __builtin_bit_cast(unsigned, my)); }
+    }
+    __syncthreads();     // maxima complete; every wave has finished reading the previous patch
+    if (P::SCALED) {
+      const int ex = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[par][0]));
+      const int ey = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[par][1]));
+      if (ex + ey > E) {
+        const float f = pow2f(E - ex - ey);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] *= f;
+        E = ex + ey;
+      }
+      sx = pow2f(14 - (E - ey)); sy = pow2f(14 - ey);
+      par ^= 1;
+      if (tid < 2) amax_cell[par][tid] = 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < MP_NXI; ++i) {
+      X4 p[NPL];
+      P::split4(P::SCALED ? rx[i] * sx : rx[i], p);
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Xl[xw + i * 1024 + pl * MP_XPL]) = p[pl];
+    }
+#pragma unroll
+    for (int i = 0; i < MP_NYI; ++i) {
+      X4 p[NPL];
+      P::split4(P::SCALED ? ry[i] * sy : ry[i], p);
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Yl[yw + i * 1024 + pl * MP_YPL]) = p[pl];
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks < nk) {
+        X8 fb[NPL], fa[2][NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) fb[pl] = cat(tr(Yl, yb + ks * 1024 + pl * MP_YPL), tr(Yl, yb + ks * 1024 + 256 + pl * MP_YPL));
+        {
+          const int o0 = (a.tap_w[0] ? xb[1][ks][0] : xb[0][ks][0]) + a.tap_off[0], o1 = (a.tap_w[0] ? xb[1][ks][1] : xb[0][ks][1]) + a.tap_off[0];
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) fa[0][pl] = cat(tr(Xl, o0 + pl * MP_XPL), tr(Xl, o1 + pl * MP_XPL));
+        }
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap) {
+          if (tap + 1 < NT) {
+            const int tn = tap + 1;
+            const int o0 = (a.tap_w[tn] ? xb[1][ks][0] : xb[0][ks][0]) + a.tap_off[tn], o1 = (a.tap_w[tn] ? xb[1][ks][1] : xb[0][ks][1]) + a.tap_off[tn];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) fa[tn & 1][pl] = cat(tr(Xl, o0 + pl * MP_XPL), tr(Xl, o1 + pl * MP_XPL));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const X8(&A)[NPL] = fa[tap & 1];
+#pragma unroll
+          for (int t = 0; t < P::NTERM; ++t) acc[tap] = P::mfma(A[P::ta(t)], fb[P::tb(t)], acc[tap]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+
+  const int co = co0 + 32 * wn + (lane & 31);
+  const int Eo = E - 28;
+  const float fo1 = P::SCALED ? pow2f(Eo / 2) : 1.f, fo2 = P::SCALED ? pow2f(Eo - Eo / 2) : 1.f;
+  if (co < a.Cout && p_begin < p_end) {
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float v = acc[tap][r] * fo1 * fo2;
+        if (ci < a.Cin) fs_wgrad_out(a.dw, a.part, split, ((long)tap * a.Cin + ci) * a.Cout + co, v);
       }
     }
   }
@@ -277,6 +511,7 @@ struct WwArgs {
   int B, H, W, Cin, Cout;
   int Ph, PP, tiles_y, tiles_x, npatch, patches_per_split, tiles_ci, tiles_co;
   unsigned x_bytes, dy_bytes, magic_pp;
+  FsPart part;                      // deterministic mode: slab 2 * split + cp (the two component-pair waves add to the same elements)
 };
 
 template <class P>
@@ -460,10 +695,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino_kernel(WwArgs a) {
         const float w0 = cp == 0 ? u0 + h : h;
         const float w1 = cp == 0 ? h : -h;
         const float w2 = cp == 0 ? h : h + u1;
-        float* d = a.dw + ((long)(ky * 3) * a.Cin + ci) * a.Cout + co;
-        atomicAdd(d, w0);
-        atomicAdd(d + (long)a.Cin * a.Cout, w1);
-        atomicAdd(d + 2L * a.Cin * a.Cout, w2);
+        const long d = ((long)(ky * 3) * a.Cin + ci) * a.Cout + co;
+        fs_wgrad_out(a.dw, a.part, 2 * split + cp, d, w0);
+        fs_wgrad_out(a.dw, a.part, 2 * split + cp, d + (long)a.Cin * a.Cout, w1);
+        fs_wgrad_out(a.dw, a.part, 2 * split + cp, d + 2L * a.Cin * a.Cout, w2);
       }
   }
 }
@@ -482,6 +717,8 @@ struct LwArgs {
   float* dbias;       // nullable: [Cout] column sums of dy (the layer's bias gradient), zero-initialised or accumulated into
   int rows, Cin, Cout, tiles_ci, tiles_co, rows_per_split;
   unsigned x_bytes, dy_bytes;
+  FsPart part;        // deterministic mode: slab `split` of dW images
+  float* bpart;       // deterministic mode, with dbias: slab 4 * split + wave of Cout floats (the four waves hold different rows)
 };
 
 template <class P, int WM, int WN, int MI, int NI>
@@ -612,7 +849,10 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(LwArgs a) {
       for (int e = 0; e < 4; ++e) {
         float v = bs[i][e];
         v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-        if (lane < 8 && yoff[i] >= 0) atomicAdd(&a.dbias[co0 + 32 * i + 4 * quad + e], v);
+        if (lane < 8 && yoff[i] >= 0) {
+          if (a.bpart != nullptr) a.bpart[(long)(4 * split + wave) * a.Cout + co0 + 32 * i + 4 * quad + e] = v;
+          else atomicAdd(&a.dbias[co0 + 32 * i + 4 * quad + e], v);
+        }
       }
   }
 #pragma unroll
@@ -624,19 +864,31 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(LwArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (ci < a.Cin) atomicAdd(&a.dw[(long)ci * a.Cout + co], acc[mi][ni][r]);
+        if (ci < a.Cin) fs_wgrad_out(a.dw, a.part, split, (long)ci * a.Cout + co, acc[mi][ni][r]);
       }
     }
 }
 
+// deterministic mode: the launch's slabs must fit the caller's workspace; note how many it used
+static int part_claim(FsPartHost* ph, int nslab, FsPart& out) {
+  out.base = nullptr; out.stride = 0;
+  if (ph == nullptr || ph->base == nullptr) return FS_OK;
+  if (nslab > ph->cap) return FS_ERR_ARG;
+  if (nslab > ph->used) ph->used = nslab;
+  out.base = ph->base; out.stride = ph->stride;
+  return FS_OK;
+}
+
 template <class P, int WM, int WN, int MI, int NI>
-int launch_linear_wgrad(LwArgs a, int target, hipStream_t stream) {
+int launch_linear_wgrad(LwArgs a, int target, FsPartHost* ph, hipStream_t stream) {
   a.tiles_ci = cdiv(a.Cin, WM * MI * 32); a.tiles_co = cdiv(a.Cout, WN * NI * 32);
   const int ntile = a.tiles_ci * a.tiles_co;
   int nsplit = target / ntile;
   if (nsplit < 1) nsplit = 1;
   a.rows_per_split = cdiv(cdiv(a.rows, nsplit), 32) * 32;
   nsplit = cdiv(a.rows, a.rows_per_split);
+  if (part_claim(ph, nsplit, a.part) != FS_OK) return FS_ERR_ARG;
+  if (a.part.base == nullptr) a.bpart = nullptr;
   hipLaunchKernelGGL((linear_wgrad_kernel<P, WM, WN, MI, NI>), dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;
@@ -645,7 +897,7 @@ int launch_linear_wgrad(LwArgs a, int target, hipStream_t stream) {
 // Tile and split choice, from a sweep over the SegFormer-B5 and HRNet 1x1 layers (profiles/r03/linear_wgrad_sweep.txt): narrow operands
 // take a 64-wide tile on their side; wide layers take 128 x 128 over 512 workgroups while a split still sees >= 512 rows (the row loop
 // dominates), otherwise 64 x 64 over 1024 (a quarter of the atomics per workgroup: the epilogue dominates).
-int run_linear_wgrad(LwArgs l, hipStream_t stream) {
+int run_linear_wgrad(LwArgs l, FsPartHost* ph, hipStream_t stream) {
   static const int force = FS_ENV_INT("FS_LW_TILE", 0);       // kernel A/B builds only (common.h), read once
   static const int force_wgs = FS_ENV_INT("FS_LW_WGS", 0);
   int tile, target = 512;
@@ -661,10 +913,10 @@ int run_linear_wgrad(LwArgs l, hipStream_t stream) {
   if (force >= 1 && force <= 4) tile = force;
   if (force_wgs > 0) target = force_wgs;
   switch (tile) {
-    case 1: return launch_linear_wgrad<PrecX3, 2, 2, 1, 1>(l, target, stream);      //  64 x  64
-    case 2: return launch_linear_wgrad<PrecX3, 1, 4, 2, 1>(l, target, stream);      //  64 x 128
-    case 3: return launch_linear_wgrad<PrecX3, 4, 1, 1, 2>(l, target, stream);      // 128 x  64
-    default: return launch_linear_wgrad<PrecX3, 2, 2, 2, 2>(l, target, stream);     // 128 x 128
+    case 1: return launch_linear_wgrad<PrecX3, 2, 2, 1, 1>(l, target, ph, stream);      //  64 x  64
+    case 2: return launch_linear_wgrad<PrecX3, 1, 4, 2, 1>(l, target, ph, stream);      //  64 x 128
+    case 3: return launch_linear_wgrad<PrecX3, 4, 1, 1, 2>(l, target, ph, stream);      // 128 x  64
+    default: return launch_linear_wgrad<PrecX3, 2, 2, 2, 2>(l, target, ph, stream);     // 128 x 128
   }
 }
 
@@ -701,7 +953,7 @@ void choose_wgrad_patch(int H, int W, int NR, int NS, int& Ph, int& Pw) {
 
 namespace {
 template <class P, int NR, int NS>
-int launch_class(WgArgs a, int ntile, hipStream_t stream) {
+int launch_class(WgArgs a, int ntile, FsPartHost* ph, hipStream_t stream) {
   choose_wgrad_patch(a.H, a.W, NR, NS, a.Ph, a.Pw);
   a.tiles_y = cdiv(a.H, a.Ph); a.tiles_x = cdiv(a.W, a.Pw);
   a.magic_wh = div_magic1(a.Pw + NS - 1); a.magic_pw = div_magic1(a.Pw);
@@ -714,23 +966,85 @@ int launch_class(WgArgs a, int ntile, hipStream_t stream) {
   if (nsplit > a.npatch) nsplit = a.npatch;
   a.patches_per_split = cdiv(a.npatch, nsplit);
   nsplit = cdiv(a.npatch, a.patches_per_split);
+  if (part_claim(ph, nsplit, a.part) != FS_OK) return FS_ERR_ARG;
   hipLaunchKernelGGL((conv_wgrad_class_kernel<P, NR, NS>), dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
 
+// Plane table of a 3x3 filter with stride st (2 or 3) for a Ph x Pw patch; returns the slot count
+static int planes_plan(MpArgs& a) {
+  const int st = a.st, nres = st < 3 ? st : 3;
+  int n = 0, base = 0;
+  int idx[3][3];
+  for (int pr = 0; pr < nres; ++pr)
+    for (int pc = 0; pc < nres; ++pc) {
+      const int extra_r = (2 - pr) / st, extra_c = (2 - pc) / st;      // largest (r div st) over taps r = pr, pr + st, ... <= 2
+      a.pl_base[n] = base; a.pl_wcol[n] = a.Pw + extra_c; a.pl_pr[n] = pr; a.pl_pc[n] = pc; a.pl_magic[n] = div_magic1(a.Pw + extra_c);
+      base += (a.Ph + extra_r) * (a.Pw + extra_c);
+      idx[pr][pc] = n++;
+    }
+  for (int k = n; k < 9; ++k) { a.pl_base[k] = 1 << 30; a.pl_wcol[k] = 1; a.pl_pr[k] = 0; a.pl_pc[k] = 0; a.pl_magic[k] = 0u; }
+  a.nplanes = n; a.nslots = base;
+  for (int r = 0; r < 3; ++r)
+    for (int s2 = 0; s2 < 3; ++s2) {
+      const int p = idx[r % st][s2 % st];
+      a.tap_off[r * 3 + s2] = (a.pl_base[p] + (r / st) * a.pl_wcol[p] + s2 / st) * 64;
+      a.tap_w[r * 3 + s2] = a.pl_wcol[p] == a.Pw + 1 ? 1 : 0;
+    }
+  return base;
+}
+
+// Ph x Pw <= 32 dY pixels, all planes together <= 160 slots: fewest patches x (k-steps + 1.5), as choose_wgrad_patch
+static bool choose_planes_patch(MpArgs& a) {
+  long best = -1;
+  int bh = 0, bw = 0;
+  for (int pw = 2; pw <= MP_YP && pw <= a.W + 1; ++pw)
+    for (int ph = 1; ph <= MP_YP && ph <= a.H + 1; ++ph) {
+      if (ph * pw > MP_YP) continue;
+      a.Ph = ph; a.Pw = pw;
+      if (planes_plan(a) > MP_XS) continue;
+      const long patches = (long)cdiv(a.H, ph) * cdiv(a.W, pw);
+      const long cost = patches * (2 * cdiv(ph * pw, 16) + 3) * 10000 + ((pw & 3) ? 5000 : 0) + a.nslots;
+      if (best < 0 || cost < best) { best = cost; bh = ph; bw = pw; }
+    }
+  if (best < 0) return false;
+  a.Ph = bh; a.Pw = bw;
+  planes_plan(a);
+  return true;
+}
+
 template <class P>
-int run_classes(WgArgs& a, int ntile, int R, int S, int stride, int pad, hipStream_t stream) {
+int launch_planes(MpArgs a, FsPartHost* ph, hipStream_t stream) {
+  if (!choose_planes_patch(a)) return FS_ERR_ARG;
+  a.tiles_y = cdiv(a.H, a.Ph); a.tiles_x = cdiv(a.W, a.Pw);
+  a.magic_pw = div_magic1(a.Pw);
+  a.npatch = a.B * a.tiles_y * a.tiles_x;
+  const int ntile = a.tiles_ci * a.tiles_co;
+  static const int target = FS_ENV_INT("FS_WGRAD_S2_WGS", 512);      // kernel A/B builds only
+  int nsplit = target / ntile;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > a.npatch) nsplit = a.npatch;
+  a.patches_per_split = cdiv(a.npatch, nsplit);
+  nsplit = cdiv(a.npatch, a.patches_per_split);
+  if (part_claim(ph, nsplit, a.part) != FS_OK) return FS_ERR_ARG;
+  hipLaunchKernelGGL((conv_wgrad_planes_kernel<P>), dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+template <class P>
+int run_classes(WgArgs& a, int ntile, int R, int S, int stride, int pad, FsPartHost* ph, hipStream_t stream) {
   for (int r0 = 0; r0 < stride && r0 < R; ++r0)
     for (int s0 = 0; s0 < stride && s0 < S; ++s0) {
       const int nR = (R - r0 + stride - 1) / stride, nS = (S - s0 + stride - 1) / stride;
       a.cy = r0 - pad; a.cx = s0 - pad; a.rbase = r0; a.rstep = stride; a.sbase = s0; a.sstep = stride;
       int e = FS_ERR_ARG;
-      if (nR == 3 && nS == 3) e = launch_class<P, 3, 3>(a, ntile, stream);
-      else if (nR == 2 && nS == 2) e = launch_class<P, 2, 2>(a, ntile, stream);
-      else if (nR == 2 && nS == 1) e = launch_class<P, 2, 1>(a, ntile, stream);
-      else if (nR == 1 && nS == 2) e = launch_class<P, 1, 2>(a, ntile, stream);
-      else if (nR == 1 && nS == 1) e = launch_class<P, 1, 1>(a, ntile, stream);
+      if (nR == 3 && nS == 3) e = launch_class<P, 3, 3>(a, ntile, ph, stream);
+      else if (nR == 2 && nS == 2) e = launch_class<P, 2, 2>(a, ntile, ph, stream);
+      else if (nR == 2 && nS == 1) e = launch_class<P, 2, 1>(a, ntile, ph, stream);
+      else if (nR == 1 && nS == 2) e = launch_class<P, 1, 2>(a, ntile, ph, stream);
+      else if (nR == 1 && nS == 1) e = launch_class<P, 1, 1>(a, ntile, ph, stream);
       if (e != FS_OK) return e;
     }
   return FS_OK;
@@ -742,11 +1056,13 @@ bool fs_linear_wgrad_eligible(int mode, long rows, int Cin, int Cout) {
   return mode == 1 && rows > 0 && Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 16 && Cout >= 16 &&
          (size_t)rows * Cin * 4 < 4294967000UL && (size_t)rows * Cout * 4 < 4294967000UL;
 }
-int fs_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, long rows, int Cin, int Cout, hipStream_t stream) {
+int fs_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, long rows, int Cin, int Cout, FsPartHost* part, float* bpart,
+                    hipStream_t stream) {
   LwArgs l;
   l.x = x; l.dy = dy; l.dw = dw; l.dbias = dbias; l.rows = (int)rows; l.Cin = Cin; l.Cout = Cout;
   l.x_bytes = (unsigned)((size_t)rows * Cin * 4); l.dy_bytes = (unsigned)((size_t)rows * Cout * 4);
-  return run_linear_wgrad(l, stream);
+  l.part = FsPart{nullptr, 0}; l.bpart = dbias != nullptr ? bpart : nullptr;
+  return run_linear_wgrad(l, part, stream);
 }
 
 bool fs_wgrad_split_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil) {
@@ -759,9 +1075,10 @@ bool fs_wgrad_split_eligible(int Cin, int Cout, int R, int S, int stride, int pa
 
 // dW of any conv2d with square filter: one launch per tap class (dw zeroed by the caller or accumulated into).  mode: 1 = bf16x3, 2 = f16x2
 int fs_wgrad_split(int mode, const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S,
-                   int stride, int pad, hipStream_t stream) {
+                   int stride, int pad, FsPartHost* ph, hipStream_t stream) {
   if ((size_t)B * H * W * Cin * 4 >= 4294967000UL || (size_t)B * Ho * Wo * Cout * 4 >= 4294967000UL) return FS_ERR_ARG;
   WgArgs a;
+  a.part = FsPart{nullptr, 0};
   a.x = x; a.dy = dy; a.dw = dw;
   a.B = B; a.H = Ho; a.W = Wo; a.Hx = H; a.Wx = W; a.Cin = Cin; a.Cout = Cout;
   a.sm = stride; a.S = S;
@@ -791,6 +1108,7 @@ int fs_wgrad_split(int mode, const float* x, const float* dy, float* dw, int B, 
     // CU pays more per barrier round than two independent 4-wave ones, and the doubled split work is not hidden) -- but 960->240 @ 80x80
     // 7.0 vs 8.1 ms: long pixel loops per channel tile.  So only layers with >= 64 patches per workgroup come here (the C1 heads: 960 -> 240 at B >= 4).
     if (w.patches_per_split < 64 && !wino_wgrad_all) goto direct;
+    if (part_claim(ph, 2 * nsplit, w.part) != FS_OK) return FS_ERR_ARG;
     constexpr int lds = PrecX3::NPL * (XT_PLANE + DM_PLANE);
     {
       static unsigned long long done = 0ull;
@@ -812,7 +1130,17 @@ direct:
     LwArgs l;
     l.x = x; l.dy = dy; l.dw = dw; l.dbias = nullptr; l.rows = B * H * W; l.Cin = Cin; l.Cout = Cout;
     l.x_bytes = a.x_bytes; l.dy_bytes = a.dy_bytes;
-    return run_linear_wgrad(l, stream);
+    l.part = FsPart{nullptr, 0}; l.bpart = nullptr;
+    return run_linear_wgrad(l, ph, stream);
   }
-  return mode == 2 ? run_classes<PrecF16>(a, ntile, R, S, stride, pad, stream) : run_classes<PrecX3>(a, ntile, R, S, stride, pad, stream);
+  static const bool planes_on = FS_ENV_INT("FS_WGRAD_PLANES", 1) != 0;      // kernel A/B builds only
+  if (planes_on && R == 3 && S == 3 && (stride == 2 || stride == 3)) {
+    // all nine taps of a strided 3x3 filter in one launch (parity planes of the X halo in LDS)
+    MpArgs m;
+    m.x = x; m.dy = dy; m.dw = dw; m.B = B; m.H = Ho; m.W = Wo; m.Hx = H; m.Wx = W; m.Cin = Cin; m.Cout = Cout;
+    m.st = stride; m.pad = pad; m.tiles_ci = a.tiles_ci; m.tiles_co = a.tiles_co;
+    m.x_bytes = a.x_bytes; m.dy_bytes = a.dy_bytes; m.part = FsPart{nullptr, 0};
+    return mode == 2 ? launch_planes<PrecF16>(m, ph, stream) : launch_planes<PrecX3>(m, ph, stream);
+  }
+  return mode == 2 ? run_classes<PrecF16>(a, ntile, R, S, stride, pad, ph, stream) : run_classes<PrecX3>(a, ntile, R, S, stride, pad, ph, stream);
 }

@@ -26,7 +26,7 @@ struct RowWalk {
 // All BN kernels work on a channel window [c0, c0+C) of rows with leading dimension ld (C <= 1024 per
 // launch; wider layers are covered by several launches); per-channel pointers arrive offset by c0.
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, long M, int C, int ld, int Ctot,
-                                                       int rows_per_block, double* __restrict__ sums /* [2][Ctot] + c0 */) {
+                                                       int rows_per_block, double* __restrict__ sums /* [block][2][Ctot] + c0 */) {
   extern __shared__ double sm[];   // [rpi][C][2] partials
   RowWalk w(C);
   const long rb = (long)blockIdx.x * rows_per_block;
@@ -45,19 +45,21 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double a = 0, b = 0;
     for (int r = 0; r < w.rpi; ++r) { a += sm[((long)r * C + c) * 2]; b += sm[((long)r * C + c) * 2 + 1]; }
-    atomicAdd(&sums[c], a);
-    atomicAdd(&sums[Ctot + c], b);
+    sums[(long)blockIdx.x * 2 * Ctot + c] = a;          // this block's record: summed in block order by bn_finalize_kernel
+    sums[(long)blockIdx.x * 2 * Ctot + Ctot + c] = b;
   }
 }
 
 // ---- BN finalize: mean / invstd, running-stat update ---------------------------------------
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, long M, int C, float momentum, float eps,
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int nblk, long M, int C, float momentum, float eps,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean, float* __restrict__ invstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double mu = sums[c] / (double)M;
-  double var = sums[C + c] / (double)M - mu * mu;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nblk; ++k) { s1 += sums[(long)k * 2 * C + c]; s2 += sums[(long)k * 2 * C + C + c]; }
+  const double mu = s1 / (double)M;
+  double var = s2 / (double)M - mu * mu;
   if (var < 0) var = 0;
   mean[c] = (float)mu;
   invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -175,18 +177,21 @@ struct BnMask {
   }
 };
 
-// column sums of one block's rows -> slab[blockIdx.x][C][2]; red = [C][2] floats of LDS (ds_add_f32 from the rpi row lanes)
+// column sums of one block's rows -> slab[blockIdx.x][C][2]; red = [rpi][C][2] floats of LDS: every row lane stores its partial sums and
+// the columns are added over the row lanes in index order (no LDS atomics: their order is the waves' arrival order)
 __device__ __forceinline__ void bn_slab_store(const RowWalk& w, f32x4 s, f32x4 sx, int C, int Ctot, float* __restrict__ slab, float* red) {
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
-  __syncthreads();
   if (w.active()) {
-    const int c = 4 * w.col;
+    float* p = red + ((long)w.r0 * C + 4 * w.col) * 2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { atomicAdd(&red[2 * (c + j)], s[j]); atomicAdd(&red[2 * (c + j) + 1], sx[j]); }
+    for (int j = 0; j < 4; ++j) { p[2 * j] = s[j]; p[2 * j + 1] = sx[j]; }
   }
   __syncthreads();
   float* dst = slab + (long)blockIdx.x * Ctot * 2;
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) dst[i] = red[i];
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    float a = 0.f;
+    for (int r = 0; r < w.rpi; ++r) a += red[(long)r * 2 * C + i];
+    dst[i] = a;
+  }
 }
 
 __global__ __launch_bounds__(256)
@@ -441,21 +446,21 @@ __global__ __launch_bounds__(256) void upsample_slice_bwd_kernel(const float* __
   }
 }
 
-// ---- column sums (bias gradients), out zeroed by the launcher ----------------------------------
+// ---- column sums (bias gradients): per-row-block partials into part[block][C], summed in block order by fs_slab_reduce ----------
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long M, int C, int rows_per_block,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ part) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const long rb = (long)blockIdx.y * rows_per_block;
   long re = rb + rows_per_block; if (re > M) re = M;
   float s = 0.f;
   for (long r = rb; r < re; ++r) s += x[r * C + c];
-  atomicAdd(&out[c], s);
+  part[(long)blockIdx.y * C + c] = s;
 }
 
 // the same for C % 4 == 0, C <= 1024: 16-byte loads over the RowWalk layout (all 256 threads busy for any C, four rows in flight),
-// per-workgroup partials through LDS, one atomic per column and workgroup
-__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ x, long M, int C, int rows_per_block, float* __restrict__ out) {
+// per-workgroup partials through LDS, one store per column and workgroup
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ x, long M, int C, int rows_per_block, float* __restrict__ part) {
   extern __shared__ float csm[];   // [rpi][C]
   RowWalk w(C);
   const int c = 4 * w.col;
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ 
   for (int cc = threadIdx.x; cc < C; cc += blockDim.x) {
     float a = 0.f;
     for (int r = 0; r < w.rpi; ++r) a += csm[r * C + cc];
-    atomicAdd(&out[cc], a);
+    part[(long)blockIdx.x * C + cc] = a;
   }
 }
 
@@ -568,16 +573,59 @@ size_t stats_smem(int C) {
   return (size_t)rpi * C * 2 * sizeof(double);
 }
 
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ part, int nslab, long n, float* __restrict__ out, int accumulate) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = accumulate ? out[i] : 0.f;
+  for (int k = 0; k < nslab; ++k) s += part[(long)k * n + i];
+  out[i] = s;
+}
+// few columns, many slabs (bias / 1x1-head gradients from ~1000 workgroups): one wave per column, lane j adds slabs j, j + 64, ... in
+// order and the 64 lane sums meet in a fixed shuffle tree -- the order depends on (nslab) only, never on timing
+__global__ __launch_bounds__(256) void slab_reduce_wave_kernel(const float* __restrict__ part, int nslab, long n, float* __restrict__ out, int accumulate) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = lane; k < nslab; k += 64) s += part[(long)k * n + i];
+  s = wave_sum(s);
+  if (lane == 0) out[i] = accumulate ? out[i] + s : s;
+}
+
 }  // namespace
+
+// common.h: the ordered second stage of every cross-workgroup sum
+int fs_slab_reduce(const float* part, int nslab, long n, float* out, int accumulate, hipStream_t stream) {
+  if (part == nullptr || out == nullptr || nslab < 0 || n <= 0) return FS_ERR_ARG;
+  if (n <= 4096 && nslab > 64)
+    hipLaunchKernelGGL(slab_reduce_wave_kernel, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, stream, part, nslab, n, out, accumulate);
+  else
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, nslab, n, out, accumulate);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
 
 extern "C" {
 
 // Training-mode statistics of y (M rows, C channels): mean/invstd out, running stats updated in
 // place with `momentum` (unbiased variance), `sums` = 2*C doubles of scratch.
+// row blocks of fs_bn_stats (the widest count over its channel windows) = records of 2*C doubles in its scratch
+static int bn_stats_blocks(long M, int C) {
+  int nblk = 1;
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    const int Cc = C - c0 < 1024 ? C - c0 : 1024;
+    const int n = cdiv(M, rows_per_block_for(M, Cc));
+    if (n > nblk) nblk = n;
+  }
+  return nblk;
+}
+long fs_bn_stats_scratch_doubles(long M, int C) { return (M > 0 && C > 0) ? (long)bn_stats_blocks(M, C) * 2 * C : 0; }
+
 int fs_bn_stats(const float* y, long M, int C, float momentum, float eps, float* running_mean, float* running_var,
                 float* mean, float* invstd, double* sums, hipStream_t stream) {
   FS_REQUIRE(y && mean && invstd && sums && M > 0 && C > 0 && C % 4 == 0);
-  hipError_t e = hipMemsetAsync(sums, 0, 2 * C * sizeof(double), stream);
+  const int nblk = bn_stats_blocks(M, C);
+  hipError_t e = hipMemsetAsync(sums, 0, (size_t)nblk * 2 * C * sizeof(double), stream);       // windows with fewer row blocks leave records untouched
   if (e != hipSuccess) return (int)e;
   for (int c0 = 0; c0 < C; c0 += 1024) {
     const int Cc = C - c0 < 1024 ? C - c0 : 1024;
@@ -585,7 +633,7 @@ int fs_bn_stats(const float* y, long M, int C, float momentum, float eps, float*
     hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(M, rpb)), dim3(256), stats_smem(Cc), stream, y + c0, M, Cc, C, C, rpb, sums + c0);
     FS_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, sums, M, C, momentum, eps,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, sums, nblk, M, C, momentum, eps,
                      running_mean, running_var, mean, invstd);
   FS_LAUNCH_CHECK();
   return FS_OK;
@@ -645,6 +693,12 @@ int fs_bn_bwd_slabs(long M, int C) {
   return n;
 }
 
+// LDS of bn_slab_store: [rpi][C][2] floats, rpi = row lanes of the RowWalk layout (<= 8.2 KB)
+static size_t slab_lds_bytes(int C) {
+  int rpi = 256 / (C / 4); if (rpi < 1) rpi = 1;
+  return (size_t)rpi * C * 2 * sizeof(float);
+}
+
 int fs_bn_bwd_partial(const float* dz, const float* z, const unsigned char* mask, const float* y, const float* mean, const float* invstd,
                       long M, int C, int act, float* slab, hipStream_t stream) {
   FS_REQUIRE(dz && y && mean && invstd && slab && M > 0 && C > 0 && C % 4 == 0);
@@ -654,7 +708,7 @@ int fs_bn_bwd_partial(const float* dz, const float* z, const unsigned char* mask
     const int Cc = C - c0 < 1024 ? C - c0 : 1024;
     const int rpb = rows_per_block_for(M, Cc);
     // every launch writes all nslab rows of its channel window (blocks past the last row write zeros)
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nslab), dim3(256), 2 * Cc * sizeof(float), stream, dz + c0, z ? z + c0 : nullptr,
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nslab), dim3(256), slab_lds_bytes(Cc), stream, dz + c0, z ? z + c0 : nullptr,
                        mask ? mask + c0 / 4 : nullptr, y + c0, mean + c0, invstd + c0, M, Cc, C, rpb, act, slab + 2 * c0);
     FS_LAUNCH_CHECK();
   }
@@ -669,7 +723,7 @@ int fs_add_n_bnsum(const float* a, const float* b, const float* c, const float* 
   for (int c0 = 0; c0 < C; c0 += 1024) {
     const int Cc = C - c0 < 1024 ? C - c0 : 1024;
     const int rpb = rows_per_block_for(M, Cc);
-    hipLaunchKernelGGL(add_n_bnsum_kernel, dim3(nslab), dim3(256), 2 * Cc * sizeof(float), stream, a + c0, b + c0, c ? c + c0 : nullptr,
+    hipLaunchKernelGGL(add_n_bnsum_kernel, dim3(nslab), dim3(256), slab_lds_bytes(Cc), stream, a + c0, b + c0, c ? c + c0 : nullptr,
                        d ? d + c0 : nullptr, out + c0, mask ? mask + c0 / 4 : nullptr, y + c0, mean + c0, invstd + c0, M, Cc, C, rpb, act,
                        slab + 2 * c0);
     FS_LAUNCH_CHECK();
@@ -786,27 +840,38 @@ int fs_dropout(const float* x, float* out, long n, float drop_p, uint32_t drop_k
   return FS_OK;
 }
 
-// accumulate != 0: the column sums are ADDED to out (a gradient-arena target: no memset), else out is overwritten
-int fs_colsum(const float* x, long M, int C, float* out, int accumulate, hipStream_t stream) {
-  FS_REQUIRE(x && out && M > 0 && C > 0);
-  if (!accumulate) {
-    hipError_t e = hipMemsetAsync(out, 0, C * sizeof(float), stream);
-    if (e != hipSuccess) return (int)e;
-  }
-  if (C % 4 == 0 && C <= 1024 && ((size_t)x & 15) == 0) {
-    const int rpb = rows_per_block_for(M, C);
+// rows per block of the two colsum kernels; the number of partial rows they write
+static void colsum_plan(long M, int C, bool vec, int* rpb, int* nblk) {
+  if (vec) *rpb = rows_per_block_for(M, C);
+  else { int chunks = (int)((M + 255) / 256); if (chunks > 512) chunks = 512; *rpb = (int)((M + chunks - 1) / chunks); }
+  *nblk = cdiv(M, *rpb);
+}
+// include/fovealseg.h: floats of scratch fs_colsum needs (per-row-block partial sums)
+long fs_colsum_scratch_floats(long M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  int rpb, nblk;
+  colsum_plan(M, C, C % 4 == 0 && C <= 1024, &rpb, &nblk);
+  return (long)nblk * C;
+}
+// accumulate != 0: the column sums are ADDED to out (a gradient-arena target), else out is overwritten.  Two launches: per-row-block
+// partial sums into `scratch`, then their sum in block order (no atomics: the result does not depend on workgroup arrival order)
+int fs_colsum(const float* x, long M, int C, float* out, int accumulate, float* scratch, hipStream_t stream) {
+  FS_REQUIRE(x && out && scratch && M > 0 && C > 0);
+  const bool vec = C % 4 == 0 && C <= 1024 && ((size_t)x & 15) == 0;
+  int rpb, nblk;
+  colsum_plan(M, C, C % 4 == 0 && C <= 1024, &rpb, &nblk);
+  if (vec) {
     const int cw = C / 4;
     int rpi = 256 / cw; if (rpi < 1) rpi = 1;
-    hipLaunchKernelGGL(colsum4_kernel, dim3(cdiv(M, rpb)), dim3(256), (size_t)rpi * C * sizeof(float), stream, x, M, C, rpb, out);
-    FS_LAUNCH_CHECK();
-    return FS_OK;
+    hipLaunchKernelGGL(colsum4_kernel, dim3(nblk), dim3(256), (size_t)rpi * C * sizeof(float), stream, x, M, C, rpb, scratch);
+  } else {
+    if (C % 4 == 0 && C <= 1024) colsum_plan(M, C, false, &rpb, &nblk);      // misaligned base: the scalar kernel (fewer blocks than planned)
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 256), nblk), dim3(256), 0, stream, x, M, C, rpb, scratch);
   }
-  int chunks = (int)((M + 255) / 256); if (chunks > 512) chunks = 512;
-  const int rpb = (int)((M + chunks - 1) / chunks);
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 256), cdiv(M, rpb)), dim3(256), 0, stream, x, M, C, rpb, out);
   FS_LAUNCH_CHECK();
-  return FS_OK;
+  return fs_slab_reduce(scratch, nblk, C, out, accumulate, stream);
 }
+
 
 int fs_avgpool_fwd(const float* x, int B, int HW, int C, float* out, hipStream_t stream) {
   FS_REQUIRE(x && out && B > 0 && HW > 0 && C > 0);

@@ -81,16 +81,15 @@ __global__ __launch_bounds__(1024) void compress_softmax_fwd_kernel(const float*
 // dlogit = xs * (g - sum(g*xs)); ds[p][c] = dlogit*w[c]*(s>0); dw[c] += sum dlogit*relu(s); db += sum dlogit
 __global__ __launch_bounds__(1024) void compress_softmax_bwd_kernel(const float* __restrict__ g, const float* __restrict__ xs,
                                                                     const float* __restrict__ s, const float* __restrict__ w,
-                                                                    float* __restrict__ ds, float* __restrict__ dw,
-                                                                    float* __restrict__ db, int HW, int C) {
+                                                                    float* __restrict__ ds, float* __restrict__ part /* [B][C], then [B] */,
+                                                                    int HW, int C) {
   __shared__ float red[16];
-  __shared__ float dwacc[64];
+  __shared__ float dwacc[16 * 32];
   const int b = blockIdx.x;
   const float* gb = g + (long)b * HW;
   const float* xb = xs + (long)b * HW;
   const float* sb = s + (long)b * HW * C;
   float* dsb = ds + (long)b * HW * C;
-  if (threadIdx.x < 64) dwacc[threadIdx.x] = 0.f;
   float dot = 0.f;
   for (int p = threadIdx.x; p < HW; p += blockDim.x) dot += gb[p] * xb[p];
   dot = block_sum<float>(dot, red);
@@ -110,18 +109,23 @@ __global__ __launch_bounds__(1024) void compress_softmax_bwd_kernel(const float*
       }
     }
   }
-  __syncthreads();
+  // per-wave sums into their own LDS row, rows added in wave order; the image's record goes to part[b], summed in image order by
+  // fs_slab_reduce (no atomics anywhere: the result does not depend on which wave or workgroup finishes first)
 #pragma unroll
   for (int c = 0; c < 32; ++c) {
     if (c < C) {
       const float v = wave_sum(dwl[c]);
-      if ((threadIdx.x & 63) == 0) atomicAdd(&dwacc[c], v);
+      if ((threadIdx.x & 63) == 0) dwacc[(threadIdx.x >> 6) * 32 + c] = v;
     }
   }
   dbl = block_sum<float>(dbl, red);
   __syncthreads();
-  if (threadIdx.x < C) atomicAdd(&dw[threadIdx.x], dwacc[threadIdx.x]);
-  if (threadIdx.x == 0) atomicAdd(db, dbl);
+  if (threadIdx.x < C) {
+    float a = 0.f;
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) a += dwacc[wv * 32 + threadIdx.x];
+    part[(long)b * C + threadIdx.x] = a;
+  }
+  if (threadIdx.x == 0) part[(long)gridDim.x * C + b] = dbl;
 }
 
 // CompressNet.forward on its own (models/models.py:360-372): logit[p] = w . relu(s[p]) + bias, one thread per pixel (C <= 32: the
@@ -140,14 +144,13 @@ __global__ __launch_bounds__(256) void compress_fwd_kernel(const float* __restri
 
 __global__ __launch_bounds__(1024) void compress_bwd_kernel(const float* __restrict__ g, const float* __restrict__ s,
                                                             const float* __restrict__ w, float* __restrict__ ds,
-                                                            float* __restrict__ dw, float* __restrict__ db, int HW, int C) {
+                                                            float* __restrict__ part /* [B][C], then [B] */, int HW, int C) {
   __shared__ float red[16];
-  __shared__ float dwacc[32];
+  __shared__ float dwacc[16 * 32];
   const int b = blockIdx.x;
   const float* gb = g + (long)b * HW;
   const float* sb = s + (long)b * HW * C;
   float* dsb = ds + (long)b * HW * C;
-  if (threadIdx.x < 32) dwacc[threadIdx.x] = 0.f;
   float dbl = 0.f;
   float dwl[32];
 #pragma unroll
@@ -164,18 +167,23 @@ __global__ __launch_bounds__(1024) void compress_bwd_kernel(const float* __restr
       }
     }
   }
-  __syncthreads();
+  // per-wave sums into their own LDS row, rows added in wave order; the image's record goes to part[b], summed in image order by
+  // fs_slab_reduce (no atomics anywhere: the result does not depend on which wave or workgroup finishes first)
 #pragma unroll
   for (int c = 0; c < 32; ++c) {
     if (c < C) {
       const float v = wave_sum(dwl[c]);
-      if ((threadIdx.x & 63) == 0) atomicAdd(&dwacc[c], v);
+      if ((threadIdx.x & 63) == 0) dwacc[(threadIdx.x >> 6) * 32 + c] = v;
     }
   }
   dbl = block_sum<float>(dbl, red);
   __syncthreads();
-  if (threadIdx.x < C) atomicAdd(&dw[threadIdx.x], dwacc[threadIdx.x]);
-  if (threadIdx.x == 0) atomicAdd(db, dbl);
+  if (threadIdx.x < C) {
+    float a = 0.f;
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) a += dwacc[wv * 32 + threadIdx.x];
+    part[(long)b * C + threadIdx.x] = a;
+  }
+  if (threadIdx.x == 0) part[(long)gridDim.x * C + b] = dbl;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -875,16 +883,15 @@ int fs_compress_fwd(const float* s, const float* w, const float* bias, float* ou
   return FS_OK;
 }
 
+// scratch: B * (C + 1) floats (per-image partial sums of dw and db, added in image order)
 int fs_compress_bwd(const float* g, const float* s, const float* w, float* ds, float* dw, float* db, int B, int HW, int C,
-                    hipStream_t stream) {
-  FS_REQUIRE(g && s && w && ds && dw && db && B > 0 && HW > 0 && C > 0 && C <= 32);
-  hipError_t e = hipMemsetAsync(dw, 0, C * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(db, 0, sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(compress_bwd_kernel, dim3(B), dim3(1024), 0, stream, g, s, w, ds, dw, db, HW, C);
+                    float* scratch, hipStream_t stream) {
+  FS_REQUIRE(g && s && w && ds && dw && db && scratch && B > 0 && HW > 0 && C > 0 && C <= 32);
+  hipLaunchKernelGGL(compress_bwd_kernel, dim3(B), dim3(1024), 0, stream, g, s, w, ds, scratch, HW, C);
   FS_LAUNCH_CHECK();
-  return FS_OK;
+  const int r = fs_slab_reduce(scratch, B, C, dw, 0, stream);
+  if (r != FS_OK) return r;
+  return fs_slab_reduce(scratch + (long)B * C, B, 1, db, 0, stream);
 }
 
 int fs_compress_softmax_fwd(const float* s, const float* w, const float* bias, float* xs, int B, int HW, int C,
@@ -895,16 +902,15 @@ int fs_compress_softmax_fwd(const float* s, const float* w, const float* bias, f
   return FS_OK;
 }
 
+// scratch: B * (C + 1) floats (per-image partial sums of dw and db, added in image order)
 int fs_compress_softmax_bwd(const float* g, const float* xs, const float* s, const float* w, float* ds, float* dw, float* db,
-                            int B, int HW, int C, hipStream_t stream) {
-  FS_REQUIRE(g && xs && s && w && ds && dw && db && B > 0 && HW > 0 && C > 0 && C <= 32);
-  hipError_t e = hipMemsetAsync(dw, 0, C * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(db, 0, sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(compress_softmax_bwd_kernel, dim3(B), dim3(1024), 0, stream, g, xs, s, w, ds, dw, db, HW, C);
+                            int B, int HW, int C, float* scratch, hipStream_t stream) {
+  FS_REQUIRE(g && xs && s && w && ds && dw && db && scratch && B > 0 && HW > 0 && C > 0 && C <= 32);
+  hipLaunchKernelGGL(compress_softmax_bwd_kernel, dim3(B), dim3(1024), 0, stream, g, xs, s, w, ds, scratch, HW, C);
   FS_LAUNCH_CHECK();
-  return FS_OK;
+  const int r = fs_slab_reduce(scratch, B, C, dw, 0, stream);
+  if (r != FS_OK) return r;
+  return fs_slab_reduce(scratch + (long)B * C, B, 1, db, 0, stream);
 }
 
 int fs_area_pool_fwd(const float* y, float* out, int B, int H, int W, int hs, int ws, hipStream_t stream) {

@@ -29,13 +29,10 @@ __global__ __launch_bounds__(256) void mask_head_fwd_kernel(const float* __restr
 // dlogit = dm * s(1-s), s = m + 0.5;  dx[p][c] = dlogit*w[c];  dw[c] += sum_p dlogit*x[p][c];  db += sum dlogit
 __global__ __launch_bounds__(256) void mask_head_bwd_kernel(const float* __restrict__ dm, const float* __restrict__ m,
                                                             const float* __restrict__ x, const float* __restrict__ w,
-                                                            float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
+                                                            float* __restrict__ dx, float* __restrict__ part /* [blocks][C], then [blocks] */,
                                                             long npix, int C, int pix_per_block) {
-  extern __shared__ float dws[];   // C floats
-  __shared__ float dbs;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) dws[c] = 0.f;
-  if (threadIdx.x == 0) dbs = 0.f;
-  __syncthreads();
+  extern __shared__ float dws[];   // [4 waves][C] floats: the waves' partial sums, added in wave order (no LDS atomics)
+  __shared__ float dbs[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long p0 = (long)blockIdx.x * pix_per_block;
   long p1 = p0 + pix_per_block; if (p1 > npix) p1 = npix;
@@ -61,15 +58,14 @@ __global__ __launch_bounds__(256) void mask_head_bwd_kernel(const float* __restr
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int c = 4 * lane + 256 * j;
-    if (c < C) {
-      atomicAdd(&dws[c + 0], dwl[j].x); atomicAdd(&dws[c + 1], dwl[j].y);
-      atomicAdd(&dws[c + 2], dwl[j].z); atomicAdd(&dws[c + 3], dwl[j].w);
-    }
+    if (c < C) *reinterpret_cast<f32x4*>(&dws[wv * C + c]) = dwl[j];
   }
-  if (lane == 0) atomicAdd(&dbs, dbl);
+  // dl is wave-uniform (one pixel per wave and round): lane 0 holds the wave's sum already
+  if (lane == 0) dbs[wv] = dbl;
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&dw[c], dws[c]);
-  if (threadIdx.x == 0) atomicAdd(db, dbs);
+  // this workgroup's record, summed in block order by fs_slab_reduce
+  for (int c = threadIdx.x; c < C; c += blockDim.x) part[(long)blockIdx.x * C + c] = ((dws[c] + dws[C + c]) + dws[2 * C + c]) + dws[3 * C + c];
+  if (threadIdx.x == 0) part[(long)gridDim.x * C + blockIdx.x] = ((dbs[0] + dbs[1]) + dbs[2]) + dbs[3];
 }
 
 // pred (B,K,HW) NCHW from class logits c (B,K) and mask m (B,HW)
@@ -115,10 +111,13 @@ constexpr int KMAX = 64;
 __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restrict__ pred, const long long* __restrict__ gt,
                                                            double* __restrict__ accum, int K, int HW, int blocks_per_img,
                                                            float gamma) {
-  __shared__ float sp[KMAX], si[KMAX], sc[KMAX];
+  // sp: per-wave class sums, added in wave order; si: sum of the true class's probability in 2^-40 fixed point (integer adds commute:
+  // no dependence on which lane gets to the LDS first); sc: counts (exact in fp32)
+  __shared__ float sp[4][KMAX], sc[KMAX];
+  __shared__ unsigned long long si[KMAX];
   __shared__ double dred[16];
   const int b = blockIdx.x / blocks_per_img, chunk = blockIdx.x - b * blocks_per_img;
-  for (int k = threadIdx.x; k < KMAX; k += blockDim.x) { sp[k] = 0.f; si[k] = 0.f; sc[k] = 0.f; }
+  for (int k = threadIdx.x; k < KMAX; k += blockDim.x) { si[k] = 0ull; sc[k] = 0.f; }
   __syncthreads();
   const float* pb = pred + (long)b * K * HW;
   const int bg = K - 1;
@@ -152,7 +151,7 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
       if (k < K) {
         const float pk = expf(v[k] - mx - lse);
         spl[k] += pk;
-        if (k == t) { atomicAdd(&si[k], pk); atomicAdd(&sc[k], 1.f); vt = v[k]; }
+        if (k == t) { atomicAdd(&si[k], (unsigned long long)((double)pk * 1099511627776.0)); atomicAdd(&sc[k], 1.f); vt = v[k]; }
       }
     }
     const float logpt = vt - mx - lse;
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
   for (int k = 0; k < KMAX; ++k) {
     if (k < K) {
       const float ws = wave_sum(spl[k]);
-      if (lane == 0) atomicAdd(&sp[k], ws);
+      if (lane == 0) sp[threadIdx.x >> 6][k] = ws;
     }
   }
   __syncthreads();
@@ -174,8 +173,8 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
   // same-address double atomics from every workgroup
   double* rec = accum + (long)blockIdx.x * (3 * K + 7);
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    rec[k] = (double)sp[k];
-    rec[K + k] = (double)si[k];
+    rec[k] = (double)(((sp[0][k] + sp[1][k]) + sp[2][k]) + sp[3][k]);
+    rec[K + k] = (double)si[k] * (1.0 / 1099511627776.0);
     rec[2 * K + k] = (double)sc[k];
   }
   focal = block_sum<double>(focal, dred);
@@ -284,18 +283,20 @@ int fs_mask_head_fwd(const float* x, const float* w, const float* bias, float* m
   return FS_OK;
 }
 
+constexpr int MASK_HEAD_PPB = 256;      // pixels per workgroup of mask_head_bwd_kernel
+long fs_mask_head_bwd_scratch_floats(long npix, int C) { return (npix > 0 && C > 0) ? (long)cdiv(npix, MASK_HEAD_PPB) * (C + 1) : 0; }
+
+// scratch: fs_mask_head_bwd_scratch_floats(npix, C) floats (per-workgroup partial sums of dw and db, added in workgroup order)
 int fs_mask_head_bwd(const float* dm, const float* m, const float* x, const float* w, float* dx, float* dw, float* db, long npix,
-                     int C, hipStream_t stream) {
-  FS_REQUIRE(dm && m && x && w && dx && dw && db && npix > 0 && C > 0 && C % 4 == 0 && C <= 1024);
-  hipError_t e = hipMemsetAsync(dw, 0, C * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(db, 0, sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
-  const int ppb = 256;
-  hipLaunchKernelGGL(mask_head_bwd_kernel, dim3(cdiv(npix, ppb)), dim3(256), C * sizeof(float), stream, dm, m, x, w, dx, dw, db,
-                     npix, C, ppb);
+                     int C, float* scratch, hipStream_t stream) {
+  FS_REQUIRE(dm && m && x && w && dx && dw && db && scratch && npix > 0 && C > 0 && C % 4 == 0 && C <= 1024);
+  const int nblk = cdiv(npix, MASK_HEAD_PPB);
+  hipLaunchKernelGGL(mask_head_bwd_kernel, dim3(nblk), dim3(256), 4 * C * sizeof(float), stream, dm, m, x, w, dx, scratch,
+                     npix, C, MASK_HEAD_PPB);
   FS_LAUNCH_CHECK();
-  return FS_OK;
+  const int r = fs_slab_reduce(scratch, nblk, C, dw, 0, stream);
+  if (r != FS_OK) return r;
+  return fs_slab_reduce(scratch + (long)nblk * C, nblk, 1, db, 0, stream);
 }
 
 int fs_pred_assemble_fwd(const float* cls, const float* m, float* pred, int B, int K, int HW, hipStream_t stream) {

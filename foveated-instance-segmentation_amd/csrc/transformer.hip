@@ -5,6 +5,8 @@
 // models/segformer.py:2,9-11,33-37,88-100).  Tokens are rows of an NHWC tensor: (B, N=H*W, C).
 #include "common.h"
 
+bool fs_deterministic();      // conv.hip (include/fovealseg.h fs_set_deterministic)
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -45,15 +47,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
-// dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat));  dgamma += g*xhat, dbeta += g (atomics per block)
+// dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat));  per-block records of sum g*xhat (part_g) and sum g (part_b)
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, long M, int C,
+                                                            float* __restrict__ part_g, float* __restrict__ part_b, long M, int C,
                                                             int rows_per_block) {
-  extern __shared__ float sm[];          // [2][C] block partials of dgamma / dbeta
-  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) sm[c] = 0.f;
-  __syncthreads();
+  extern __shared__ float sm[];          // [4 waves][2][C] partials of dgamma / dbeta
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
@@ -85,16 +85,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       if (c < C) *reinterpret_cast<f32x4*>(dx + row * C + c) = rs * (gg[j] - m1 - xh[j] * m2);
     }
   }
+  // sm = [4 waves][2 C]: every wave stores its partial sums, the block adds them in wave order and writes its record to
+  // part_g[block][C] / part_b[block][C]; fs_slab_reduce adds the records in block order (no atomics: nothing depends on arrival order)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = 4 * lane + 256 * j;
     if (c < C) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { atomicAdd(&sm[c + e], ag[j][e]); atomicAdd(&sm[C + c + e], ab[j][e]); }
+      *reinterpret_cast<f32x4*>(&sm[wv * 2 * C + c]) = ag[j];
+      *reinterpret_cast<f32x4*>(&sm[wv * 2 * C + C + c]) = ab[j];
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) { atomicAdd(&dgamma[c], sm[c]); atomicAdd(&dbeta[c], sm[C + c]); }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    part_g[(long)blockIdx.x * C + c] = ((sm[c] + sm[2 * C + c]) + sm[4 * C + c]) + sm[6 * C + c];
+    part_b[(long)blockIdx.x * C + c] = ((sm[C + c] + sm[3 * C + c]) + sm[5 * C + c]) + sm[7 * C + c];
+  }
 }
 
 // Sixteen lanes per row (C <= 320): the Mix-Transformer widths are 64 .. 512, where a wave per row leaves 3/4 (C = 64) to 3/8 (C = 320,
@@ -146,11 +151,9 @@ template <int NJ>
 __global__ __launch_bounds__(256) void layernorm_bwd16_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, float* __restrict__ dx,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, long M, int C,
+                                                              float* __restrict__ part_g, float* __restrict__ part_b, long M, int C,
                                                               int rows_per_block) {
-  extern __shared__ float sm[];          // [2][C] block partials of dgamma / dbeta
-  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) sm[c] = 0.f;
-  __syncthreads();
+  extern __shared__ float sm[];          // [4 waves][2][C] partials of dgamma / dbeta
   const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
@@ -197,17 +200,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd16_kernel(const float* __res
       ab[j][e] += __shfl_xor(ab[j][e], 16, 64); ab[j][e] += __shfl_xor(ab[j][e], 32, 64);
     }
   if ((threadIdx.x & 63) < 16) {
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = 4 * l16 + 64 * j;
       if (c < C) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { atomicAdd(&sm[c + e], ag[j][e]); atomicAdd(&sm[C + c + e], ab[j][e]); }
+        *reinterpret_cast<f32x4*>(&sm[wv * 2 * C + c]) = ag[j];
+        *reinterpret_cast<f32x4*>(&sm[wv * 2 * C + C + c]) = ab[j];
       }
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) { atomicAdd(&dgamma[c], sm[c]); atomicAdd(&dbeta[c], sm[C + c]); }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    part_g[(long)blockIdx.x * C + c] = ((sm[c] + sm[2 * C + c]) + sm[4 * C + c]) + sm[6 * C + c];
+    part_b[(long)blockIdx.x * C + c] = ((sm[C + c] + sm[3 * C + c]) + sm[5 * C + c]) + sm[7 * C + c];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -820,32 +827,49 @@ int fs_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
 }
 
 // accumulate != 0: dgamma / dbeta are ADDED to (gradient-arena targets: no memset), else overwritten
-int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
-                     float* dgamma, float* dbeta, long M, int C, int accumulate, hipStream_t stream) {
-  FS_REQUIRE(g && x && gamma && mean && rstd && dx && dgamma && dbeta && M > 0 && C > 0 && C % 4 == 0 && C <= 2048);
-  if (!accumulate) {
-    hipError_t e = hipMemsetAsync(dgamma, 0, C * sizeof(float), stream);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(dbeta, 0, C * sizeof(float), stream);
-    if (e != hipSuccess) return (int)e;
+// rows per workgroup / workgroups of the two layernorm backward kernels
+static void ln_bwd_plan(long M, int C, int* rpb, int* nblk) {
+  if (cdiv(C, 64) <= 5) {           // 16 rows in flight per workgroup; ~2048 workgroups (8 per CU)
+    int r = (int)((M + 2047) / 2048); r = (r + 15) / 16 * 16; if (r < 16) r = 16;
+    *rpb = r;
+  } else {
+    int r = (int)((M + 1023) / 1024); if (r < 4) r = 4;
+    *rpb = r;
   }
+  *nblk = cdiv(M, *rpb);
+}
+long fs_layernorm_bwd_scratch_floats(long M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  int rpb, nblk;
+  ln_bwd_plan(M, C, &rpb, &nblk);
+  return 2L * nblk * C;
+}
+
+// scratch: fs_layernorm_bwd_scratch_floats(M, C) floats -- per-workgroup records of the dgamma / dbeta sums, added in workgroup order
+int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                     float* dgamma, float* dbeta, long M, int C, int accumulate, float* scratch, hipStream_t stream) {
+  FS_REQUIRE(g && x && gamma && mean && rstd && dx && dgamma && dbeta && scratch && M > 0 && C > 0 && C % 4 == 0 && C <= 2048);
+  int rpb, nblk;
+  ln_bwd_plan(M, C, &rpb, &nblk);
+  float* part_g = scratch;
+  float* part_b = scratch + (long)nblk * C;
   const int need = cdiv(C, 64);
+  const size_t lds = 8 * (size_t)C * sizeof(float);
   if (need <= 5) {                  // (wider rows fill a wave per row; 8 float4s per lane of five arrays would spill)
-    // 16 rows in flight per workgroup; ~2048 workgroups (8 per CU) so the 2 C global atomics per workgroup stay a small share
-    int rpb = (int)((M + 2047) / 2048); rpb = (rpb + 15) / 16 * 16; if (rpb < 16) rpb = 16;
-    const dim3 grid((unsigned)cdiv(M, rpb));
-#define FS_LN_BWD16(NJ_) hipLaunchKernelGGL(layernorm_bwd16_kernel<NJ_>, grid, dim3(256), 2 * C * sizeof(float), stream, g, x, gamma, mean, rstd, dx, dgamma, dbeta, M, C, rpb)
+    const dim3 grid((unsigned)nblk);
+#define FS_LN_BWD16(NJ_) hipLaunchKernelGGL(layernorm_bwd16_kernel<NJ_>, grid, dim3(256), lds, stream, g, x, gamma, mean, rstd, dx, part_g, part_b, M, C, rpb)
     if (need <= 1) FS_LN_BWD16(1);
     else if (need <= 2) FS_LN_BWD16(2);
     else FS_LN_BWD16(5);
 #undef FS_LN_BWD16
   } else {
-    int rpb = (int)((M + 1023) / 1024); if (rpb < 4) rpb = 4;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 2 * C * sizeof(float), stream, g, x, gamma, mean, rstd,
-                       dx, dgamma, dbeta, M, C, rpb);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), lds, stream, g, x, gamma, mean, rstd,
+                       dx, part_g, part_b, M, C, rpb);
   }
   FS_LAUNCH_CHECK();
-  return FS_OK;
+  const int r = fs_slab_reduce(part_g, nblk, C, dgamma, accumulate, stream);
+  if (r != FS_OK) return r;
+  return fs_slab_reduce(part_b, nblk, C, dbeta, accumulate, stream);
 }
 
 int fs_gelu_fwd(const float* x, float* y, long n, hipStream_t stream) {
@@ -998,6 +1022,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
   int nsplit = cdiv(512, (long)nkc * B * heads);
   if (nsplit > nqb) nsplit = nqb;
   if (nsplit > 64) nsplit = 64;
+  if (fs_deterministic()) nsplit = 1;        // deterministic mode: one query range per key chunk, no atomics (the split-precision kernels sum partial tensors in order instead)
   const int bps = cdiv(nqb, nsplit);
   nsplit = cdiv(nqb, bps);
   if (nsplit > 1) {

@@ -19,9 +19,9 @@ SIGNATURES = {
     "fs_ingest_sample": "ppppiiiiiiiii",
     "fs_gaze_lowres_fwd": "pppiiiii",
     "fs_compress_fwd": "ppppiii",
-    "fs_compress_bwd": "ppppppiii",
+    "fs_compress_bwd": "ppppppiiip",
     "fs_compress_softmax_fwd": "ppppiii",
-    "fs_compress_softmax_bwd": "pppppppiii",
+    "fs_compress_softmax_bwd": "pppppppiiip",
     "fs_area_pool_fwd": "ppiiiii",
     "fs_edge_loss_fwd": "pplfpp",
     "fs_edge_loss_bwd": "pplfppp",
@@ -42,8 +42,8 @@ SIGNATURES = {
     "fs_conv2d_bwd_data": "pppiiiiiiiiiiiiplp",
     "fs_conv2d_bwd_data_bnsum": "pppiiiiiiiiiiiiplp" + "ppppp" + "pp",
     "fs_weight_amax_segments": "pppip",
-    "fs_conv2d_bwd_weight": "pppiiiiiiiiiiiii",
-    "fs_linear_bwd_weight_bias": "pppp" + "lii" + "ii",
+    "fs_conv2d_bwd_weight": "pppiiiiiiiiiiiii" + "pl",
+    "fs_linear_bwd_weight_bias": "pppp" + "lii" + "ii" + "pl",
     "fs_bn_stats": "pliffppppp",
     "fs_bn_finalize_slab": "piliffpppp",
     "fs_bn_eval_prepare": "ppifpp",
@@ -58,21 +58,21 @@ SIGNATURES = {
     "fs_add_n": "pppppl",
     "fs_upsample_slice_fwd": "piiiipiiii",
     "fs_upsample_slice_bwd": "piiiiipiii",
-    "fs_colsum": "plipi",
+    "fs_colsum": "plipip",
     "fs_maxpool_fwd": "pppiiiiiiiii",
     "fs_maxpool_bwd": "pppiiiiiiiii",
     "fs_dropout": "pplfu",
     "fs_avgpool_fwd": "piiip",
     "fs_avgpool_bwd": "piiip",
     "fs_mask_head_fwd": "ppppli",
-    "fs_mask_head_bwd": "pppppppli",
+    "fs_mask_head_bwd": "pppppppli" + "p",
     "fs_pred_assemble_fwd": "pppiii",
     "fs_pred_assemble_bwd": "pppppiii",
     "fs_seg_loss_fwd": "ppiiiffppp",
     "fs_seg_loss_bwd": "pppppiiif",
     "fs_adam_step": "pppplfffffif",
     "fs_layernorm_fwd": "pppppplif",
-    "fs_layernorm_bwd": "pppppppplii",
+    "fs_layernorm_bwd": "pppppppplii" + "p",
     "fs_gelu_fwd": "ppl",
     "fs_gelu_bwd": "pppl",
     "fs_unfold": "pp" + "iiiiiiiiii",
@@ -95,7 +95,9 @@ _lib = None
 # declared in the header, host-side only (no stream argument)
 HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice",
              "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes", "fs_conv2d_bwd_data_bnsum_slabs",
-             "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes", "fs_attention_bwd_split_ws_bytes", "fs_attention_mask_words", "fs_attention_bwd_split_parts_offset")
+             "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes", "fs_attention_bwd_split_ws_bytes", "fs_attention_mask_words", "fs_attention_bwd_split_parts_offset",
+             "fs_set_deterministic", "fs_get_deterministic", "fs_conv2d_bwd_weight_ws_bytes", "fs_linear_bwd_weight_bias_ws_bytes",
+             "fs_colsum_scratch_floats", "fs_bn_stats_scratch_doubles", "fs_mask_head_bwd_scratch_floats", "fs_layernorm_bwd_scratch_floats")
 
 
 class HipLibraryError(RuntimeError):
@@ -128,6 +130,22 @@ def load():
     lib.fs_set_conv_precision.argtypes = [_I]
     lib.fs_get_conv_precision.restype = _I
     lib.fs_get_conv_precision.argtypes = []
+    lib.fs_colsum_scratch_floats.restype = _L
+    lib.fs_colsum_scratch_floats.argtypes = [_L, _I]
+    lib.fs_bn_stats_scratch_doubles.restype = _L
+    lib.fs_bn_stats_scratch_doubles.argtypes = [_L, _I]
+    lib.fs_mask_head_bwd_scratch_floats.restype = _L
+    lib.fs_mask_head_bwd_scratch_floats.argtypes = [_L, _I]
+    lib.fs_layernorm_bwd_scratch_floats.restype = _L
+    lib.fs_layernorm_bwd_scratch_floats.argtypes = [_L, _I]
+    lib.fs_set_deterministic.restype = _I
+    lib.fs_set_deterministic.argtypes = [_I]
+    lib.fs_get_deterministic.restype = _I
+    lib.fs_get_deterministic.argtypes = []
+    lib.fs_conv2d_bwd_weight_ws_bytes.restype = _L
+    lib.fs_conv2d_bwd_weight_ws_bytes.argtypes = [_I] * 7
+    lib.fs_linear_bwd_weight_bias_ws_bytes.restype = _L
+    lib.fs_linear_bwd_weight_bias_ws_bytes.argtypes = [_I] * 2
     lib.fs_conv2d_workspace_bytes.restype = _L
     lib.fs_conv2d_workspace_bytes.argtypes = [_I] * 12
     lib.fs_conv2d_stats_slabs.restype = _I
@@ -176,6 +194,25 @@ def set_conv_precision(mode: str) -> None:
     if load().fs_set_conv_precision(code) != 0:
         raise HipLibraryError("fs_set_conv_precision rejected the mode")
     _ws_cache.clear()
+
+
+def set_deterministic(on: bool) -> None:
+    """Bit-reproducible training steps (the reference's cudnn.deterministic = True): bwd-weight sums its split-K partial tiles in index
+    order instead of by fp32 atomics (include/fovealseg.h fs_set_deterministic)."""
+    if load().fs_set_deterministic(1 if on else 0) != 0:
+        raise HipLibraryError("fs_set_deterministic failed")
+
+
+def get_deterministic() -> bool:
+    return bool(load().fs_get_deterministic())
+
+
+def wgrad_workspace(device, Cin, Cout, R, S, stride, pad, dil):
+    """(scratch tensor | None, bytes) for fs_conv2d_bwd_weight: the per-split partial tiles of deterministic mode, nothing otherwise."""
+    n = int(load().fs_conv2d_bwd_weight_ws_bytes(Cin, Cout, R, S, stride, pad, dil))
+    if n == 0:
+        return None, 0
+    return torch.empty(n, device=device, dtype=torch.uint8), n
 
 
 _ws_cache = {}

@@ -306,19 +306,22 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None, dil=1, accumulate=F
         return buf
     dw = rsck(out) if out is not None else torch.empty(R, S, Cin, Cout, device=x.device, dtype=torch.float32)
     k3 = R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 16 and Cout >= 16
+    dws, dws_bytes = hip.wgrad_workspace(x.device, Cin, Cout, R, S, stride, pad, dil)      # deterministic mode only
     _launch("wgrad3x3" if (k3 and hip.get_conv_precision() != "f32") else "conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin,
             "fs_conv2d_bwd_weight", hip.ptr(x), hip.ptr(dy), hip.ptr(dw),
-            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 1 if accumulate else 0)
+            B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 1 if accumulate else 0, hip.ptr(dws), dws_bytes)
     return out if out is not None else dw.permute(3, 2, 0, 1)
 
 
 def colsum(x2d_rows, C, into=None):
     """Column sums (bias gradients).  into = a gradient-arena target: the sums are ADDED to it and None is returned."""
+    M = x2d_rows.numel() // C
+    scratch = torch.empty(int(hip.load().fs_colsum_scratch_floats(M, C)), device=x2d_rows.device, dtype=torch.float32)
     if into is not None:
-        hip.call("fs_colsum", hip.ptr(x2d_rows), x2d_rows.numel() // C, C, hip.ptr(into), 1)
+        hip.call("fs_colsum", hip.ptr(x2d_rows), M, C, hip.ptr(into), 1, hip.ptr(scratch))
         return None
     out = torch.empty(C, device=x2d_rows.device, dtype=torch.float32)
-    hip.call("fs_colsum", hip.ptr(x2d_rows), x2d_rows.numel() // C, C, hip.ptr(out), 0)
+    hip.call("fs_colsum", hip.ptr(x2d_rows), M, C, hip.ptr(out), 0, hip.ptr(scratch))
     return out
 
 
@@ -549,7 +552,7 @@ class ConvBnAct(Function):
                      hip.ptr(meta["running_mean"]), hip.ptr(meta["running_var"]), hip.ptr(mean), hip.ptr(invstd))
             meta["num_batches_tracked"].add_(1)
         elif training:
-            sums = torch.empty(2 * C, device=y.device, dtype=torch.float64)
+            sums = torch.empty(int(hip.load().fs_bn_stats_scratch_doubles(M, C)), device=y.device, dtype=torch.float64)
             hip.call("fs_bn_stats", hip.ptr(y), M, C, float(meta["momentum"]), BN_EPS, hip.ptr(meta["running_mean"]),
                      hip.ptr(meta["running_var"]), hip.ptr(mean), hip.ptr(invstd), hip.ptr(sums))
             meta["num_batches_tracked"].add_(1)
@@ -680,8 +683,10 @@ class ConvBias(Function):
             btgt = _direct_grad_target(ctx.bias_ref)
             dw = rsck(tgt) if tgt is not None else torch.empty(1, 1, cin, cout, device=x.device, dtype=torch.float32)
             db = btgt if btgt is not None else torch.empty(cout, device=x.device, dtype=torch.float32)
+            lws_bytes = int(hip.load().fs_linear_bwd_weight_bias_ws_bytes(cin, cout))      # deterministic mode only
+            lws = torch.empty(lws_bytes, device=x.device, dtype=torch.uint8) if lws_bytes else None
             _launch("conv_wgrad", 2.0 * rows * cout * cin, "fs_linear_bwd_weight_bias", hip.ptr(x), hip.ptr(dy), hip.ptr(dw), hip.ptr(db),
-                    rows, cin, cout, 1 if tgt is not None else 0, 1 if btgt is not None else 0)
+                    rows, cin, cout, 1 if tgt is not None else 0, 1 if btgt is not None else 0, hip.ptr(lws), lws_bytes)
             return (dx, None if tgt is not None else dw.permute(3, 2, 0, 1), None if btgt is not None else db, None, None, None, None)
         dw = conv2d_bwd_weight(x, dy, w.shape, stride, pad, out=tgt, accumulate=tgt is not None)
         if tgt is not None:
@@ -799,8 +804,9 @@ class MaskHead(Function):
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         db = torch.empty(1, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(int(hip.load().fs_mask_head_bwd_scratch_floats(m.numel(), C)), device=x.device, dtype=torch.float32)
         hip.call("fs_mask_head_bwd", hip.ptr(dm), hip.ptr(m), hip.ptr(x), hip.ptr(w), hip.ptr(dx), hip.ptr(dw), hip.ptr(db),
-                 m.numel(), C)
+                 m.numel(), C, hip.ptr(scratch))
         return dx, dw, db
 
 
@@ -940,8 +946,9 @@ class CompressSoftmax(Function):
         ds = torch.empty_like(s)
         dw = torch.empty_like(w)
         db = torch.empty(1, device=s.device, dtype=torch.float32)
+        scratch = torch.empty(B * (C + 1), device=s.device, dtype=torch.float32)
         hip.call("fs_compress_softmax_bwd", hip.ptr(g.contiguous()), hip.ptr(xs), hip.ptr(s), hip.ptr(w), hip.ptr(ds), hip.ptr(dw),
-                 hip.ptr(db), B, H * W, C)
+                 hip.ptr(db), B, H * W, C, hip.ptr(scratch))
         return ds, dw, db
 
 
@@ -963,7 +970,9 @@ class Compress(Function):
         ds = torch.empty_like(s)
         dw = torch.empty_like(w)
         db = torch.empty(1, device=s.device, dtype=torch.float32)
-        hip.call("fs_compress_bwd", hip.ptr(g.contiguous()), hip.ptr(s), hip.ptr(w), hip.ptr(ds), hip.ptr(dw), hip.ptr(db), B, H * W, C)
+        scratch = torch.empty(B * (C + 1), device=s.device, dtype=torch.float32)
+        hip.call("fs_compress_bwd", hip.ptr(g.contiguous()), hip.ptr(s), hip.ptr(w), hip.ptr(ds), hip.ptr(dw), hip.ptr(db), B, H * W, C,
+                 hip.ptr(scratch))
         return ds, dw, db
 
 
@@ -1130,8 +1139,10 @@ class LayerNorm(Function):
         direct = tg is not None and tb is not None
         dgamma = tg if direct else torch.empty_like(gamma)
         dbeta = tb if direct else torch.empty_like(gamma)
+        M = x.numel() // C
+        scratch = torch.empty(int(hip.load().fs_layernorm_bwd_scratch_floats(M, C)), device=x.device, dtype=torch.float32)
         hip.call("fs_layernorm_bwd", hip.ptr(g.contiguous()), hip.ptr(x), hip.ptr(gamma), hip.ptr(mean), hip.ptr(rstd), hip.ptr(dx),
-                 hip.ptr(dgamma), hip.ptr(dbeta), x.numel() // C, C, 1 if direct else 0)
+                 hip.ptr(dgamma), hip.ptr(dbeta), M, C, 1 if direct else 0, hip.ptr(scratch))
         if direct:
             dgamma = dbeta = None
         return dx, dgamma, dbeta, None

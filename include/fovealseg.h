@@ -38,12 +38,14 @@ int fs_gaze_lowres_fwd(const float* x, const float* focus, float* out, int B, in
 /* CompressNet.forward on its own: s (B,HW,C) -> out (B,HW) = w . relu(s) + bias (the logits; C <= 32), and its backward
  * (ds, dw (C), db (1) overwritten).  models/models.py:360-372 (the plugin contract net_compress((B,24,.,.)) -> (B,1,.,.), call site :713). */
 int fs_compress_fwd(const float* s, const float* w, const float* bias, float* out, int B, int HW, int C, fs_stream_t stream);
+/* scratch (both backward entry points): B*(C+1) floats -- the per-image partial sums of dw and db, added in image order (every
+ * cross-workgroup sum of this library is two launches, partials then an ordered sum: no result depends on workgroup timing). */
 int fs_compress_bwd(const float* g, const float* s, const float* w, float* ds, float* dw, float* db, int B, int HW, int C,
-                    fs_stream_t stream);
+                    float* scratch, fs_stream_t stream);
 /* s (B,HW,C) -> xs (B,HW) = softmax_HW(w . relu(s) + bias).  models/models.py:369-372,715-723. */
 int fs_compress_softmax_fwd(const float* s, const float* w, const float* bias, float* xs, int B, int HW, int C, fs_stream_t stream);
 int fs_compress_softmax_bwd(const float* g, const float* xs, const float* s, const float* w, float* ds, float* dw, float* db,
-                            int B, int HW, int C, fs_stream_t stream);
+                            int B, int HW, int C, float* scratch, fs_stream_t stream);
 /* y (B,1,H,W) -> (B,1,hs,ws) adaptive area average.  models/models.py:730. */
 int fs_area_pool_fwd(const float* y, float* out, int B, int H, int W, int hs, int ws, fs_stream_t stream);
 /* loss = coef * mean((minmax(xs) - minmax(t))^2) with whole-batch min/max; stats = 6 floats kept for bwd.
@@ -96,6 +98,14 @@ int fs_inverse_index_maps(const float* grid, long long* u, long long* v, long n,
  * else the entry points need comes in through their arguments. */
 int fs_set_conv_precision(int mode);
 int fs_get_conv_precision(void);
+/* Deterministic mode -- the reference asks for it with torch.backends.cudnn.deterministic = True (train_deform_semantic.py:680-681).
+ * By default the bwd-weight kernels add their split-K partial tiles with fp32 atomics, whose order is the workgroups' arrival order:
+ * two runs of the same step differ in the last bits of the weight gradients.  on = 1 (or FS_DETERMINISTIC=1 in the environment at
+ * load time): every split writes its partial tile to its own slab of a caller-provided scratch and the slabs are summed in index
+ * order; every other reduction of the library is order-fixed in both modes.  Two runs of a training step are then bit-identical.
+ * Process-global host-side word like the precision mode (same rules); costs one memset + one reduce launch per bwd-weight call. */
+int fs_set_deterministic(int on);
+int fs_get_deterministic(void);
 /* Scratch the forward (transposed=0) / bwd-data (transposed=1) entry points can use for this shape, in bytes
  * (0 = none).  In split-precision mode 3x3 / stride 1 / pad 1 convolutions with >= 32 input channels run as a
  * halo-tiled kernel that first packs the weights, already split into bf16 terms, into this scratch; without
@@ -164,16 +174,22 @@ int fs_conv2d_bwd_data_bnsum(const float* dy, const float* w, float* dx, int B, 
  * bf16x3 mode for Cin, Cout multiples of 4 and >= 16 (fs_linear_bwd_weight_bias_ok == 1); otherwise FS_ERR_ARG -- callers then use
  * fs_conv2d_bwd_weight + fs_colsum.  accumulate_w / accumulate_b as `accumulate` below. */
 int fs_linear_bwd_weight_bias_ok(long rows, int Cin, int Cout);
+long fs_linear_bwd_weight_bias_ws_bytes(int Cin, int Cout);
 int fs_linear_bwd_weight_bias(const float* x, const float* dy, float* dw, float* dbias, long rows, int Cin, int Cout, int accumulate_w,
-                              int accumulate_b, fs_stream_t stream);
+                              int accumulate_b, void* ws, long ws_bytes, fs_stream_t stream);
 /* accumulate = 0: dw is overwritten; 1: the gradient is ADDED to dw (torch's .grad accumulation; saves the memset when the caller
- * keeps a zeroed gradient arena). */
+ * keeps a zeroed gradient arena).  ws / ws_bytes: scratch for the per-split partial tiles of deterministic mode --
+ * fs_conv2d_bwd_weight_ws_bytes (0 outside that mode; ws may then be NULL).  In deterministic mode a missing or short scratch is
+ * FS_ERR_ARG: the call never falls back to the atomics silently. */
+long fs_conv2d_bwd_weight_ws_bytes(int Cin, int Cout, int R, int S, int stride, int pad, int dil);
 int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                         int R, int S, int stride, int pad, int dil, int accumulate, fs_stream_t stream);
+                         int R, int S, int stride, int pad, int dil, int accumulate, void* ws, long ws_bytes, fs_stream_t stream);
 
 /* ---- BatchNorm / activation / residual ------------------------------------------------------ */
 /* F.batch_norm(training=True) statistics over M rows; running stats updated in place (nullable).
- * lib/nn/modules/batchnorm.py:56-61.  sums = 2*C doubles scratch. */
+ * lib/nn/modules/batchnorm.py:56-61.  sums = fs_bn_stats_scratch_doubles(M, C) doubles of scratch (per-row-block records, added in
+ * block order). */
+long fs_bn_stats_scratch_doubles(long M, int C);
 int fs_bn_stats(const float* y, long M, int C, float momentum, float eps, float* running_mean, float* running_var, float* mean,
                 float* invstd, double* sums, fs_stream_t stream);
 int fs_bn_finalize_slab(const float* slab, int nwg, long M, int C, float momentum, float eps, float* running_mean,
@@ -223,8 +239,10 @@ int fs_upsample_slice_fwd(const float* src, int B, int th, int tw, int C, float*
                           fs_stream_t stream);
 int fs_upsample_slice_bwd(const float* g, int B, int Ho, int Wo, int Cg, int coff, float* dsrc, int th, int tw, int C,
                           fs_stream_t stream);
-/* column sums of M rows of C floats (bias gradients); accumulate != 0: ADDED to out (a gradient-arena target), else overwritten. */
-int fs_colsum(const float* x, long M, int C, float* out, int accumulate, fs_stream_t stream);
+/* column sums of M rows of C floats (bias gradients); accumulate != 0: ADDED to out (a gradient-arena target), else overwritten.
+ * scratch = fs_colsum_scratch_floats(M, C) floats (per-row-block partial sums, added in block order). */
+long fs_colsum_scratch_floats(long M, int C);
+int fs_colsum(const float* x, long M, int C, float* out, int accumulate, float* scratch, fs_stream_t stream);
 /* nn.MaxPool2d(k, stride, pad) on NHWC; arg = flat input pixel index of the maximum (int32), used by the backward.
  * torchvision ResNet stem behind models/deeplab.py:15. */
 int fs_maxpool_fwd(const float* x, float* out, int* arg, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad,
@@ -240,8 +258,10 @@ int fs_avgpool_bwd(const float* dout, int B, int HW, int C, float* dx, fs_stream
 /* ---- C1 head tail + losses --------------------------------------------------------------------- */
 /* m = sigmoid(w . x + bias) - 0.5 per pixel.  models/model_utils.py:293-298. */
 int fs_mask_head_fwd(const float* x, const float* w, const float* bias, float* m, long npix, int C, fs_stream_t stream);
+/* scratch = fs_mask_head_bwd_scratch_floats(npix, C) floats (per-workgroup partial sums of dw and db, added in workgroup order) */
+long fs_mask_head_bwd_scratch_floats(long npix, int C);
 int fs_mask_head_bwd(const float* dm, const float* m, const float* x, const float* w, float* dx, float* dw, float* db, long npix,
-                     int C, fs_stream_t stream);
+                     int C, float* scratch, fs_stream_t stream);
 /* pred (B,K,HW) NCHW: pred[:, :K-1] = cls, pred[:, K-1] = cls[K-1]*m.  models/model_utils.py:300-306. */
 int fs_pred_assemble_fwd(const float* cls, const float* m, float* pred, int B, int K, int HW, fs_stream_t stream);
 int fs_pred_assemble_bwd(const float* dpred, const float* cls, const float* m, float* dcls, float* dm, int B, int K, int HW,
@@ -259,9 +279,11 @@ int fs_seg_loss_bwd(const float* pred, const long long* gt, const float* coef, c
 /* nn.LayerNorm(C, eps) over the last dim of M rows; mean/rstd (M floats each) kept for the backward. */
 int fs_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long M, int C,
                      float eps, fs_stream_t stream);
-/* accumulate != 0: dgamma / dbeta are ADDED to (gradient-arena targets), else overwritten. */
+/* accumulate != 0: dgamma / dbeta are ADDED to (gradient-arena targets), else overwritten.  scratch =
+ * fs_layernorm_bwd_scratch_floats(M, C) floats (per-workgroup records of the two column sums, added in workgroup order). */
+long fs_layernorm_bwd_scratch_floats(long M, int C);
 int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
-                     float* dgamma, float* dbeta, long M, int C, int accumulate, fs_stream_t stream);
+                     float* dgamma, float* dbeta, long M, int C, int accumulate, float* scratch, fs_stream_t stream);
 /* exact (erf) GELU. */
 int fs_gelu_fwd(const float* x, float* y, long n, fs_stream_t stream);
 int fs_gelu_bwd(const float* g, const float* x, float* dx, long n, fs_stream_t stream);

@@ -281,11 +281,16 @@ def test_reference_ddp_wrapper_line_on_gpu():
 
 @pytest.mark.gpu
 def test_train_step_through_one_rank_rccl_group():
-    """VERDICT r2 #6b: with a process group of ONE rank on the nccl (= RCCL) backend the step takes the same code path as N > 1 --
-    communicator bound to the device (`device_id`), buffer broadcast before the forward, one all-reduce per arena after a
-    backward that ran on four side streams -- and must give the step it gives without a group."""
+    """VERDICT r2 #6b / r3 #3: with a process group of ONE rank on the nccl (= RCCL) backend the step takes the same code path as N > 1 --
+    communicator bound to the device (`device_id`), buffer broadcast before the forward, one all-reduce per arena after a backward that
+    ran on four side streams -- and must give the step it gives without a group.
+    Settled from evidence, not from a widened bound: in DETERMINISTIC mode (hip.set_deterministic: bwd-weight sums its split-K partial
+    tiles in index order; every other reduction of the library is order-fixed in both modes) two runs of two train_steps WITHOUT a group
+    are bit-identical, and the run through the 1-rank RCCL group is bit-identical to them -- so the collective path adds no missing stream
+    dependency and no arithmetic of its own.  In the default mode the same three runs differ by the order of the bwd-weight atomics only,
+    and the bound on group-vs-no-group is the spread of a no-group / no-group pair measured here (x4 margin), not a constant."""
     import fovealseg
-    from fovealseg import ops
+    from fovealseg import ops, hip
     assert not dist.is_initialized()
     dev = torch.device("cuda", 0)
     cfg = fovealseg.lvis50_cfg()
@@ -305,30 +310,52 @@ def test_train_step_through_one_rank_rccl_group():
             losses.append(float(o[0]))
         torch.cuda.synchronize()
         return losses, [op.flat.data.clone() for op in optimizers], [op.grad_scale for op in optimizers]
-    base_losses, base_params, _ = run(group=False)
-    saved = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+
+    def run_in_group():
+        saved = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        try:
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+            assert train._collectives_on() and dist.get_backend() == "nccl"
+            out = run(group=True)
+            dist.barrier()
+            return out
+        finally:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    # ---- deterministic mode: all three runs bit-identical ----
+    assert not hip.get_deterministic()
+    hip.set_deterministic(True)
     try:
-        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
-        assert train._collectives_on() and dist.get_backend() == "nccl"
-        losses, params, scales = run(group=True)
-        dist.barrier()
+        la, pa, _ = run(group=False)
+        lb, pb, _ = run(group=False)
+        lg, pg, scales = run_in_group()
     finally:
-        if dist.is_initialized():
-            dist.destroy_process_group()
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        hip.set_deterministic(False)
     assert scales == [1.0] * 4
-    for a, b in zip(base_losses, losses):
-        # bwd-weight float atomics reorder: not bit-identical.  The first loss is (measured: bit-equal), the second sits behind one Adam
-        # update whose +-lr steps on near-zero gradients can flip with the summation order: run-to-run spread up to 2.2e-5 relative
-        assert abs(a - b) <= 6e-5 * max(1.0, abs(a)), (base_losses, losses)
-    # Adam moves an element by at most lr (= 1e-4 here) per step whatever the size of its gradient, so where a gradient is within the
-    # atomics' rounding of zero the two runs can step in opposite directions: the worst element differs by <= 2 steps x 2 lr, while the
-    # arena as a whole stays at the rounding level
-    for p0, p1 in zip(base_params, params):
-        d = (p0 - p1).abs()
-        assert float(d.max()) <= 4.1e-4 and float(d.mean()) <= 1e-5, (float(d.max()), float(d.mean()))
+    assert la == lb == lg, (la, lb, lg)
+    for x, y, z in zip(pa, pb, pg):
+        assert torch.equal(x, y), "two deterministic runs without a group differ"
+        assert torch.equal(x, z), "the deterministic run through the 1-rank RCCL group differs from the run without a group"
+
+    # ---- default mode: the group run sits inside the run-to-run spread of the atomics ----
+    l0, p0, _ = run(group=False)
+    l1, p1, _ = run(group=False)
+    l2, p2, _ = run_in_group()
+    assert l0[0] == l1[0] == l2[0] or abs(l0[0] - l2[0]) <= 1e-6 * abs(l0[0])       # first loss: before any update
+    spread_loss = max(abs(a - b) for a, b in zip(l0, l1))
+    spread_mean = max(float((a - b).abs().mean()) for a, b in zip(p0, p1))
+    for a, b in zip(l0, l2):
+        assert abs(a - b) <= 4.0 * max(spread_loss, 1e-5 * abs(a)), (l0, l1, l2)
+    # Adam moves an element by at most lr (1e-4 here) per step whatever the size of its gradient, so an element whose gradient is within
+    # the atomics' rounding of zero can step in opposite directions in two runs: worst element <= 2 steps x 2 lr in ANY pair of runs;
+    # the arena as a whole stays at the level the no-group pair shows
+    for a, b in zip(p0, p2):
+        d = (a - b).abs()
+        assert float(d.max()) <= 4.1e-4 and float(d.mean()) <= 4.0 * max(spread_mean, 1e-7), (float(d.max()), float(d.mean()), spread_mean)
