@@ -27,7 +27,7 @@ struct TsArgs {
   int Hq, Wq, os, oy0, ox0, sm;
   int ncls;
   FsTapClass cls[9];
-  int Npad, nchunk, ttot;
+  int Npad, nchunk, ttot, nw;
   int Ph, Pw, tiles_y, tiles_x, nx, ny;
   unsigned src_bytes, wp_bytes, dst_bytes;
   unsigned magic_pw, magic_wh[8];      // div_small1 magics of Pw and of the halo width Pw + nS - 1, nS = 1..8
@@ -81,7 +81,11 @@ __global__ __launch_bounds__(256) void conv_tapset_pack_kernel(const float* __re
   }
 }
 
-template <class P>
+// NW = 32-column sub-tiles per wave (conv_halo.hip): the workgroup covers 64 * NW destination channels, so every class halo is loaded and
+// split once for twice the MFMAs when NW = 2.  Round 4 (SQ counters, profiles/r04/pmc/sq_bf16x3_conv_tapset_kernel_fwd_shape7.txt):
+// the 64-column form runs 9.2 VALU instructions per MFMA on 64 -> 128 stride 2 with the matrix pipe 37 % busy -- the split / address
+// work of a (class, chunk) refill feeds only 24-96 MFMAs per wave -- so it is bound by the vector ALU, not by the matrix cores or HBM.
+template <class P, int NW>
 __global__ __launch_bounds__(256) void conv_tapset_kernel(TsArgs a) {
   typedef typename P::x8 X8;
   typedef typename P::x4 X4;
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_tapset_kernel(TsArgs a) {
   const int qd = nwg >> 3, rm = nwg & 7;
   const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + loc;
   const int mt = wg / a.ny;
-  const int n0 = (wg - mt * a.ny) * 64;
+  const int n0 = (wg - mt * a.ny) * 64 * NW;
   const int tpi = a.tiles_y * a.tiles_x;
   const int b = mt / tpi;
   const int trem = mt - b * tpi;
@@ -182,18 +186,26 @@ __global__ __launch_bounds__(256) void conv_tapset_kernel(TsArgs a) {
   const int plane_bytes = a.Npad * 32;
   const int step_bytes = NPL * plane_bytes;
   const int G = 2 * a.ttot;
-  auto load_b = [&](int g, X8 (&dst)[NPL]) {
+  auto load_b = [&](int g, X8 (&dst)[NW][NPL]) {
     const int gg = g < G ? g : G - 1;
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff, gg * step_bytes + pl * plane_bytes, 0);
-      dst[pl] = __builtin_bit_cast(X8, v);
-    }
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, bvoff + j * 2048, gg * step_bytes + pl * plane_bytes, 0);      // sub-tile j: + 64 columns
+        dst[j][pl] = __builtin_bit_cast(X8, v);
+      }
   };
 
-  f32x16 acc0 = {0}, acc1 = {0};
+  f32x16 acc[2][NW];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.f;
   X8 fa[2][2][NPL];         // [k16 step][mi][plane]
-  X8 fbA[2][NPL], fbB[2][NPL];
+  X8 fbA[2][NW][NPL], fbB[2][NW][NPL];
   int E = EMIN, par = 0;
   // MFMA-loop state
   int c = 0, chunk = 0, tap = 0, tr = 0, ts = 0;
@@ -207,15 +219,17 @@ __global__ __launch_bounds__(256) void conv_tapset_kernel(TsArgs a) {
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) dst[mi][pl] = *reinterpret_cast<const X8*>(&Ah[pl * PLANE + rowbase[mi] + toff + 16 * s2]);
   };
-  auto mfmas = [&](const X8 (&A)[2][NPL], const X8 (&Bf)[NPL]) {
+  auto mfmas = [&](const X8 (&A)[2][NPL], const X8 (&Bf)[NW][NPL]) {
 #pragma unroll
-    for (int t = 0; t < P::NTERM; ++t) {           // smallest terms first, the two pixel halves interleaved
-      acc0 = P::mfma(A[0][P::ta(t)], Bf[P::tb(t)], acc0);
-      acc1 = P::mfma(A[1][P::ta(t)], Bf[P::tb(t)], acc1);
-    }
+    for (int j = 0; j < NW; ++j)
+#pragma unroll
+      for (int t = 0; t < P::NTERM; ++t) {           // smallest terms first, the two pixel halves interleaved
+        acc[0][j] = P::mfma(A[0][P::ta(t)], Bf[j][P::tb(t)], acc[0][j]);
+        acc[1][j] = P::mfma(A[1][P::ta(t)], Bf[j][P::tb(t)], acc[1][j]);
+      }
   };
   // one filter tap = two k16 steps; `cur` holds this tap's B fragments, `nxt` receives the next tap's
-  auto tap_body = [&](X8 (&cur)[2][NPL], X8 (&nxt)[2][NPL]) {
+  auto tap_body = [&](X8 (&cur)[2][NW][NPL], X8 (&nxt)[2][NW][NPL]) {
     if (tap == 0) {                      // first tap of a (class, chunk): refill LDS
       if (chunk == 0) {
         ntaps = a.cls[c].nR * a.cls[c].nS; nS = a.cls[c].nS; Wh = a.Pw + nS - 1;
@@ -229,7 +243,11 @@ __global__ __launch_bounds__(256) void conv_tapset_kernel(TsArgs a) {
         if (ec > E) {
           const float f = pow2f(E - ec);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { acc0[r] *= f; acc1[r] *= f; }
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mi][j][r] *= f;
           E = ec;
         }
         par ^= 1;
@@ -276,19 +294,22 @@ __global__ __launch_bounds__(256) void conv_tapset_kernel(TsArgs a) {
   __syncthreads();     // rowpix visible (and all LDS reads done before the stats scratch reuse)
 
   // ---- epilogue ----
-  const int n = n0 + 32 * wn + l31;
-  float csum = 0.f, csq = 0.f;
-  if (n < a.Cd) {
+  float csum[NW], csq[NW];
+  float f1 = 1.f, f2 = 1.f;
+  if (P::SCALED) {
+    const int Ew = exponent_of_bits(*a.ew);
+    const int es = E + Ew - 28;
+    const bool one = es >= -126 && es <= 127;
+    f1 = one ? pow2f(es) : pow2f(E - 14);
+    f2 = one ? 1.f : pow2f(Ew - 14);
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    csum[j] = 0.f; csq[j] = 0.f;
+    const int n = n0 + 64 * j + 32 * wn + l31;
+    if (n >= a.Cd) continue;
     const float bv = (a.bias != nullptr) ? a.bias[n] : 0.f;
-    float f1 = 1.f, f2 = 1.f;
-    if (P::SCALED) {
-      const int Ew = exponent_of_bits(*a.ew);
-      const int es = E + Ew - 28;
-      const bool one = es >= -126 && es <= 127;
-      f1 = one ? pow2f(es) : pow2f(E - 14);
-      f2 = one ? 1.f : pow2f(Ew - 14);
-    }
-    const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -299,24 +320,28 @@ __global__ __launch_bounds__(256) void conv_tapset_kernel(TsArgs a) {
           const int r = 4 * rg + ri;
           const bool live = pix[ri] >= 0;
           const unsigned e = (unsigned)pix[ri] * (unsigned)a.Cd + (unsigned)n;
-          float v = P::SCALED ? fmaf((mi == 0 ? acc0[r] : acc1[r]) * f2, f1, bv) : (mi == 0 ? acc0[r] : acc1[r]) + bv;
+          float v = P::SCALED ? fmaf(acc[mi][j][r] * f2, f1, bv) : acc[mi][j][r] + bv;
           if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
           v = live ? v : 0.f;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
-          csum += v; csq += v * v;
+          csum[j] += v; csq[j] += v * v;
         }
       }
     }
   }
   if (a.stats != nullptr) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(&Ah[0]);     // [wm][64 cols][2]
-    const float s1 = csum + __shfl_xor(csum, 32, 64), s2 = csq + __shfl_xor(csq, 32, 64);
-    if (lh == 0) { red[(wm * 64 + 32 * wn + l31) * 2] = s1; red[(wm * 64 + 32 * wn + l31) * 2 + 1] = s2; }
+    float* red = reinterpret_cast<float*>(&Ah[0]);     // [wm][64 * NW cols][2]
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const float s1 = csum[j] + __shfl_xor(csum[j], 32, 64), s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
+      const int col = 64 * j + 32 * wn + l31;
+      if (lh == 0) { red[(wm * 64 * NW + col) * 2] = s1; red[(wm * 64 * NW + col) * 2 + 1] = s2; }
+    }
     __syncthreads();
-    if (tid < 128) {
-      const int col = tid >> 1, which = tid & 1;
-      const float v = red[col * 2 + which] + red[(64 + col) * 2 + which];
+    for (int t = tid; t < 128 * NW; t += 256) {
+      const int col = t >> 1, which = t & 1;
+      const float v = red[col * 2 + which] + red[(64 * NW + col) * 2 + which];
       if (n0 + col < a.Cd) a.stats[((long)mt * a.Cd + n0 + col) * 2 + which] = v;
     }
   }
@@ -340,7 +365,7 @@ void fs_tapset_patch(int Hq, int Wq, int maxR, int maxS, int* Ph, int* Pw) {
 }
 
 long fs_tapset_pack_bytes(int mode, int Cs, int Cd, int total_taps) {
-  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 63) / 64) * 64;
+  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 127) / 128) * 128;       // room for either column tiling
   return HDR + nchunk * total_taps * 2 * (mode == 2 ? 2 : 3) * Npad * 16 * 2;
 }
 
@@ -361,7 +386,11 @@ int run_tapset(TsArgs& a, const FsTapsetProblem& p, hipStream_t stream) {
                      reinterpret_cast<unsigned char*>(p.ws), a.ew, p.Cin, p.Cout, p.S, p.transposed, p.Cs, p.Cd, a.Npad, a.nchunk, a.ncls,
                      a.cls[0], a.cls[1], a.cls[2], a.cls[3], a.cls[4], a.cls[5], a.cls[6], a.cls[7], a.cls[8], total);
   FS_LAUNCH_CHECK();
-  hipLaunchKernelGGL((conv_tapset_kernel<P>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+#ifdef FS_EXPERIMENTS          // the 128-column form is measured-and-rejected (below): only the A/B build carries it
+  if (a.nw == 2) hipLaunchKernelGGL((conv_tapset_kernel<P, 2>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+  else
+#endif
+  hipLaunchKernelGGL((conv_tapset_kernel<P, 1>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -384,7 +413,7 @@ int fs_tapset_conv(int mode, const FsTapsetProblem& p, hipStream_t stream) {
     }
   }
   if (p.ncls < 1 || p.ncls > 9 || total_taps < 1) return FS_ERR_ARG;
-  a.Npad = ((p.Cd + 63) / 64) * 64;
+  a.Npad = ((p.Cd + 127) / 128) * 128;
   a.nchunk = (p.Cs + 31) / 32;
   a.ttot = a.nchunk * total_taps;
   fs_tapset_patch(p.Hq, p.Wq, maxR, maxS, &a.Ph, &a.Pw);
@@ -394,7 +423,14 @@ int fs_tapset_conv(int mode, const FsTapsetProblem& p, hipStream_t stream) {
   if (maxS > 8) return FS_ERR_ARG;
   for (int ns = 1; ns <= 8; ++ns) a.magic_wh[ns - 1] = div_magic1(a.Pw + ns - 1);
   a.nx = p.B * a.tiles_y * a.tiles_x;
-  a.ny = a.Npad / 64;
+  // 128-column workgroups (two sub-tiles per wave: every class halo split once for twice the MFMAs) were measured against the 64-column
+  // form in one gpurun call (profiles/r04/tapset_nw_ab.txt, us, bf16x3, B = 64): forward 64 -> 128 s2 @ 80x80 145 -> 159, 128 -> 256 @ 40x40
+  // 151 -> 152, 256 -> 512 @ 20x20 146 -> 143-151, 512 -> 512 @ 20x20 277 -> 279; bwd-data the same or slower.  Every strided shape sits at
+  // ~100 TF whatever its K: what bounds the kernel is the number of (class, chunk) LDS refills -- two barriers and a split phase around
+  // 24-96 MFMAs per wave -- not the split work per MFMA.  Policy 0 (shipped) = 64 columns; 1 / 2 only in the A/B build.
+  static const int nw_pol = FS_ENV_INT("FS_TAPSET_NW", 0);
+  a.nw = (nw_pol != 0 && p.Cd >= 128 && (nw_pol == 2 || (long)a.nx * (a.Npad / 128) >= 440)) ? 2 : 1;
+  a.ny = a.nw == 2 ? a.Npad / 128 : (p.Cd + 63) / 64;
   const long pack_bytes = fs_tapset_pack_bytes(mode, p.Cs, p.Cd, total_taps);
   if (pack_bytes >= 2147483647L || (size_t)p.B * p.Hs * p.Ws * p.Cs * 4 >= 4294967000UL || (size_t)p.B * p.Hd * p.Wd * p.Cd * 4 >= 4294967000UL)
     return FS_ERR_ARG;

@@ -1133,8 +1133,13 @@ direct:
     l.part = FsPart{nullptr, 0}; l.bpart = nullptr;
     return run_linear_wgrad(l, ph, stream);
   }
-  static const bool planes_on = FS_ENV_INT("FS_WGRAD_PLANES", 1) != 0;      // kernel A/B builds only
-  if (planes_on && R == 3 && S == 3 && (stride == 2 || stride == 3)) {
+  // Measured in one gpurun call against the per-class launches (profiles/r04/wgrad_s2_planes_ab.txt, us, bf16x3, B = 64): 64 -> 64 @ 80x80
+  // 164 -> 123, but 64 -> 128 @ 80x80 158-165 -> 166-172, 128 -> 256 @ 40x40 167 -> 174, 256 -> 512 @ 20x20 176 -> 177: the launch is one
+  // round of 512 workgroups whose time is (patch rounds per workgroup) x ~7 us of load -> split -> barrier -> MFMA latency plus ~80 us
+  // of split-K atomics (512 x 147 KB at the L2's one dword per channel and clock), and neither term depends on how the taps are grouped;
+  // only a single channel tile (twice the splits, half the rounds) gains.  planes policy 1 = those layers, 2 = every strided 3x3, 0 = off.
+  static const int planes_pol = FS_ENV_INT("FS_WGRAD_PLANES", 1);      // kernel A/B builds only
+  if (planes_pol != 0 && (planes_pol == 2 || ntile == 1) && R == 3 && S == 3 && (stride == 2 || stride == 3)) {
     // all nine taps of a strided 3x3 filter in one launch (parity planes of the X halo in LDS)
     MpArgs m;
     m.x = x; m.dy = dy; m.dw = dw; m.B = B; m.H = Ho; m.W = Wo; m.Hx = H; m.Wx = W; m.Cin = Cin; m.Cout = Cout;

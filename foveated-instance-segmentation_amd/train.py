@@ -257,6 +257,9 @@ def broadcast_buffers(module, src=0):
     dist.broadcast(flat.data, src=src)
 
 
+COMM_EVENTS = None      # bench.py: a list that receives one (start, stop) HIP-event pair per gradient exchange (the four arena all-reduces)
+
+
 def allreduce_gradients(optimizers, module=None):
     """Gradient average across ranks: one SUM all-reduce per arena; the 1/world is folded into Adam.
     `module` wrapped by torch's DistributedDataParallel (the reference's call site, train_deform_semantic.py:395): its reducer has
@@ -266,9 +269,16 @@ def allreduce_gradients(optimizers, module=None):
             opt.grad_scale = 1.0
         return
     world = dist.get_world_size()
+    timed = COMM_EVENTS is not None and optimizers[0].flat.grad.is_cuda
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     for opt in optimizers:
         dist.all_reduce(opt.flat.grad, op=dist.ReduceOp.SUM)
         opt.grad_scale = 1.0 / world
+    if timed:
+        ev1.record()          # (the process group's stream is joined to the current stream by the collective's own event hand-off)
+        COMM_EVENTS.append((ev0, ev1))
 
 
 def shard_indices(n_samples, rank, world, epoch_seed=0, shuffle=True):

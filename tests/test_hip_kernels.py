@@ -127,6 +127,8 @@ CONV_CASES = [
     (2, 10, 10, 64, 64, 3, 1, False, 2),    # dilation 2 (DeepLab layer3)
     (1, 10, 10, 128, 64, 3, 1, False, 12),  # ASPP rate 12: only the centre tap is in range
     (2, 23, 17, 3, 64, 7, 2, False),        # ResNet stem 7x7 stride 2 (generic kernel)
+    (3, 21, 19, 48, 64, 3, 2, False),       # one channel tile, stride 2: bwd-weight with all nine taps in one launch (parity planes), ragged
+    (2, 40, 40, 64, 64, 3, 2, True),        # the HRNet fuse down-path shape of that kernel
 ]
 
 
@@ -163,7 +165,7 @@ def test_conv_fwd_bwd(case, prec):
 # them in index order: two calls are bit-identical, equal the atomics' result to rounding, accumulate on top of an existing gradient,
 # and a missing scratch is an error, never a silent fall-back to the atomics.
 DET_WGRAD_CASES = [
-    (8, 40, 40, 64, 64, 3, 1), (4, 40, 40, 64, 128, 3, 2), (2, 40, 40, 96, 64, 3, 4), (4, 80, 80, 192, 24, 3, 1),
+    (8, 40, 40, 64, 64, 3, 1), (4, 40, 40, 64, 128, 3, 2), (4, 40, 40, 64, 64, 3, 2), (2, 40, 40, 96, 64, 3, 4), (4, 80, 80, 192, 24, 3, 1),
     (4, 40, 40, 64, 256, 1, 1), (4, 20, 20, 256, 64, 1, 1), (2, 16, 16, 64, 64, 1, 2), (3, 1, 1, 512, 51, 1, 1), (2, 23, 17, 3, 64, 7, 2),
 ]
 

@@ -23,6 +23,10 @@ SHAPES = [  # B, H, W, Cin, Cout, k, stride
     (64, 80, 80, 960, 512, 3, 4),     # C1 classification head: stride > filter reach, every tap class is a single tap
     (64, 80, 80, 960, 512, 1, 4),
     (64, 20, 20, 512, 512, 3, 2),
+    (64, 80, 80, 64, 64, 3, 2),       # [12..15] the HRNet fuse down-paths (round 4)
+    (64, 40, 40, 128, 256, 3, 2),
+    (64, 40, 40, 64, 256, 3, 2),
+    (64, 20, 20, 256, 512, 3, 2),
 ]
 
 # the linear layers of configs[3] (SegFormer-B5 at 160x160, B=16) as 1x1 convs over (1, tokens, 1, C): MB_SET=segformer
