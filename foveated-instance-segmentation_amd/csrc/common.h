@@ -33,16 +33,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // activation codes shared with the host side
 enum { FS_ACT_NONE = 0, FS_ACT_RELU = 1, FS_ACT_RELU6 = 2 };
 
-// Dropout keep decision for linear element index e (NHWC order) -- integer hash, restated in
-// numpy by oracle/fovealseg_oracle.py:dropout_keep_mask_nhwc for replay tests.
-__device__ __forceinline__ bool fs_dropout_keep(uint32_t e, uint32_t key, uint32_t thresh) {
-  uint32_t h = e * 0x9E3779B1u + key;
+// Dropout keep decision for linear element index e (NHWC order) -- integer hash, restated in numpy by
+// oracle/fovealseg_oracle.py:dropout_keep_mask_nhwc for replay tests.  One 32-bit hash (Weyl step + the murmur3 finaliser) serves the
+// element PAIR (e >> 1): element 2i takes its low 16 bits, element 2i + 1 its high 16 bits, each compared with the 16-bit threshold
+// thresh >> 16 (p = 0.3: 19660 / 65536, 1e-5 from p).  v_mul_lo_u32 is a quarter-rate instruction and the finaliser has two of them:
+// the F(2,3) forward epilogue hashes 32 outputs per thread -- 72 such multiplies per tile, a fifth of its epilogue time -- so halving
+// the hashes per element is worth having (round 4); a one-multiply finaliser shows 0.2-0.5 % lag and 6 % cross-key correlation of
+// the masks and was rejected on that.
+__device__ __forceinline__ uint32_t fs_dropout_hash(uint32_t pair, uint32_t key) {
+  uint32_t h = pair * 0x9E3779B1u + key;
   h ^= h >> 16;
   h *= 0x85EBCA6Bu;
   h ^= h >> 13;
   h *= 0xC2B2AE35u;
   h ^= h >> 16;
-  return h >= thresh;
+  return h;
+}
+__device__ __forceinline__ bool fs_dropout_keep(uint32_t e, uint32_t key, uint32_t thresh) {
+  const uint32_t h = fs_dropout_hash(e >> 1, key);
+  return ((e & 1u) ? (h >> 16) : (h & 0xffffu)) >= (thresh >> 16);
+}
+// the same for four consecutive elements e .. e + 3 with e EVEN: bit j of the result = fs_dropout_keep(e + j); two hashes
+__device__ __forceinline__ uint32_t fs_dropout_keep4(uint32_t e, uint32_t key, uint32_t thresh) {
+  const uint32_t t = thresh >> 16;
+  const uint32_t h0 = fs_dropout_hash(e >> 1, key), h1 = fs_dropout_hash((e >> 1) + 1u, key);
+  return ((h0 & 0xffffu) >= t ? 1u : 0u) | ((h0 >> 16) >= t ? 2u : 0u) | ((h1 & 0xffffu) >= t ? 4u : 0u) | ((h1 >> 16) >= t ? 8u : 0u);
 }
 
 __device__ __forceinline__ float fs_act(float v, int act) {

@@ -461,10 +461,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
           const bool live = pix >= 0 && nok;
           const unsigned e = (unsigned)(pix + n + cp * a.Cd);                 // the {2,3} waves write the odd pixel of the pair
           f32x4 v;
+          const uint32_t keep = a.drop_thresh != 0u ? fs_dropout_keep4((uint32_t)e, a.drop_key, a.drop_thresh) : 15u;      // e is a multiple of 4
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float x = P::SCALED ? fmaf(m[j] * f2, f1, bv[j]) : m[j] + bv[j];
-            if (a.drop_thresh != 0u) x = fs_dropout_keep((uint32_t)(e + j), a.drop_key, a.drop_thresh) ? x * a.drop_scale : 0.f;
+            if (a.drop_thresh != 0u) x = ((keep >> j) & 1u) ? x * a.drop_scale : 0.f;
             v[j] = live ? x : 0.f;
           }
           if (a.ep_scale != nullptr && live) {
@@ -853,10 +854,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_kernel(WinoArgs a) {
           const bool live = pix >= 0 && nok;
           const unsigned e = (unsigned)(pix + n + cp * a.Cd);                 // the {2,3} waves write the odd pixel of the pair
           f32x4 v;
+          const uint32_t keep = a.drop_thresh != 0u ? fs_dropout_keep4((uint32_t)e, a.drop_key, a.drop_thresh) : 15u;      // e is a multiple of 4
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float x = m[j] + bv[j];
-            if (a.drop_thresh != 0u) x = fs_dropout_keep((uint32_t)(e + j), a.drop_key, a.drop_thresh) ? x * a.drop_scale : 0.f;
+            if (a.drop_thresh != 0u) x = ((keep >> j) & 1u) ? x * a.drop_scale : 0.f;
             v[j] = live ? x : 0.f;
           }
           if (a.ep_scale != nullptr && live) {

@@ -293,9 +293,10 @@ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__
     if (dres != nullptr) *reinterpret_cast<f32x4*>(dres + o) = g;
     f32x4 v = ga * g - dd * (yy - mu) - bb;
     if (drop_thresh != 0u) {
-      const uint32_t e = (uint32_t)(o + c0);
+      const uint32_t e = (uint32_t)(o + c0);                       // a multiple of 4 (channel quad of an NHWC row)
+      const uint32_t keep = fs_dropout_keep4(e, drop_key, drop_thresh);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = fs_dropout_keep(e + j, drop_key, drop_thresh) ? v[j] * drop_scale : 0.f;
+      for (int j = 0; j < 4; ++j) v[j] = ((keep >> j) & 1u) ? v[j] * drop_scale : 0.f;
     }
     *reinterpret_cast<f32x4*>(dy + o) = v;
   };

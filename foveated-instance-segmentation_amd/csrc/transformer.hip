@@ -225,10 +225,11 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__
                                                        uint32_t thresh, uint32_t key) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    const uint32_t keep = thresh != 0u ? fs_dropout_keep4((uint32_t)(4 * i), key, thresh) : 15u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752440f));
-      if (thresh != 0u) v[j] = fs_dropout_keep((uint32_t)(4 * i + j), key, thresh) ? v[j] * drop_scale : 0.f;
+      if (thresh != 0u) v[j] = ((keep >> j) & 1u) ? v[j] * drop_scale : 0.f;
     }
     reinterpret_cast<f32x4*>(y)[i] = v;
   }
@@ -238,11 +239,12 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
     f32x4 d = reinterpret_cast<const f32x4*>(g)[i];
+    const uint32_t keep = thresh != 0u ? fs_dropout_keep4((uint32_t)(4 * i), key, thresh) : 15u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float cdf = 0.5f * (1.f + erff(v[j] * 0.70710678118654752440f));
       const float pdf = 0.39894228040143267794f * expf(-0.5f * v[j] * v[j]);
-      if (thresh != 0u) d[j] = fs_dropout_keep((uint32_t)(4 * i + j), key, thresh) ? d[j] * drop_scale : 0.f;
+      if (thresh != 0u) d[j] = ((keep >> j) & 1u) ? d[j] * drop_scale : 0.f;
       d[j] *= cdf + v[j] * pdf;
     }
     reinterpret_cast<f32x4*>(dx)[i] = d;

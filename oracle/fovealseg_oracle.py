@@ -585,17 +585,19 @@ def make_optimizers(m: OracleDeformSeg, weight_decay=1e-4, lr=2e-5):
 # the dropout-mask hash shared with the HIP kernels (integer work, numpy)
 # --------------------------------------------------------------------------------------------
 def dropout_keep_mask_nhwc(n_elem: int, key: int, p: float) -> np.ndarray:
-    """keep[e] for linear NHWC element index e, identical to `fs_dropout_keep` in csrc/common.h:
-    h = fmix32(e * 0x9E3779B1 + key); keep = h >= floor(p * 2**32)."""
+    """keep[e] for linear NHWC element index e, identical to `fs_dropout_keep` in csrc/common.h: one hash per element PAIR,
+    h = fmix32((e >> 1) * 0x9E3779B1 + key); element 2i compares the low 16 bits of h, element 2i + 1 the high 16 bits, with the 16-bit
+    threshold floor(p * 2**32) >> 16."""
     e = np.arange(n_elem, dtype=np.uint64)
-    h = (e * np.uint64(0x9E3779B1) + np.uint64(key)) & np.uint64(0xFFFFFFFF)
+    odd = (e & np.uint64(1)).astype(bool)
+    h = ((e >> np.uint64(1)) * np.uint64(0x9E3779B1) + np.uint64(key)) & np.uint64(0xFFFFFFFF)
     h ^= h >> np.uint64(16)
     h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
     h ^= h >> np.uint64(13)
     h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
     h ^= h >> np.uint64(16)
-    thresh = np.uint64(int(math.floor(p * 4294967296.0)))
-    return h >= thresh
+    thresh = np.uint64(int(math.floor(p * 4294967296.0)) >> 16)
+    return np.where(odd, h >> np.uint64(16), h & np.uint64(0xFFFF)) >= thresh
 
 
 def layer_key(seed: int, layer_id: int) -> int:

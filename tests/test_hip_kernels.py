@@ -1573,7 +1573,8 @@ def test_layernorm_gelu_dwconv_droppath():
     assert torch.equal(ya.detach(), yb.detach())
     assert relerr(xa.grad, xb.grad) <= 1e-7
     keep = torch.from_numpy(O.dropout_keep_mask_nhwc(x.numel(), key, 0.3)).view(x.shape)
-    assert torch.equal(ya.detach().cpu() != 0, keep & (F.gelu(x) != 0))
+    # (zero-ness of gelu(x) from the DEVICE gelu: at x ~ -5.5 the last ulp of erff decides between -0 and -1.6e-7, CPU and device differ there)
+    assert torch.equal(ya.detach().cpu() != 0, keep & (ops.Gelu.apply(x.to(DEV)).cpu() != 0))
     # depthwise 3x3
     C = 256
     xi = torch.randn(2, C, 11, 13, generator=g)

@@ -57,7 +57,8 @@ def main():
         y = ops.conv2d_fwd(x, w, None, s, pad)
         dy = torch.zeros_like(y) if os.environ.get("MB_ZEROS") == "1" else torch.randn_like(y)
         flops = 2.0 * y.numel() * Ci * k * k
-        fns = {"fwd": lambda: ops.conv2d_fwd(x, w, None, s, pad),
+        drop = float(os.environ.get("MB_DROP", "0"))       # forward with the dropout hash in the epilogue (BasicBlock convs: p = 0.3)
+        fns = {"fwd": lambda: ops.conv2d_fwd(x, w, None, s, pad, drop, 12345 if drop > 0 else 0),
                "bwd_data": lambda: ops.conv2d_bwd_data(dy, w, x.shape, s, pad),
                "wgrad": lambda: ops.conv2d_bwd_weight(x, dy, w.shape, s, pad)}
         res = []
