@@ -1030,6 +1030,15 @@ bool use_tapset(const ConvArgs& c) {
          (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;        // the tap-class kernel addresses the source with 32-bit byte offsets too
 }
 
+// bwd-data of 3x3 / stride 2 / pad 1 layers: all four output parities in one launch (conv_s2bwd.hip)
+static const bool g_s2bwd = FS_ENV_INT("FS_S2BWD", 1) != 0;      // kernel A/B builds only
+bool use_s2bwd(const ConvArgs& c) {
+  return g_s2bwd && g_conv_precision >= 1 && c.transposed && c.ws_ != nullptr && c.bias == nullptr &&
+         fs_s2bwd_eligible(c.Hd, c.Wd, c.Cd, c.Hs, c.Ws, c.Cs, c.R, c.S, c.stride, c.pad, c.dil) &&
+         c.ws_bytes_ >= fs_s2bwd_pack_bytes(g_conv_precision, c.Cd, c.Cs) &&
+         (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL && (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;
+}
+
 // 1x1 / stride-1 layers go to the GEMM kernel with pre-split weights (conv_pointwise.hip) when the caller handed over its scratch.
 static const bool g_pointwise = FS_ENV_INT("FS_POINTWISE", 1) != 0;
 bool use_pointwise(const ConvArgs& c) {
@@ -1094,6 +1103,8 @@ int launch_affine(const ConvArgs& c, long M) {
                              c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key,
                              c.stream_);
   if (!c.transposed || c.stride == 1) return launch_affine_one(a);
+  if (use_s2bwd(c))
+    return fs_s2bwd_conv(g_conv_precision, c.src, c.w, c.dst, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cd, c.Hs, c.Ws, c.Cs, c.stream_);
   // stride>1 bwd-data: one dense sub-problem per output parity class (oy0, ox0).  dX pixel y receives
   // tap r iff (y + pad - r) % stride == 0, i.e. r = r0 + stride*t with r0 = (oy0 + pad) % stride, and then
   // reads dY row (y + pad - r)/stride = py + (oy0 + pad - r0)/stride - t.
@@ -1210,13 +1221,17 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
     const long t = fs_pointwise_pack_bytes(g_conv_precision, Cs, Cd);
     if (t > need) need = t;
   }
+  if (g_s2bwd && transposed && fs_s2bwd_eligible(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)) {
+    const long t = fs_s2bwd_pack_bytes(g_conv_precision, Cin, Cout);
+    if (t > need) need = t;
+  }
   return need;
 }
 
 // include/fovealseg.h: fs_conv2d_kernel_choice -- which kernel family the conv entry points select for this problem under the current
 // precision mode and `ws_bytes` of scratch (host-side predicate, no launch; the dispatch below uses the same functions).
 // 0 = generic 64-bit-indexed kernel, 1 = plain aligned implicit GEMM, 2 = halo-tiled 3x3, 3 = tap-class kernel, 4 = 1x1 GEMM kernel,
-// 5 = halo-tiled 3x3 with F(2,3) minimal filtering along the row.
+// 5 = halo-tiled 3x3 with F(2,3) minimal filtering along the row, 6 = stride-2 bwd-data with the four output parities in one launch.
 int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                             int transposed, long ws_bytes) {
   ConvArgs c{nullptr, nullptr, nullptr, nullptr, B, transposed ? Ho : H, transposed ? Wo : W, transposed ? Cout : Cin,
@@ -1229,6 +1244,7 @@ int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Co
   if (use_wino(c)) return 5;
   if (use_halo(c)) return 2;
   if (use_pointwise(c)) return 4;
+  if (use_s2bwd(c)) return 6;
   if (transposed && stride > 1 && use_tapset(c)) return 3;     // the multi-tap parity sub-problems
   return 1;
 }

@@ -70,6 +70,12 @@ int fs_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, lo
 int fs_wgrad_split(int mode, const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S,
                    int stride, int pad, FsPartHost* part, hipStream_t stream);
 
+// ---- conv_s2bwd.hip: bwd-data of a 3x3 / stride 2 / pad 1 convolution, the four output parities in one launch ----
+bool fs_s2bwd_eligible(int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil);
+long fs_s2bwd_pack_bytes(int mode, int Cin, int Cout);
+int fs_s2bwd_conv(int mode, const float* dy, const float* w, float* dx, void* ws, const unsigned* w_amax, int B, int H, int W, int Cin, int Ho,
+                  int Wo, int Cout, hipStream_t stream);
+
 // conv_tapset.hip: general halo-tiled split-precision convolution over a list of tap classes.
 //   source row of (loop row oy, class tap tr) = sm*(oy + tr) + cy,  filter row r = rbase + rstep*tr  (columns alike)
 struct FsTapClass { int cy, cx, nR, nS, rbase, rstep, sbase, sstep; };
