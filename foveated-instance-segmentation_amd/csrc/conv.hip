@@ -1030,6 +1030,15 @@ bool use_tapset(const ConvArgs& c) {
          (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;        // the tap-class kernel addresses the source with 32-bit byte offsets too
 }
 
+// forward of 3x3 / stride 2 / pad 1 layers: the four input parity planes in one LDS refill per chunk (conv_s2fwd.hip)
+static const bool g_s2fwd = FS_ENV_INT("FS_S2FWD", 1) != 0;      // kernel A/B builds only
+bool use_s2fwd(const ConvArgs& c) {
+  return g_s2fwd && g_conv_precision >= 1 && !c.transposed && c.ws_ != nullptr && c.bn_ == nullptr &&
+         fs_s2fwd_eligible(c.Hs, c.Ws, c.Cs, c.Hd, c.Wd, c.Cd, c.R, c.S, c.stride, c.pad, c.dil) &&
+         c.ws_bytes_ >= fs_s2fwd_pack_bytes(g_conv_precision, c.Cs, c.Cd) &&
+         (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL && (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;
+}
+
 // bwd-data of 3x3 / stride 2 / pad 1 layers: all four output parities in one launch (conv_s2bwd.hip)
 static const bool g_s2bwd = FS_ENV_INT("FS_S2BWD", 1) != 0;      // kernel A/B builds only
 bool use_s2bwd(const ConvArgs& c) {
@@ -1082,6 +1091,9 @@ int launch_affine(const ConvArgs& c, long M) {
             c.Hd, c.Wd, 1, 0, 0, 0, 0, 1, c.R, c.S, c.pad, c.pad, 0, 0, c.stats_};
   a_stream = c.stream_;
   (void)M;
+  if (use_s2fwd(c))
+    return fs_s2fwd_conv(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, c.B, c.Hs, c.Ws, c.Cs, c.Hd, c.Wd, c.Cd,
+                         c.drop_scale, c.drop_thresh, c.drop_key, c.stream_);
   if (!c.transposed && use_tapset(c) && !use_halo(c)) return launch_tapset_forward(c);
   if (c.transposed && c.stride == 1 && use_tapset(c) && !use_halo(c)) {
     FsTapsetProblem p = tapset_base(c);
@@ -1221,6 +1233,10 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
     const long t = fs_pointwise_pack_bytes(g_conv_precision, Cs, Cd);
     if (t > need) need = t;
   }
+  if (g_s2fwd && !transposed && fs_s2fwd_eligible(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)) {
+    const long t = fs_s2fwd_pack_bytes(g_conv_precision, Cin, Cout);
+    if (t > need) need = t;
+  }
   if (g_s2bwd && transposed && fs_s2bwd_eligible(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)) {
     const long t = fs_s2bwd_pack_bytes(g_conv_precision, Cin, Cout);
     if (t > need) need = t;
@@ -1231,7 +1247,8 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
 // include/fovealseg.h: fs_conv2d_kernel_choice -- which kernel family the conv entry points select for this problem under the current
 // precision mode and `ws_bytes` of scratch (host-side predicate, no launch; the dispatch below uses the same functions).
 // 0 = generic 64-bit-indexed kernel, 1 = plain aligned implicit GEMM, 2 = halo-tiled 3x3, 3 = tap-class kernel, 4 = 1x1 GEMM kernel,
-// 5 = halo-tiled 3x3 with F(2,3) minimal filtering along the row, 6 = stride-2 bwd-data with the four output parities in one launch.
+// 5 = halo-tiled 3x3 with F(2,3) minimal filtering along the row, 6 = stride-2 bwd-data with the four output parities in one launch,
+// 7 = stride-2 forward with the four input parity planes in one LDS refill.
 int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                             int transposed, long ws_bytes) {
   ConvArgs c{nullptr, nullptr, nullptr, nullptr, B, transposed ? Ho : H, transposed ? Wo : W, transposed ? Cout : Cin,
@@ -1239,6 +1256,7 @@ int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Co
   c.ws_ = ws_bytes > 0 ? (void*)&c : nullptr;
   c.ws_bytes_ = ws_bytes;
   if (!aligned_ok(c)) return 0;
+  if (use_s2fwd(c)) return 7;
   if (!transposed && use_tapset(c) && !use_halo(c)) return 3;
   if (transposed && stride == 1 && use_tapset(c) && !use_halo(c)) return 3;
   if (use_wino(c)) return 5;
@@ -1258,8 +1276,8 @@ int fs_conv2d_stats_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout
     const bool halo = H == Ho && W == Wo && fs_halo_eligible(H, W, Cin, Cout, R, S, stride, pad, dil);
     if (halo && fs_wino_eligible(g_conv_precision, B, Ho, Wo, Cin, Cout)) return fs_wino_stats_slabs(g_conv_precision, B, Ho, Wo, Cin, Cout);
     if (halo) return fs_halo_stats_slabs(B, Ho, Wo);
+    if (g_s2fwd && fs_s2fwd_eligible(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)) return fs_s2fwd_slabs(B, Ho, Wo);
     if (tapset_shape_ok(Cin, Cout, R, S, stride, dil)) return fs_tapset_slabs(B, Ho, Wo, (R + stride - 1) / stride, (S + stride - 1) / stride);
-    if (halo) return fs_halo_stats_slabs(B, Ho, Wo);
   }
   return cdiv((long)B * Ho * Wo, 128);
 }

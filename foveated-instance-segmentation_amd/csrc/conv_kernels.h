@@ -76,6 +76,14 @@ long fs_s2bwd_pack_bytes(int mode, int Cin, int Cout);
 int fs_s2bwd_conv(int mode, const float* dy, const float* w, float* dx, void* ws, const unsigned* w_amax, int B, int H, int W, int Cin, int Ho,
                   int Wo, int Cout, hipStream_t stream);
 
+// ---- conv_s2fwd.hip: forward of a 3x3 / stride 2 / pad 1 convolution, the four input parity planes in one LDS refill per chunk ----
+bool fs_s2fwd_eligible(int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil);
+long fs_s2fwd_pack_bytes(int mode, int Cin, int Cout);
+int fs_s2fwd_slabs(int B, int Ho, int Wo);          // BatchNorm partial-sum slabs (= pixel tiles) of the stats variant
+int fs_s2fwd_conv(int mode, const float* x, const float* w, const float* bias, float* y, float* stats, void* ws, const unsigned* w_amax,
+                  int B, int H, int W, int Cin, int Ho, int Wo, int Cout, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,
+                  hipStream_t stream);
+
 // conv_tapset.hip: general halo-tiled split-precision convolution over a list of tap classes.
 //   source row of (loop row oy, class tap tr) = sm*(oy + tr) + cy,  filter row r = rbase + rstep*tr  (columns alike)
 struct FsTapClass { int cy, cx, nR, nS, rbase, rstep, sbase, sstep; };

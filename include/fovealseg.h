@@ -117,7 +117,7 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
  * 4 GB and more), 1 = plain channel-aligned implicit GEMM, 2 = halo-tiled 3x3 stride-1 kernel, 3 = tap-class kernel,
  * 4 = 1x1 / stride-1 GEMM kernel with pre-split weights, 5 = halo-tiled 3x3 stride-1 kernel with F(2,3) minimal filtering along
  * the row (even widths; 12 instead of 18 matrix steps per pixel pair), 6 = bwd-data of a 3x3 / stride-2 / pad-1 layer with the four
- * output parities in one launch.  The
+ * output parities in one launch, 7 = its forward with the four input parity planes in one LDS refill per chunk.  The
  * aligned kernels address the source with 32-bit byte offsets, so they are chosen only below 4 GB.  Host-side predicate. */
 int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                             int transposed, long ws_bytes);
