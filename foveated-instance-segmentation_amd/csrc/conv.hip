@@ -1172,7 +1172,8 @@ int fs_wgrad_reduce(const float* part, int nslab, long n, float* dw, int accumul
 static long wgrad_slab_cap(int Cin, int Cout, int R, int S, int stride, int pad, int dil) {
   const long tiles = (long)cdiv(Cin, 64) * cdiv(Cout, 64);
   if (g_conv_precision >= 1 && fs_wgrad_split_eligible(Cin, Cout, R, S, stride, pad, dil)) {
-    if (R == 1 && S == 1 && stride == 1 && pad == 0) return 2048 / tiles + 2;      // linear_wgrad_kernel: up to 1024 workgroups of 64 x 64 tiles, 512 of wider ones
+    if ((R == 1 && S == 1 && stride == 1 && pad == 0) || (stride >= R && stride >= S))
+      return 2048 / tiles + 2;      // linear_wgrad_kernel (plain or gathered rows): up to 1024 workgroups of 64 x 64 tiles, 512 of wider ones
     return 512 / tiles + 2;                                                      // class kernels: 512 workgroups; transform-domain kernel: 2 x 256
   }
   if (R == 3 && S == 3 && Cin % 4 == 0 && Cout % 4 == 0) return 1024 / tiles + 2;

@@ -719,6 +719,10 @@ struct LwArgs {
   unsigned x_bytes, dy_bytes;
   FsPart part;        // deterministic mode: slab `split` of dW images
   float* bpart;       // deterministic mode, with dbias: slab 4 * split + wave of Cout floats (the four waves hold different rows)
+  // gathered rows (round 4): the single-tap classes of a convolution whose stride is at least its filter size -- 3x3 stride 4 in the C1
+  // classification head, 1x1 stride 2 -- as ntap linear layers in ONE launch.  Row r of dY = output pixel (b, oy, ox); tap (tr, ts) pairs
+  // it with X pixel (b, oy * st + tr - pad, ox * st + ts - pad) (zero outside the image) and owns dw + tap * Cin * Cout.  ntap = 0: plain rows.
+  int ntap, S, Ho, Wo, Hx, Wx, st, pad;
 };
 
 template <class P, int WM, int WN, int MI, int NI>
@@ -742,7 +746,9 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(LwArgs a) {
   const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
   const int qd = nwg >> 3, rmd = nwg & 7;
   const int wg = (xcd < rmd ? xcd * (qd + 1) : rmd * (qd + 1) + (xcd - rmd) * qd) + loc;
-  const int split = wg / ntile, tile = wg - split * ntile;
+  const int per_tap = a.ntap > 0 ? nwg / a.ntap : nwg;           // gathered rows: tap-major, then split, then channel tile
+  const int tap = wg / per_tap, wgl = wg - tap * per_tap;
+  const int split = wgl / ntile, tile = wgl - split * ntile;
   const int tci = tile / a.tiles_co, tco = tile - tci * a.tiles_co;
   const int ci0 = tci * (XB * 32), co0 = tco * (YB * 32);
   const int k_begin = split * a.rows_per_split;
@@ -759,13 +765,34 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(LwArgs a) {
 #pragma unroll
   for (int i = 0; i < YB; ++i) { const int c = co0 + 32 * i + 4 * quad; yoff[i] = c < a.Cout ? c * 4 : -1; }
   f32x4 rx[XB], ry[YB];
+  // gathered rows: (image, output row, output column) of this thread's row, advanced by 32 rows per chunk (load_chunk is called once per
+  // chunk, in order); the tap's shift of the source pixel
+  int gb = 0, goy = 0, gox = 0;
+  const int tr_ = a.ntap > 0 ? tap / a.S : 0, ts_ = a.ntap > 0 ? tap - tr_ * a.S : 0;
+  if (a.ntap > 0) {
+    const int r0 = k_begin + lrow, hw = a.Ho * a.Wo;
+    gb = r0 / hw;
+    const int rem = r0 - gb * hw;
+    goy = rem / a.Wo; gox = rem - goy * a.Wo;
+  }
+  const long part_tap = (long)tap * a.Cin * a.Cout;
   auto load_chunk = [&](int k) {
     const int r = k + lrow;
-    const bool rok = r < k_end;
-    const int xr = r * a.Cin * 4, yr = r * a.Cout * 4;
+    bool rok = r < k_end;
+    int xr = r * a.Cin * 4;
+    const int yr = r * a.Cout * 4;
+    bool xok = rok;
+    if (a.ntap > 0) {
+      const int iy = goy * a.st + tr_ - a.pad, ix = gox * a.st + ts_ - a.pad;
+      xok = rok && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx;
+      xr = ((gb * a.Hx + iy) * a.Wx + ix) * a.Cin * 4;
+      gox += 32;
+      while (gox >= a.Wo) { gox -= a.Wo; ++goy; }
+      while (goy >= a.Ho) { goy -= a.Ho; ++gb; }
+    }
 #pragma unroll
     for (int i = 0; i < XB; ++i)
-      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, rok && xoff[i] >= 0 ? xr + xoff[i] : (int)OOB, 0, 0));
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, xok && xoff[i] >= 0 ? xr + xoff[i] : (int)OOB, 0, 0));
 #pragma unroll
     for (int i = 0; i < YB; ++i)
       ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, rok && yoff[i] >= 0 ? yr + yoff[i] : (int)OOB, 0, 0));
@@ -864,7 +891,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(LwArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (ci < a.Cin) fs_wgrad_out(a.dw, a.part, split, (long)ci * a.Cout + co, acc[mi][ni][r]);
+        if (ci < a.Cin) fs_wgrad_out(a.dw, a.part, split, part_tap + (long)ci * a.Cout + co, acc[mi][ni][r]);
       }
     }
 }
@@ -889,7 +916,8 @@ int launch_linear_wgrad(LwArgs a, int target, FsPartHost* ph, hipStream_t stream
   nsplit = cdiv(a.rows, a.rows_per_split);
   if (part_claim(ph, nsplit, a.part) != FS_OK) return FS_ERR_ARG;
   if (a.part.base == nullptr) a.bpart = nullptr;
-  hipLaunchKernelGGL((linear_wgrad_kernel<P, WM, WN, MI, NI>), dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
+  const int ntap = a.ntap > 0 ? a.ntap : 1;
+  hipLaunchKernelGGL((linear_wgrad_kernel<P, WM, WN, MI, NI>), dim3((unsigned)(ntile * nsplit * ntap)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -910,6 +938,7 @@ int run_linear_wgrad(LwArgs l, FsPartHost* ph, hipStream_t stream) {
     tile = l.rows / nsplit >= 512 ? 4 : 1;
     if (tile == 1) target = 1024;
   }
+  if (l.ntap > 0) target = 1024 / l.ntap > 64 ? 1024 / l.ntap : 64;      // gathered rows: ~1000 workgroups over all taps together
   if (force >= 1 && force <= 4) tile = force;
   if (force_wgs > 0) target = force_wgs;
   switch (tile) {
@@ -1062,6 +1091,7 @@ int fs_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, lo
   l.x = x; l.dy = dy; l.dw = dw; l.dbias = dbias; l.rows = (int)rows; l.Cin = Cin; l.Cout = Cout;
   l.x_bytes = (unsigned)((size_t)rows * Cin * 4); l.dy_bytes = (unsigned)((size_t)rows * Cout * 4);
   l.part = FsPart{nullptr, 0}; l.bpart = dbias != nullptr ? bpart : nullptr;
+  l.ntap = 0; l.S = 1; l.Ho = l.Wo = l.Hx = l.Wx = 1; l.st = 1; l.pad = 0;
   return run_linear_wgrad(l, part, stream);
 }
 
@@ -1131,6 +1161,17 @@ direct:
     l.x = x; l.dy = dy; l.dw = dw; l.dbias = nullptr; l.rows = B * H * W; l.Cin = Cin; l.Cout = Cout;
     l.x_bytes = a.x_bytes; l.dy_bytes = a.dy_bytes;
     l.part = FsPart{nullptr, 0}; l.bpart = nullptr;
+    l.ntap = 0; l.S = 1; l.Ho = l.Wo = l.Hx = l.Wx = 1; l.st = 1; l.pad = 0;
+    return run_linear_wgrad(l, ph, stream);
+  }
+  static const bool gather_on = FS_ENV_INT("FS_WGRAD_GATHER", 1) != 0;      // kernel A/B builds only
+  if (mode == 1 && gather_on && stride >= R && stride >= S && R * S <= 16 && (R > 1 || stride > 1) && (long)B * Ho * Wo < 2000000000L / (Cin > Cout ? Cin : Cout)) {
+    // every tap class is a single tap (3x3 stride 4, 1x1 stride 2 ...): R * S linear layers over gathered X rows, one launch
+    LwArgs l;
+    l.x = x; l.dy = dy; l.dw = dw; l.dbias = nullptr; l.rows = B * Ho * Wo; l.Cin = Cin; l.Cout = Cout;
+    l.x_bytes = a.x_bytes; l.dy_bytes = a.dy_bytes;
+    l.part = FsPart{nullptr, 0}; l.bpart = nullptr;
+    l.ntap = R * S; l.S = S; l.Ho = Ho; l.Wo = Wo; l.Hx = H; l.Wx = W; l.st = stride; l.pad = pad;
     return run_linear_wgrad(l, ph, stream);
   }
   // Measured in one gpurun call against the per-class launches (profiles/r04/wgrad_s2_planes_ab.txt, us, bf16x3, B = 64): 64 -> 64 @ 80x80
