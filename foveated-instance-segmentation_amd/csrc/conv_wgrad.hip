@@ -21,6 +21,7 @@
 #include "conv_split.h"
 #include "conv_kernels.h"
 #include <stdio.h>
+#include <math.h>
 #include <stdlib.h>
 
 namespace {
@@ -896,6 +897,17 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(LwArgs a) {
     }
 }
 
+// Split-K count of a small problem.  A launch costs about (K rounds per workgroup) x t_round + (workgroups x tile bytes) / (1 TB/s of fp32
+// atomics at the L2: one dword per channel and clock), so the best split count is n* = sqrt(rounds * t_round / (ntile * t_tile)), with
+// t_tile the time the L2 needs for one workgroup's tile.  On the HRNet layers n* is at or above the "fill the chip" count used so far
+// (64 -> 64 @ 80x80, B = 64: 6 400 patches, one tile: n* = 530), so nothing changes there; on DeepLab's 10x10 maps at 16 images per GPU
+// (25 patches, 16 tiles: n* = 8) "fill the chip" launched 400 workgroups that each ran ONE 6 us round and then pushed 147 KB of atomics:
+// 81 us per launch for a 1.9 GFLOP problem (gpurun_out/trace_c4, round 4).
+static int splitk_model(long rounds, int ntile, double t_round_us, double tile_kb) {
+  const double n = sqrt((double)rounds * t_round_us / ((double)ntile * tile_kb * 0.001));      // 1 KB of atomics ~ 1 ns
+  return n < 1.0 ? 1 : (n > 4096.0 ? 4096 : (int)(n + 0.5));
+}
+
 // deterministic mode: the launch's slabs must fit the caller's workspace; note how many it used
 static int part_claim(FsPartHost* ph, int nslab, FsPart& out) {
   out.base = nullptr; out.stride = 0;
@@ -912,6 +924,10 @@ int launch_linear_wgrad(LwArgs a, int target, FsPartHost* ph, hipStream_t stream
   const int ntile = a.tiles_ci * a.tiles_co;
   int nsplit = target / ntile;
   if (nsplit < 1) nsplit = 1;
+  {
+    const int nm = splitk_model(cdiv(a.rows, 32), ntile, 1.0, WM * MI * WN * NI * 4.0);      // a 32-row chunk ~ 1 us; tile = 32 x 32 x 4 B per block pair
+    if (nm < nsplit) nsplit = nm;
+  }
   a.rows_per_split = cdiv(cdiv(a.rows, nsplit), 32) * 32;
   nsplit = cdiv(a.rows, a.rows_per_split);
   if (part_claim(ph, nsplit, a.part) != FS_OK) return FS_ERR_ARG;
@@ -993,6 +1009,10 @@ int launch_class(WgArgs a, int ntile, FsPartHost* ph, hipStream_t stream) {
   int nsplit = 512 / ntile;
   if (nsplit < 1) nsplit = 1;
   if (nsplit > a.npatch) nsplit = a.npatch;
+  {
+    const int nm = splitk_model(a.npatch, ntile, 0.75 * NR * NS, 16.0 * NR * NS);      // ~0.75 us and 16 KB per tap and patch round
+    if (nm < nsplit) nsplit = nm;
+  }
   a.patches_per_split = cdiv(a.npatch, nsplit);
   nsplit = cdiv(a.npatch, a.patches_per_split);
   if (part_claim(ph, nsplit, a.part) != FS_OK) return FS_ERR_ARG;

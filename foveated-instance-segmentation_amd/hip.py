@@ -193,6 +193,8 @@ def set_conv_precision(mode: str) -> None:
     code = {"f32": 0, "bf16x3": 1, "f16x2": 2}[mode]
     if load().fs_set_conv_precision(code) != 0:
         raise HipLibraryError("fs_set_conv_precision rejected the mode")
+    global _mode_name
+    _mode_name = mode
     _ws_cache.clear()
 
 
@@ -277,18 +279,39 @@ def bn_bwd_slabs(M, C):
     return v
 
 
+_mode_name = None      # the library's precision mode as a string, kept in step by set_conv_precision (one ctypes call less per conv launch)
+
+
 def get_conv_precision() -> str:
-    return ("f32", "bf16x3", "f16x2")[load().fs_get_conv_precision()]
+    global _mode_name
+    if _mode_name is None:
+        _mode_name = ("f32", "bf16x3", "f16x2")[load().fs_get_conv_precision()]
+    return _mode_name
+
+
+# torch's current HIP stream as a raw handle.  torch.cuda.current_stream() builds a Python Stream object through several layers of device
+# index helpers (~10 us, twice the cost of the ctypes launch itself: configs[4] is host-bound at ~1 700 launches per 30 ms step); the
+# private accessor returns the same handle in ~0.3 us and follows stream guards and the autograd engine's per-node streams alike.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def _stream():
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+_fn_cache = {}
 
 
 def call(name, *args):
     """Launch `name` on torch's current HIP stream; raises on any non-zero status."""
-    lib = _lib if _lib is not None else load()
-    err = getattr(lib, name)(*args, _stream())
+    fn = _fn_cache.get(name)
+    if fn is None:
+        lib = _lib if _lib is not None else load()
+        fn = _fn_cache[name] = getattr(lib, name)
+    err = fn(*args, _stream())
     if err != 0:
         what = "argument rejected at the C-ABI boundary" if err == 1001 else f"hipError {err}"
         raise HipLibraryError(f"{name}: {what}")

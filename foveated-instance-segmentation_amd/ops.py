@@ -389,6 +389,32 @@ def pad_in_channels(x, w):
 
 FANOUT = os.environ.get("FS_FANOUT", "1") != "0"
 
+# Launch-latency-bound layers (DeepLab's 10x10 / 20x20 stages at 16 images per GPU: ~1 700 launches of 5-15 us per 30 ms step, the GPU
+# mostly waiting on the dependency chain): a weight gradient has no consumer before the optimiser, so below WGRAD_SIDE_FLOPS it is
+# launched on a side stream beside the bwd-data chain.  Only where the kernel adds straight into the gradient arena (no autograd consumer);
+# FlatAdam.step / zero_grad and train.allreduce_gradients join the side stream first (join_wgrad_streams).  The headline layers are 30 GFLOP
+# each and keep the one-stream order: there the GPU is saturated and a side stream was measured at +-0.
+WGRAD_SIDE_FLOPS = float(os.environ.get("FS_WGRAD_SIDE_GFLOP", "4")) * 1e9
+_WGRAD_SIDE = {}
+_WGRAD_SIDE_BUSY = set()
+
+
+def _wgrad_side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _WGRAD_SIDE.get(key)
+    if s is None:
+        s = _WGRAD_SIDE[key] = torch.cuda.Stream(device=device)
+    return s
+
+
+def join_wgrad_streams():
+    """The current stream waits for every weight-gradient launch that went to a side stream since the last join."""
+    if _WGRAD_SIDE_BUSY:
+        cur = torch.cuda.current_stream()
+        for s in _WGRAD_SIDE_BUSY:
+            cur.wait_stream(s)
+        _WGRAD_SIDE_BUSY.clear()
+
 
 # BatchNorm-backward column sums that the PRODUCER of a gradient tensor already formed (FanOut.backward below):
 # dz.data_ptr() -> (slab, nslab, dz).  The entry keeps dz alive, so its address cannot be reused while the entry exists;
@@ -642,7 +668,17 @@ class ConvBnAct(Function):
         src_bn = ctx.src_bn if ctx.fan is None else (ctx.fan[1] if pend is not None else None)
         if not WGRAD_FIRST:
             dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax, src_bn=src_bn, addend=pend) if ctx.needs_input_grad[0] else None
-        dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"], accumulate=tgt is not None)
+        if tgt is not None and 2.0 * M * C * w.shape[1] * w.shape[2] * w.shape[3] < WGRAD_SIDE_FLOPS and TIMER is None:
+            side, cur = _wgrad_side_stream(dy.device), torch.cuda.current_stream()
+            side.wait_stream(cur)                  # dy (and x) were produced on the current stream
+            with torch.cuda.stream(side):
+                conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"], accumulate=True)
+            dy.record_stream(side)
+            x.record_stream(side)
+            _WGRAD_SIDE_BUSY.add(side)
+            dw = None
+        else:
+            dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"], accumulate=tgt is not None)
         if tgt is not None:
             dw = None
         if WGRAD_FIRST:     # dx is what the next backward node reads: produce it last so it is the freshest tensor in the cache

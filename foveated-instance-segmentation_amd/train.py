@@ -111,6 +111,8 @@ class FlatAdam:
         self.param_groups = [g]
 
     def zero_grad(self, set_to_none=False):
+        from . import ops
+        ops.join_wgrad_streams()          # (a backward whose small-layer weight gradients went to the side stream, never stepped)
         self.flat.zero_grad()
 
     def check_grads_in_arena(self):
@@ -127,7 +129,8 @@ class FlatAdam:
         g = self.param_groups[0]
         self.check_grads_in_arena()
         self.t += 1
-        from .ops import _launch
+        from .ops import _launch, join_wgrad_streams
+        join_wgrad_streams()              # the arena is complete only when the side-stream weight gradients have landed
         _launch("fe_adam", 28.0 * self.flat.numel, "fs_adam_step", hip.ptr(self.flat.data), hip.ptr(self.flat.grad), hip.ptr(self.m), hip.ptr(self.v),
                 self.flat.numel, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                 float(g["weight_decay"]), self.t, float(self.grad_scale))
@@ -264,6 +267,8 @@ def allreduce_gradients(optimizers, module=None):
     """Gradient average across ranks: one SUM all-reduce per arena; the 1/world is folded into Adam.
     `module` wrapped by torch's DistributedDataParallel (the reference's call site, train_deform_semantic.py:395): its reducer has
     already averaged the gradients into the arena views during backward, so nothing is exchanged here."""
+    from . import ops
+    ops.join_wgrad_streams()          # weight gradients of small layers may still be running on their side stream
     if not _collectives_on() or _is_torch_ddp(module):
         for opt in optimizers:
             opt.grad_scale = 1.0

@@ -1951,6 +1951,61 @@ def test_config3_segformer_task160():
     assert len(outs) == 6 and all(np.isfinite(float(o)) for o in outs)
 
 
+@pytest.mark.parametrize("B", [16, 64])
+def test_config3_segformer_at_its_real_size(B):
+    """configs[3]'s stated workload through the real module -- SegFormer encoder (fc_dim 1024), 1024 x 1024 input, task size
+    160 x 160, B = 16 per GPU; B = 64 takes the >= 4 GB batch-range path of the conv entry points (the C1 head's 1024-channel input at
+    160 x 160 is 6.7 GB) and needs ~180 GB of HBM, so it is skipped on a smaller card.  Size-independent properties: finite loss, accuracies
+    in [0, 1], every parameter gradient present and finite, the saliency net reached through the up-sampled grid, label map int64 of the
+    task size, four optimiser steps that move every arena, batch-range path really taken."""
+    from fovealseg import train
+    free, total = torch.cuda.mem_get_info()
+    if B == 64 and total < 230 * 2 ** 30:
+        pytest.skip("B = 64 at 1024^2 / 160^2 needs ~180 GB")
+    cfg = fovealseg.lvis50_cfg()
+    cfg.MODEL.arch_encoder, cfg.MODEL.fc_dim = "segformer", 1024
+    cfg.TRAIN.task_input_size = (160, 160)
+    module, nets = train.build_module(cfg, device=DEV)
+    module.train()
+    opts = train.create_optimizers(nets, cfg)
+    batch = train.synthetic_batch(B, 1024, 1024, seed=21, device=DEV)
+    ranges = []
+    real = ops._batch_ranges
+
+    def spy(Bn, *per):
+        r = real(Bn, *per)
+        ranges.append(len(r))
+        return r
+    ops._batch_ranges = spy
+    try:
+        ops.DropoutState.seed, ops.DropoutState.step = 17, 0
+        start = [op.flat.data.clone() for op in opts]
+        out0 = train.train_step(module, opts, batch, cfg, epoch=1, cur_iter=0)
+        l0 = float(out0[0].detach())
+        for n, p_ in module.named_parameters():
+            if p_.requires_grad and not n.startswith("encoder.decode_head"):
+                assert p_.grad is not None and bool(torch.isfinite(p_.grad).all()), n
+        assert float(module.localization.fov_expand_1.weight.grad.abs().max()) > 0
+        losses = [l0]
+        for it in range(1, 4):
+            losses.append(float(train.train_step(module, opts, batch, cfg, epoch=1, cur_iter=it)[0].detach()))
+    finally:
+        ops._batch_ranges = real
+    assert all(np.isfinite(v) for v in losses), losses
+    assert 0.0 <= float(out0[1]) <= 1.0 and np.isfinite(float(out0[2]))
+    assert all(float((op.flat.data - w0).abs().max()) > 0 for op, w0 in zip(opts, start)), "an optimiser did not move its parameters"
+    assert (max(ranges) > 1) == (B == 64), (B, max(ranges))            # tensors of 4 GB and more are convolved in batch ranges
+    module.eval()
+    X, Fp, Y, cls = batch
+    feed = {"img_data": X[:, :3], "seg_label": Y, "focus_point": Fp, "cls_label": cls}
+    with torch.no_grad():
+        outs = module(feed, is_inference=True)
+    assert feed["seg_label"].shape == (B, 160, 160) and feed["seg_label"].dtype == torch.int64
+    assert len(outs) == 6 and all(np.isfinite(float(o)) for o in outs)
+    del module, nets, opts, batch
+    torch.cuda.empty_cache()
+
+
 def test_config4_deeplab_2048():
     """BASELINE configs[4] at its per-GPU size: DeepLab encoder, 2048x2048 input -> (80,80) foveated warp, batch 16."""
     from fovealseg import train

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--profile", action="store_true", help="cProfile one enqueue and print the top host functions")
+    ap.add_argument("--config", default="headline", help="headline | config3 (SegFormer 160x160) | config4 (DeepLab, 2048^2 input)")
     args = ap.parse_args()
     import fovealseg
     from fovealseg import train as T, ops, modules as Mods
@@ -23,6 +24,11 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     cfg = fovealseg.lvis50_cfg()
+    if args.config == "config3":
+        cfg.MODEL.arch_encoder, cfg.MODEL.fc_dim = "segformer", 1024
+        cfg.TRAIN.task_input_size = (160, 160)
+    elif args.config == "config4":
+        cfg.MODEL.arch_encoder = "deeplab"
     module, nets = T.build_module(cfg, device=dev)
     module.train()
     optimizers = T.create_optimizers(nets, cfg)
