@@ -45,7 +45,7 @@ def _profiled_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this same command
     (profiles/rNN/hbm_traffic_serial*.json; FETCH_SIZE doubled per the gfx950 correction).  PMC counters
     cannot be read from inside the benchmark process, so this is the offline measurement, or None."""
-    for rel in ("profiles/r03/hbm_traffic_serial.json", "profiles/r02/hbm_traffic_serial.json", "profiles/r01/hbm_traffic_serial.json"):
+    for rel in ("profiles/r04/hbm_traffic_serial.json", "profiles/r03/hbm_traffic_serial.json", "profiles/r02/hbm_traffic_serial.json", "profiles/r01/hbm_traffic_serial.json"):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 table = json.load(f)
@@ -61,7 +61,7 @@ def _profiled_traffic(kernel):
 
 
 def _profiled_traffic_table():
-    for rel in ("profiles/r03/hbm_traffic_serial.json",):
+    for rel in ("profiles/r04/hbm_traffic_serial.json", "profiles/r03/hbm_traffic_serial.json"):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 return json.load(f), rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
@@ -75,9 +75,10 @@ def _profiled_mfma_busy(mode, kernel):
     (profiles/r02/pmc/sq_<mode>_<kernel>_fwd_shape0.txt: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)), or None."""
     import ast
     import re
-    rel = f"profiles/r03/pmc/sq_{mode}_{kernel}_fwd_shape0.txt"
-    if not os.path.exists(os.path.join(ROOT, rel)):
-        rel = f"profiles/r02/pmc/sq_{mode}_{kernel}_fwd_shape0.txt"
+    rel = f"profiles/r04/pmc/sq_{mode}_{kernel}_fwd_shape0.txt"
+    for older in ("r03", "r02"):
+        if not os.path.exists(os.path.join(ROOT, rel)):
+            rel = f"profiles/{older}/pmc/sq_{mode}_{kernel}_fwd_shape0.txt"
     try:
         vals = {}
         for line in open(os.path.join(ROOT, rel)):
@@ -505,8 +506,10 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
                                           f"conv_wgrad_class_kernel<fs_split::{tag}, 3, 3")
         if "conv_affine" in summ:
             out["roofline_other_convs"] = entry(
-                summ["conv_affine"], f"conv_tapset_kernel<{tag}> (strided 3x3 forward + bwd-data sub-problems) + conv_igemm_split_kernel<{tag}> (1x1 convs "
-                                     "and single-tap sub-problems, HBM-bound at these channel counts)", f"conv_igemm_split_kernel<fs_split::{tag}>")
+                summ["conv_affine"], f"conv_s2fwd_kernel<{tag}> / conv_s2bwd_kernel<{tag}> (3x3 stride-2 forward over the four input parity planes, bwd-data "
+                                     f"with the four output parities in one launch; round 4) + conv1x1_gemm_kernel<{tag}> / conv_igemm_split_kernel<{tag}> "
+                                     "(1x1 convs and the stride-4 head conv: HBM-bound at these channel counts)",
+                [f"conv_s2fwd_kernel<fs_split::{tag}", f"conv_s2bwd_kernel<fs_split::{tag}", f"conv1x1_gemm_kernel<fs_split::{tag}", f"conv_igemm_split_kernel<fs_split::{tag}>"])
     elif "conv_affine" in summ:
         out["roofline"] = entry(summ["conv_affine"], "conv_igemm_affine_kernel<1> (fwd + bwd-data implicit GEMM, fp32 MFMA 32x32x2)", "conv_igemm_affine_kernel<1>")
         if "conv_wgrad" in summ:

@@ -593,7 +593,28 @@ __global__ __launch_bounds__(256) void slab_reduce_wave_kernel(const float* __re
   if (lane == 0) out[i] = accumulate ? out[i] + s : s;
 }
 
+// two such sums of equal shape in one launch (blockIdx.y picks the pair member): LayerNorm's dgamma / dbeta, a head's dw / db
+__global__ __launch_bounds__(256) void slab_reduce_pair_kernel(const float* __restrict__ part0, const float* __restrict__ part1, int nslab, long n,
+                                                               float* __restrict__ out0, float* __restrict__ out1, int accumulate) {
+  const float* part = blockIdx.y ? part1 : part0;
+  float* out = blockIdx.y ? out1 : out0;
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = lane; k < nslab; k += 64) s += part[(long)k * n + i];
+  s = wave_sum(s);
+  if (lane == 0) out[i] = accumulate ? out[i] + s : s;
+}
+
 }  // namespace
+
+int fs_slab_reduce_pair(const float* part0, const float* part1, int nslab, long n, float* out0, float* out1, int accumulate, hipStream_t stream) {
+  if (!part0 || !part1 || !out0 || !out1 || nslab < 0 || n <= 0) return FS_ERR_ARG;
+  hipLaunchKernelGGL(slab_reduce_pair_kernel, dim3((unsigned)((n * 64 + 255) / 256), 2), dim3(256), 0, stream, part0, part1, nslab, n, out0, out1, accumulate);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
 
 // common.h: the ordered second stage of every cross-workgroup sum
 int fs_slab_reduce(const float* part, int nslab, long n, float* out, int accumulate, hipStream_t stream) {

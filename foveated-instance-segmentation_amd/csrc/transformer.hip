@@ -869,9 +869,7 @@ int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const f
                        dx, part_g, part_b, M, C, rpb);
   }
   FS_LAUNCH_CHECK();
-  const int r = fs_slab_reduce(part_g, nblk, C, dgamma, accumulate, stream);
-  if (r != FS_OK) return r;
-  return fs_slab_reduce(part_b, nblk, C, dbeta, accumulate, stream);
+  return fs_slab_reduce_pair(part_g, part_b, nblk, C, dgamma, dbeta, accumulate, stream);
 }
 
 int fs_gelu_fwd(const float* x, float* y, long n, hipStream_t stream) {

@@ -1228,7 +1228,11 @@ def conv_bias_any(x, w, bias, stride, pad):
     kernels) unfolded into patch rows and computed as one linear layer.  The weight's RSCK storage [r][s][c][k] IS the (k*k*C, Cout) matrix
     of that layer: a view, no copy, and its gradient lands in the same storage."""
     cout, cin, r, s = w.shape
-    if not UNFOLD_BIG_FILTERS or r != s or r * s <= 32 or hip.get_conv_precision() != "bf16x3" or cout % 4 or cout < 16:
+    # ... and so are filters whose stride equals their size (the 2x2 / 4x4 sequence-reduction convs of the Mix-Transformer): their patches
+    # do not overlap, the unfold is a pure permutation, and the alternative is one single-tap launch per filter tap and pass (configs[3]:
+    # 312 conv_igemm_split launches per step, 13.7 ms; round 4)
+    patchify = r > 1 and stride == r and pad == 0
+    if (not UNFOLD_BIG_FILTERS or r != s or (r * s <= 32 and not patchify) or hip.get_conv_precision() != "bf16x3" or cout % 4 or cout < 16):
         return ConvBias.apply(x, w, bias, stride, pad)
     B, H, W, _ = x.shape
     Ho, Wo = _out_hw(H, W, r, s, stride, pad)
