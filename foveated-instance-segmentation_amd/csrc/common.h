@@ -113,5 +113,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // of every cross-workgroup sum of the library: per-workgroup partials are written with plain stores and added here in index order, so
 // no result depends on the order in which workgroups finish.
 int fs_slab_reduce(const float* part, int nslab, long n, float* out, int accumulate, hipStream_t stream);
+// the same for many slabs of a mid-sized tensor: a first stage folds the slabs into the first 8 IN PLACE (part is scratch)
+int fs_slab_reduce_inplace(float* part, int nslab, long n, float* out, int accumulate, hipStream_t stream);
 // two sums of equal shape in one launch (a wave per column: meant for n up to a few thousand)
 int fs_slab_reduce_pair(const float* part0, const float* part1, int nslab, long n, float* out0, float* out1, int accumulate, hipStream_t stream);

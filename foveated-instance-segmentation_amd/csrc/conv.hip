@@ -1164,8 +1164,8 @@ int launch_affine(const ConvArgs& c, long M) {
 
 bool fs_deterministic() { return g_deterministic != 0; }
 
-int fs_wgrad_reduce(const float* part, int nslab, long n, float* dw, int accumulate, hipStream_t stream) {
-  return fs_slab_reduce(part, nslab, n, dw, accumulate, stream);
+int fs_wgrad_reduce(float* part, int nslab, long n, float* dw, int accumulate, hipStream_t stream) {
+  return fs_slab_reduce_inplace(part, nslab, n, dw, accumulate, stream);
 }
 
 // slabs one bwd-weight call can need in deterministic mode: an upper bound of the split counts chosen below and in conv_wgrad.hip
@@ -1190,8 +1190,17 @@ int fs_set_deterministic(int on) {
 int fs_get_deterministic(void) { return g_deterministic; }
 
 // include/fovealseg.h: scratch fs_conv2d_bwd_weight needs for this layer (0 unless deterministic mode is on)
+// Strided 3x3 layers (one round of <= 512 workgroups: ~50-85 us of patch rounds, then ~80 us of split-K atomics with nothing left to
+// overlap them): partial tiles by plain stores into per-split slabs + one ordered reduce launch instead of the atomics, in the default
+// mode too -- the machinery of deterministic mode, without the memset (the one-launch kernel writes every element of every slab it uses).
+static const int g_wgrad_store = FS_ENV_INT("FS_WGRAD_STORE", 1);      // kernel A/B builds only: 0 atomics everywhere, 2 also the 3x3 stride-1 class kernel
+static bool wgrad_store_route(int Cin, int Cout, int R, int S, int stride, int pad, int dil) {
+  if (g_wgrad_store == 0 || g_conv_precision < 1 || R != 3 || S != 3 || !fs_wgrad_split_eligible(Cin, Cout, R, S, stride, pad, dil)) return false;
+  return stride == 2 || stride == 3 || (g_wgrad_store == 2 && stride == 1 && pad == 1);
+}
 long fs_conv2d_bwd_weight_ws_bytes(int Cin, int Cout, int R, int S, int stride, int pad, int dil) {
-  if (!g_deterministic || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0) return 0;
+  if (Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0) return 0;
+  if (!g_deterministic && !wgrad_store_route(Cin, Cout, R, S, stride, pad, dil)) return 0;
   return wgrad_slab_cap(Cin, Cout, R, S, stride, pad, dil) * (long)R * S * Cin * Cout * 4;
 }
 // include/fovealseg.h: scratch of fs_linear_bwd_weight_bias (dW slabs, then 4 bias slabs per dW slab)
@@ -1422,7 +1431,7 @@ int fs_linear_bwd_weight_bias(const float* x, const float* dy, float* dw, float*
     FS_REQUIRE(ws != nullptr && ws_bytes >= fs_linear_bwd_weight_bias_ws_bytes(Cin, Cout));
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)cap * (n + 4L * Cout) * 4, stream);
     if (e != hipSuccess) return (int)e;
-    FsPartHost ph{static_cast<float*>(ws), n, cap, 0};
+    FsPartHost ph{static_cast<float*>(ws), n, cap, 0, 0};
     float* bpart = static_cast<float*>(ws) + cap * n;
     const int r = fs_linear_wgrad(x, dy, dw, dbias, rows, Cin, Cout, &ph, bpart, stream);
     if (r != FS_OK) return r;
@@ -1455,10 +1464,20 @@ int fs_conv2d_bwd_weight(const float* x, const float* dy, float* dw, int B, int 
     FS_REQUIRE(ws != nullptr && ws_bytes >= cap * n * 4);
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)cap * n * 4, stream);
     if (e != hipSuccess) return (int)e;
-    FsPartHost ph{static_cast<float*>(ws), n, cap, 0};
+    FsPartHost ph{static_cast<float*>(ws), n, cap, 0, 0};
     const int r = conv2d_bwd_weight_impl(x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, &ph, stream);
     if (r != FS_OK) return r;
     return fs_wgrad_reduce(ph.base, ph.used, n, dw, accumulate, stream);
+  }
+  if (ws != nullptr && wgrad_store_route(Cin, Cout, R, S, stride, pad, dil) &&
+      (size_t)B * H * W * Cin * 4 < 4294967000UL && (size_t)B * Ho * Wo * Cout * 4 < 4294967000UL) {
+    const long n = (long)R * S * Cin * Cout, cap = wgrad_slab_cap(Cin, Cout, R, S, stride, pad, dil);
+    if (ws_bytes >= cap * n * 4) {
+      FsPartHost ph{static_cast<float*>(ws), n, cap, 0, 1};
+      const int r = fs_wgrad_split(g_conv_precision, x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, &ph, stream);
+      if (r != FS_OK) return r;
+      return fs_wgrad_reduce(ph.base, ph.used, n, dw, accumulate, stream);
+    }
   }
   if (!accumulate) {         // every kernel below adds its split-K partials atomically: dw = 0 first, unless the caller accumulates
     hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)R * S * Cin * Cout, stream);

@@ -56,9 +56,9 @@ __device__ __forceinline__ void fs_wgrad_out(float* dw, const FsPart p, int slab
 }
 bool fs_deterministic();
 // dw[i] = (accumulate ? dw[i] : 0) + part[0][i] + part[1][i] + ... + part[nslab-1][i], in that order
-int fs_wgrad_reduce(const float* part, int nslab, long n, float* dw, int accumulate, hipStream_t stream);
+int fs_wgrad_reduce(float* part, int nslab, long n, float* dw, int accumulate, hipStream_t stream);
 // host-side bookkeeping of one bwd-weight call in deterministic mode: slabs available / slabs the launches used
-struct FsPartHost { float* base; long stride; long cap; int used; };
+struct FsPartHost { float* base; long stride; long cap; int used; int force_planes; };      // force_planes: the strided 3x3 layer must take the one-launch kernel (every slab element written: no memset)
 
 // ---- conv_wgrad.hip: split-precision weight gradient, one launch per tap class (dw zeroed by the caller or accumulated into) ----
 // any square filter / stride whose tap classes have at most 2 taps per dimension (3x3 s2/s4, 1x1 any stride), plus 3x3 s1

@@ -1200,7 +1200,7 @@ direct:
   // of split-K atomics (512 x 147 KB at the L2's one dword per channel and clock), and neither term depends on how the taps are grouped;
   // only a single channel tile (twice the splits, half the rounds) gains.  planes policy 1 = those layers, 2 = every strided 3x3, 0 = off.
   static const int planes_pol = FS_ENV_INT("FS_WGRAD_PLANES", 1);      // kernel A/B builds only
-  if (planes_pol != 0 && (planes_pol == 2 || ntile == 1) && R == 3 && S == 3 && (stride == 2 || stride == 3)) {
+  if (((planes_pol != 0 && (planes_pol == 2 || ntile == 1)) || (ph != nullptr && ph->force_planes)) && R == 3 && S == 3 && (stride == 2 || stride == 3)) {
     // all nine taps of a strided 3x3 filter in one launch (parity planes of the X halo in LDS)
     MpArgs m;
     m.x = x; m.dy = dy; m.dw = dw; m.B = B; m.H = Ho; m.W = Wo; m.Hx = H; m.Wx = W; m.Cin = Cin; m.Cout = Cout;

@@ -593,6 +593,19 @@ __global__ __launch_bounds__(256) void slab_reduce_wave_kernel(const float* __re
   if (lane == 0) out[i] = accumulate ? out[i] + s : s;
 }
 
+// many slabs of a mid-sized tensor (512 partial dW tiles of a 64 x 64 x 9 layer: 36 864 elements each): one thread per element walking 512
+// slabs leaves the chip to 144 workgroups of serial loads.  Stage 1 lets G workgroup rows (blockIdx.y = g) each add the slabs k = g, g + G, ...
+// of their elements in ascending k and leaves the sum IN slab g (the only reader of slab g's element i is the thread that overwrites
+// it); stage 2 is the plain kernel over the first G slabs.  The order is fixed by (nslab, G): still independent of timing.
+__global__ __launch_bounds__(256) void slab_reduce_stage1_kernel(float* __restrict__ part, int nslab, long n, int G) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = g; k < nslab; k += G) s += part[(long)k * n + i];
+  part[(long)g * n + i] = s;
+}
+
 // two such sums of equal shape in one launch (blockIdx.y picks the pair member): LayerNorm's dgamma / dbeta, a head's dw / db
 __global__ __launch_bounds__(256) void slab_reduce_pair_kernel(const float* __restrict__ part0, const float* __restrict__ part1, int nslab, long n,
                                                                float* __restrict__ out0, float* __restrict__ out1, int accumulate) {
@@ -614,6 +627,17 @@ int fs_slab_reduce_pair(const float* part0, const float* part1, int nslab, long 
   hipLaunchKernelGGL(slab_reduce_pair_kernel, dim3((unsigned)((n * 64 + 255) / 256), 2), dim3(256), 0, stream, part0, part1, nslab, n, out0, out1, accumulate);
   FS_LAUNCH_CHECK();
   return FS_OK;
+}
+
+int fs_slab_reduce_inplace(float* part, int nslab, long n, float* out, int accumulate, hipStream_t stream) {
+  if (part == nullptr || out == nullptr || nslab < 0 || n <= 0) return FS_ERR_ARG;
+  constexpr int G = 8;
+  if (nslab >= 4 * G && n > 4096 && n * (long)nslab >= (1L << 22)) {
+    hipLaunchKernelGGL(slab_reduce_stage1_kernel, dim3((unsigned)((n + 255) / 256), G), dim3(256), 0, stream, part, nslab, n, G);
+    FS_LAUNCH_CHECK();
+    nslab = G;
+  }
+  return fs_slab_reduce(part, nslab, n, out, accumulate, stream);
 }
 
 // common.h: the ordered second stage of every cross-workgroup sum
