@@ -273,6 +273,7 @@ def main():
                 barrier()
                 serial_elapsed = time.perf_counter() - tr0
                 res.update(roofline_entries(mode, timer.summary(), args.steps, serial_elapsed))
+                res.update(family_entries(mode, timer, args.steps))
             except Exception as exc:                       # the throughput line must survive a failure of the diagnostic pass
                 res["roofline"] = None
                 res["roofline_error"] = repr(exc)
@@ -543,6 +544,47 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
     if fe:
         fe["note"] = "algorithmic bytes (SURVEY.md 8(d)): every operand element the kernel needs read once, every result written once; the gather kernels touch 4 taps per output"
         out["frontend"] = fe
+    return out
+
+
+def family_entries(mode, timer, nsteps):
+    """The strided / 1x1 convolution family by the bound the round-4 counters established: strided 3x3 layers against the
+    mode's MFMA roof, 1x1 layers against the HBM roof with their algorithmic bytes (input read once, output written once, weights)."""
+    peak = mode_peak(mode)
+    groups = {"strided": [0, 0.0, 0.0], "strided_wgrad": [0, 0.0, 0.0], "pointwise": [0, 0.0, 0.0], "pointwise_wgrad": [0, 0.0, 0.0]}
+    for kind in ("conv_affine", "conv_wgrad"):
+        for (s, e, f), tag in zip(timer.records.get(kind, []), timer.tags.get(kind, [])):
+            if tag is None or len(tag) < 13:
+                continue
+            B, H, W, Cin, Ho, Wo, Cout, R, S, stride = tag[1:11]
+            ms = s.elapsed_time(e)
+            wg = "_wgrad" if kind == "conv_wgrad" else ""
+            if R == 1 and S == 1:
+                d = groups["pointwise" + wg]
+                d[2] += 4.0 * (B * H * W * Cin / (stride * stride) + B * Ho * Wo * Cout + Cin * Cout)
+            elif stride > 1:
+                d = groups["strided" + wg]
+                d[2] += f
+            else:
+                continue
+            d[0] += 1
+            d[1] += ms
+    out = {}
+    for name, (n, ms, work) in groups.items():
+        if n == 0 or ms <= 0:
+            continue
+        if name.startswith("pointwise"):
+            gbs = work / (ms * 1e-3) / 1e9
+            out["roofline_" + name] = {"kernel": "1x1 convolutions" + (" (bwd-weight: linear_wgrad_kernel)" if "wgrad" in name else " forward + bwd-data (conv1x1_gemm_kernel)") +
+                                                 ": HBM-bound at 64-512 channels (profiles/r04/pmc); algorithmic bytes = input read once, output written once, weights",
+                                       "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                       "launches_per_step": n // nsteps, "avg_launch_us": round(1e3 * ms / n, 2), "ms_per_step": round(ms / nsteps, 3)}
+        else:
+            tf = work / (ms * 1e-3) / 1e12
+            out["roofline_" + name] = {"kernel": "strided 3x3 convolutions" + (" bwd-weight (conv_wgrad_class / conv_wgrad_planes / gathered linear_wgrad kernels)" if "wgrad" in name
+                                                 else " forward + bwd-data (conv_s2fwd_kernel, conv_s2bwd_kernel; the stride-4 head conv on conv_igemm_split_kernel)"),
+                                       "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                                       "launches_per_step": n // nsteps, "avg_launch_us": round(1e3 * ms / n, 2), "ms_per_step": round(ms / nsteps, 3)}
     return out
 
 
