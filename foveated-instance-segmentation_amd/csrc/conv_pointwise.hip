@@ -317,8 +317,17 @@ int fs_pointwise_conv(int mode, const float* src, const float* w, const float* b
   a.Npad = ((Cd + 64 * nwp - 1) / (64 * nwp)) * 64 * nwp;
   a.nchunk = (Cs + 31) / 32;
   a.nx = cdiv(M, ROWS);
-  // 128-column workgroups (two sub-tiles per wave, the A tile split once for twice the MFMAs) while the grid still fills the chip
-  const int nw = (nwp == 2 && (long)a.nx * (a.Npad / 128) >= 440) ? 2 : 1;
+  // 128-column workgroups (two sub-tiles per wave, the A tile split once for twice the MFMAs) or 64-column ones: whichever needs less
+  // time by rounds of 512 resident workgroups x cost of a workgroup per chunk (a refill ~ 1 000 cycles + 768 cycles of MFMAs per 64 columns).
+  // N = 320 (the Mix-Transformer's stage-3 width) is the case that matters: 128-column tiles pad it to 384 and leave 600 workgroups =
+  // 1.17 rounds, 64-column tiles give 1 000 workgroups of 0.7x the work each (1280 -> 320 forward: 129 TF against 163 for 320 -> 1280).
+  int nw = 1;
+  if (nwp == 2) {
+    const long wg2 = (long)a.nx * (a.Npad / 128), wg1 = (long)a.nx * ((Cd + 63) / 64);
+    const long cost2 = ((wg2 + 511) / 512) * (1000 + 2 * 768), cost1 = ((wg1 + 511) / 512) * (1000 + 768);
+    static const int force = FS_ENV_INT("FS_PW_NW", 0);      // kernel A/B builds only: 1 / 2 force the tiling
+    nw = force == 1 ? 1 : (force == 2 ? 2 : ((wg2 >= 440 && cost2 <= cost1) ? 2 : 1));
+  }
   a.ny = nw == 2 ? a.Npad / 128 : (Cd + 63) / 64;
   const long pack_bytes = fs_pointwise_pack_bytes(mode, Cs, Cd);
   if (pack_bytes >= 2147483647L || (size_t)M * Cs * 4 >= 4294967000UL || (size_t)M * Cd * 4 >= 4294967000UL) return FS_ERR_ARG;
