@@ -1196,6 +1196,7 @@ int fs_get_deterministic(void) { return g_deterministic; }
 static const int g_wgrad_store = FS_ENV_INT("FS_WGRAD_STORE", 1);      // kernel A/B builds only: 0 atomics everywhere, 2 also the 3x3 stride-1 class kernel
 static bool wgrad_store_route(int Cin, int Cout, int R, int S, int stride, int pad, int dil) {
   if (g_wgrad_store == 0 || g_conv_precision < 1 || R != 3 || S != 3 || !fs_wgrad_split_eligible(Cin, Cout, R, S, stride, pad, dil)) return false;
+  if (g_conv_precision == 1 && fs_wgrad_gather_s2(Cin, R, S, stride) && g_wgrad_store != 3) return false;      // those run as gathered-row GEMMs (conv_wgrad.hip)
   return stride == 2 || stride == 3 || (g_wgrad_store == 2 && stride == 1 && pad == 1);
 }
 long fs_conv2d_bwd_weight_ws_bytes(int Cin, int Cout, int R, int S, int stride, int pad, int dil) {

@@ -63,6 +63,7 @@ struct FsPartHost { float* base; long stride; long cap; int used; int force_plan
 // ---- conv_wgrad.hip: split-precision weight gradient, one launch per tap class (dw zeroed by the caller or accumulated into) ----
 // any square filter / stride whose tap classes have at most 2 taps per dimension (3x3 s2/s4, 1x1 any stride), plus 3x3 s1
 bool fs_wgrad_split_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil);
+bool fs_wgrad_gather_s2(int Cin, int R, int S, int stride);
 bool fs_linear_wgrad_eligible(int mode, long rows, int Cin, int Cout);
 // part (nullable): deterministic mode.  fs_linear_wgrad: bpart (nullable) = slabs of Cout floats for the bias column sums, 4 per split.
 int fs_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, long rows, int Cin, int Cout, FsPartHost* part, float* bpart,

@@ -1115,6 +1115,9 @@ int fs_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, lo
   return run_linear_wgrad(l, part, stream);
 }
 
+// strided 3x3 layers whose bwd-weight runs as nine gathered-row GEMMs (policy above); conv.hip keeps them off the store + reduce route
+bool fs_wgrad_gather_s2(int Cin, int R, int S, int stride) { return R == 3 && S == 3 && (stride == 2 || stride == 3) && Cin <= 64; }
+
 bool fs_wgrad_split_eligible(int Cin, int Cout, int R, int S, int stride, int pad, int dil) {
   (void)pad;
   if (dil != 1 || Cin % 4 || Cout % 4 || Cin < 16 || Cout < 16 || R != S) return false;
@@ -1184,8 +1187,14 @@ direct:
     l.ntap = 0; l.S = 1; l.Ho = l.Wo = l.Hx = l.Wx = 1; l.st = 1; l.pad = 0;
     return run_linear_wgrad(l, ph, stream);
   }
-  static const bool gather_on = FS_ENV_INT("FS_WGRAD_GATHER", 1) != 0;      // kernel A/B builds only
-  if (mode == 1 && gather_on && stride >= R && stride >= S && R * S <= 16 && (R > 1 || stride > 1) && (long)B * Ho * Wo < 2000000000L / (Cin > Cout ? Cin : Cout)) {
+  // ... and so do strided 3x3 layers with <= 64 input channels: there the nine-accumulator kernels are bound by their split-K reduction
+  // (512 x 147 KB), while nine GEMMs over gathered rows have 32 KB tiles, prefetch their next chunk during the MFMA phase and read X only
+  // 2.25 times (each tap a quarter of the pixels).  Same-box A/B (profiles/r04/wgrad_gather_s2_ab.txt, us): 64 -> 64 @ 80x80 104 -> 75,
+  // 64 -> 128 173 -> 138, 64 -> 256 @ 40x40 100 -> 75; 128 -> 256 155 -> 151, 256 -> 512 157 -> 162, 512 -> 512 268 -> 356 (those stay).
+  static const int gather_pol = FS_ENV_INT("FS_WGRAD_GATHER", 1);      // kernel A/B builds only: 0 off, 2 = every strided layer
+  const bool gather_s2 = stride > 1 && (gather_pol == 2 || fs_wgrad_gather_s2(Cin, R, S, stride)) && !(ph != nullptr && ph->force_planes);
+  if (mode == 1 && gather_pol != 0 && ((stride >= R && stride >= S) || gather_s2) && R * S <= 16 &&
+      (R > 1 || stride > 1) && (long)B * Ho * Wo < 2000000000L / (Cin > Cout ? Cin : Cout)) {
     // every tap class is a single tap (3x3 stride 4, 1x1 stride 2 ...): R * S linear layers over gathered X rows, one launch
     LwArgs l;
     l.x = x; l.dy = dy; l.dw = dw; l.dbias = nullptr; l.rows = B * Ho * Wo; l.Cin = Cin; l.Cout = Cout;
