@@ -203,21 +203,32 @@ def set_deterministic(on: bool) -> None:
     order instead of by fp32 atomics (include/fovealseg.h fs_set_deterministic)."""
     if load().fs_set_deterministic(1 if on else 0) != 0:
         raise HipLibraryError("fs_set_deterministic failed")
+    _ws_cache.clear()
 
 
 def get_deterministic() -> bool:
     return bool(load().fs_get_deterministic())
 
 
+_ws_cache = {}
+
+
+def query(name, *args):
+    """A host-only size / predicate query of the library (fs_*_bytes, fs_*_floats ...), cached per argument tuple: one dictionary lookup
+    instead of a ctypes call on every launch.  The cache is dropped whenever the precision or deterministic mode changes."""
+    key = (name,) + args
+    v = _ws_cache.get(key)
+    if v is None:
+        v = _ws_cache[key] = int(getattr(load(), name)(*args))
+    return v
+
+
 def wgrad_workspace(device, Cin, Cout, R, S, stride, pad, dil):
-    """(scratch tensor | None, bytes) for fs_conv2d_bwd_weight: the per-split partial tiles of deterministic mode, nothing otherwise."""
-    n = int(load().fs_conv2d_bwd_weight_ws_bytes(Cin, Cout, R, S, stride, pad, dil))
+    """(scratch tensor | None, bytes) for fs_conv2d_bwd_weight: per-split partial tiles (deterministic mode; strided 3x3 layers in every mode)."""
+    n = query("fs_conv2d_bwd_weight_ws_bytes", Cin, Cout, R, S, stride, pad, dil)
     if n == 0:
         return None, 0
     return torch.empty(n, device=device, dtype=torch.uint8), n
-
-
-_ws_cache = {}
 
 
 def conv_workspace_bytes(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed):
@@ -239,8 +250,7 @@ def conv_stats_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_byte
 
 def attention_split_ws_bytes(B, Nk, heads, backward=False):
     """Scratch bytes of the split-precision attention entry points (packed K / V planes)."""
-    lib = load()
-    return int(lib.fs_attention_bwd_split_ws_bytes(B, Nk, heads) if backward else lib.fs_attention_split_ws_bytes(B, Nk, heads))
+    return query("fs_attention_bwd_split_ws_bytes" if backward else "fs_attention_split_ws_bytes", B, Nk, heads)
 
 
 def linear_bwd_weight_bias_ok(rows, Cin, Cout):

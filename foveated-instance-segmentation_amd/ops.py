@@ -316,7 +316,7 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None, dil=1, accumulate=F
 def colsum(x2d_rows, C, into=None):
     """Column sums (bias gradients).  into = a gradient-arena target: the sums are ADDED to it and None is returned."""
     M = x2d_rows.numel() // C
-    scratch = torch.empty(int(hip.load().fs_colsum_scratch_floats(M, C)), device=x2d_rows.device, dtype=torch.float32)
+    scratch = torch.empty(hip.query("fs_colsum_scratch_floats", M, C), device=x2d_rows.device, dtype=torch.float32)
     if into is not None:
         hip.call("fs_colsum", hip.ptr(x2d_rows), M, C, hip.ptr(into), 1, hip.ptr(scratch))
         return None
@@ -578,7 +578,7 @@ class ConvBnAct(Function):
                      hip.ptr(meta["running_mean"]), hip.ptr(meta["running_var"]), hip.ptr(mean), hip.ptr(invstd))
             meta["num_batches_tracked"].add_(1)
         elif training:
-            sums = torch.empty(int(hip.load().fs_bn_stats_scratch_doubles(M, C)), device=y.device, dtype=torch.float64)
+            sums = torch.empty(hip.query("fs_bn_stats_scratch_doubles", M, C), device=y.device, dtype=torch.float64)
             hip.call("fs_bn_stats", hip.ptr(y), M, C, float(meta["momentum"]), BN_EPS, hip.ptr(meta["running_mean"]),
                      hip.ptr(meta["running_var"]), hip.ptr(mean), hip.ptr(invstd), hip.ptr(sums))
             meta["num_batches_tracked"].add_(1)
@@ -719,7 +719,7 @@ class ConvBias(Function):
             btgt = _direct_grad_target(ctx.bias_ref)
             dw = rsck(tgt) if tgt is not None else torch.empty(1, 1, cin, cout, device=x.device, dtype=torch.float32)
             db = btgt if btgt is not None else torch.empty(cout, device=x.device, dtype=torch.float32)
-            lws_bytes = int(hip.load().fs_linear_bwd_weight_bias_ws_bytes(cin, cout))      # deterministic mode only
+            lws_bytes = hip.query("fs_linear_bwd_weight_bias_ws_bytes", cin, cout)      # deterministic mode only
             lws = torch.empty(lws_bytes, device=x.device, dtype=torch.uint8) if lws_bytes else None
             _launch("conv_wgrad", 2.0 * rows * cout * cin, "fs_linear_bwd_weight_bias", hip.ptr(x), hip.ptr(dy), hip.ptr(dw), hip.ptr(db),
                     rows, cin, cout, 1 if tgt is not None else 0, 1 if btgt is not None else 0, hip.ptr(lws), lws_bytes)
@@ -840,7 +840,7 @@ class MaskHead(Function):
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         db = torch.empty(1, device=x.device, dtype=torch.float32)
-        scratch = torch.empty(int(hip.load().fs_mask_head_bwd_scratch_floats(m.numel(), C)), device=x.device, dtype=torch.float32)
+        scratch = torch.empty(hip.query("fs_mask_head_bwd_scratch_floats", m.numel(), C), device=x.device, dtype=torch.float32)
         hip.call("fs_mask_head_bwd", hip.ptr(dm), hip.ptr(m), hip.ptr(x), hip.ptr(w), hip.ptr(dx), hip.ptr(dw), hip.ptr(db),
                  m.numel(), C, hip.ptr(scratch))
         return dx, dw, db
@@ -1176,7 +1176,7 @@ class LayerNorm(Function):
         dgamma = tg if direct else torch.empty_like(gamma)
         dbeta = tb if direct else torch.empty_like(gamma)
         M = x.numel() // C
-        scratch = torch.empty(int(hip.load().fs_layernorm_bwd_scratch_floats(M, C)), device=x.device, dtype=torch.float32)
+        scratch = torch.empty(hip.query("fs_layernorm_bwd_scratch_floats", M, C), device=x.device, dtype=torch.float32)
         hip.call("fs_layernorm_bwd", hip.ptr(g.contiguous()), hip.ptr(x), hip.ptr(gamma), hip.ptr(mean), hip.ptr(rstd), hip.ptr(dx),
                  hip.ptr(dgamma), hip.ptr(dbeta), M, C, 1 if direct else 0, hip.ptr(scratch))
         if direct:
@@ -1288,7 +1288,7 @@ class DwConv3(Function):
         tgt = _direct_grad_target(w)
         tgt = tgt if (tgt is not None and tgt.is_contiguous()) else None
         dw = tgt if tgt is not None else torch.empty_like(w)
-        ws = torch.empty(hip.load().fs_dwconv3_wgrad_lanes(B, H, W, C) * 9 * C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(hip.query("fs_dwconv3_wgrad_lanes", B, H, W, C) * 9 * C, device=x.device, dtype=torch.float32)
         hip.call("fs_dwconv3_bwd_weight", hip.ptr(x), hip.ptr(g), hip.ptr(dw), hip.ptr(ws), B, H, W, C, 1 if tgt is not None else 0)
         if tgt is not None:
             dw = None
@@ -1342,7 +1342,7 @@ class Attention(Function):
             ws = torch.empty(nb, device=q.device, dtype=torch.uint8)
             if p > 0 and will_backward:
                 # one keep bit per (query, key), left by the forward so that the three backward kernels do not hash every element again
-                mask = torch.empty(int(hip.load().fs_attention_mask_words(B, N, Nk, heads)), device=q.device, dtype=torch.int32)
+                mask = torch.empty(hip.query("fs_attention_mask_words", B, N, Nk, heads), device=q.device, dtype=torch.int32)
             _launch("attn_fwd", 4.0 * B * heads * N * Nk * 64, "fs_attention_fwd_split", hip.ptr(q), hip.ptr(k), hip.ptr(v), hip.ptr(o),
                     hip.ptr(lse), hip.ptr(mask) if mask is not None else None, hip.ptr(ws), nb, B, N, Nk, heads, 0.125, float(p), int(key))
         else:
