@@ -653,6 +653,35 @@ int fs_slab_reduce(const float* part, int nslab, long n, float* out, int accumul
 
 extern "C" {
 
+// include/fovealseg.h: fs_stream_wait -- everything enqueued on `waiter` after this call runs after everything enqueued on `signaller`
+// before it (hipEventRecord + hipStreamWaitEvent on an event from a per-thread ring; a wait captures the record that precedes it, so
+// an event can be recorded again as soon as its wait has been enqueued).  One host call instead of torch's Stream / Event round trip.
+int fs_stream_wait(hipStream_t waiter, hipStream_t signaller) {
+  constexpr int RING = 64;
+  static thread_local hipEvent_t ring[RING];
+  static thread_local int ring_dev[RING];
+  static thread_local int ring_n = 0, next = 0;
+  if (waiter == signaller) return FS_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return FS_ERR_ARG;
+  if (ring_n < RING) {
+    if (hipEventCreateWithFlags(&ring[ring_n], hipEventDisableTiming) != hipSuccess) return FS_ERR_ARG;
+    ring_dev[ring_n] = dev;
+    next = ring_n++;
+  } else {
+    next = (next + 1) % RING;
+    if (ring_dev[next] != dev) {           // the thread moved to another device: the slot's event belongs to the old one
+      (void)hipEventDestroy(ring[next]);
+      if (hipEventCreateWithFlags(&ring[next], hipEventDisableTiming) != hipSuccess) return FS_ERR_ARG;
+      ring_dev[next] = dev;
+    }
+  }
+  hipError_t e = hipEventRecord(ring[next], signaller);
+  if (e != hipSuccess) return (int)e;
+  e = hipStreamWaitEvent(waiter, ring[next], 0);
+  return e == hipSuccess ? FS_OK : (int)e;
+}
+
 // Training-mode statistics of y (M rows, C channels): mean/invstd out, running stats updated in
 // place with `momentum` (unbiased variance), `sums` = 2*C doubles of scratch.
 // row blocks of fs_bn_stats (the widest count over its channel windows) = records of 2*C doubles in its scratch

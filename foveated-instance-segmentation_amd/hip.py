@@ -96,7 +96,7 @@ _lib = None
 HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice",
              "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes", "fs_conv2d_bwd_data_bnsum_slabs",
              "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes", "fs_attention_bwd_split_ws_bytes", "fs_attention_mask_words", "fs_attention_bwd_split_parts_offset",
-             "fs_set_deterministic", "fs_get_deterministic", "fs_conv2d_bwd_weight_ws_bytes", "fs_linear_bwd_weight_bias_ws_bytes",
+             "fs_stream_wait", "fs_set_deterministic", "fs_get_deterministic", "fs_conv2d_bwd_weight_ws_bytes", "fs_linear_bwd_weight_bias_ws_bytes",
              "fs_colsum_scratch_floats", "fs_bn_stats_scratch_doubles", "fs_mask_head_bwd_scratch_floats", "fs_layernorm_bwd_scratch_floats")
 
 
@@ -138,6 +138,8 @@ def load():
     lib.fs_mask_head_bwd_scratch_floats.argtypes = [_L, _I]
     lib.fs_layernorm_bwd_scratch_floats.restype = _L
     lib.fs_layernorm_bwd_scratch_floats.argtypes = [_L, _I]
+    lib.fs_stream_wait.restype = _I
+    lib.fs_stream_wait.argtypes = [_P, _P]
     lib.fs_set_deterministic.restype = _I
     lib.fs_set_deterministic.argtypes = [_I]
     lib.fs_get_deterministic.restype = _I
@@ -315,13 +317,24 @@ def _stream():
 _fn_cache = {}
 
 
+STREAM_OVERRIDE = None      # a raw stream handle: launches go there instead of torch's current stream (ops: side-stream weight gradients)
+
+
+def stream_wait(waiter, signaller):
+    """`waiter` (raw handle) waits for everything enqueued so far on `signaller` (fs_stream_wait: one host call)."""
+    lib = _lib if _lib is not None else load()
+    err = lib.fs_stream_wait(waiter, signaller)
+    if err != 0:
+        raise HipLibraryError(f"fs_stream_wait: hipError {err}")
+
+
 def call(name, *args):
-    """Launch `name` on torch's current HIP stream; raises on any non-zero status."""
+    """Launch `name` on torch's current HIP stream (or STREAM_OVERRIDE); raises on any non-zero status."""
     fn = _fn_cache.get(name)
     if fn is None:
         lib = _lib if _lib is not None else load()
         fn = _fn_cache[name] = getattr(lib, name)
-    err = fn(*args, _stream())
+    err = fn(*args, STREAM_OVERRIDE if STREAM_OVERRIDE is not None else _stream())
     if err != 0:
         what = "argument rejected at the C-ABI boundary" if err == 1001 else f"hipError {err}"
         raise HipLibraryError(f"{name}: {what}")

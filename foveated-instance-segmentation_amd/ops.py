@@ -292,7 +292,7 @@ def _direct_grad_target(p):
     return None
 
 
-def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None, dil=1, accumulate=False):
+def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None, dil=1, accumulate=False, keep=None):
     """dW of conv2d.  out = a gradient buffer in the weight's layout; accumulate=True adds into it (the DIRECT_GRAD arena
     is zeroed once per step by zero_grad, so the per-layer memset is skipped and repeated backwards accumulate like .grad)."""
     B, H, W, Cin = x.shape
@@ -306,7 +306,9 @@ def conv2d_bwd_weight(x, dy, w_shape, stride, pad, out=None, dil=1, accumulate=F
         return buf
     dw = rsck(out) if out is not None else torch.empty(R, S, Cin, Cout, device=x.device, dtype=torch.float32)
     k3 = R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and Cin % 4 == 0 and Cout % 4 == 0 and Cin >= 16 and Cout >= 16
-    dws, dws_bytes = hip.wgrad_workspace(x.device, Cin, Cout, R, S, stride, pad, dil)      # deterministic mode only
+    dws, dws_bytes = hip.wgrad_workspace(x.device, Cin, Cout, R, S, stride, pad, dil)      # deterministic mode; strided 3x3 layers
+    if keep is not None and dws is not None:
+        keep.append(dws)          # the launch runs on a side stream: the scratch must outlive this call (join_wgrad_streams)
     _launch("wgrad3x3" if (k3 and hip.get_conv_precision() != "f32") else "conv_wgrad", 2.0 * B * Ho * Wo * Cout * R * S * Cin,
             "fs_conv2d_bwd_weight", hip.ptr(x), hip.ptr(dy), hip.ptr(dw),
             B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 1 if accumulate else 0, hip.ptr(dws), dws_bytes)
@@ -395,24 +397,27 @@ FANOUT = os.environ.get("FS_FANOUT", "1") != "0"
 # FlatAdam.step / zero_grad and train.allreduce_gradients join the side stream first (join_wgrad_streams).  The headline layers are 30 GFLOP
 # each and keep the one-stream order: there the GPU is saturated and a side stream was measured at +-0.
 WGRAD_SIDE_FLOPS = float(os.environ.get("FS_WGRAD_SIDE_GFLOP", "4")) * 1e9
-_WGRAD_SIDE = {}
-_WGRAD_SIDE_BUSY = set()
+_WGRAD_SIDE = {}            # device index -> (torch Stream, raw handle)
+_WGRAD_SIDE_BUSY = {}       # raw handle of a side stream with launches since the last join -> tensors those launches read or write
+                            # (kept alive until the join: they were allocated on the main stream's pool, so freeing them earlier would let
+                            # the allocator hand them out again while the side stream still uses them; cheaper than three record_stream calls)
 
 
 def _wgrad_side_stream(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     s = _WGRAD_SIDE.get(key)
     if s is None:
-        s = _WGRAD_SIDE[key] = torch.cuda.Stream(device=device)
-    return s
+        st = torch.cuda.Stream(device=device)
+        s = _WGRAD_SIDE[key] = (st, st.cuda_stream)
+    return s[1]
 
 
 def join_wgrad_streams():
     """The current stream waits for every weight-gradient launch that went to a side stream since the last join."""
     if _WGRAD_SIDE_BUSY:
-        cur = torch.cuda.current_stream()
-        for s in _WGRAD_SIDE_BUSY:
-            cur.wait_stream(s)
+        cur = hip._stream()
+        for h in _WGRAD_SIDE_BUSY:
+            hip.stream_wait(cur, h)
         _WGRAD_SIDE_BUSY.clear()
 
 
@@ -669,13 +674,15 @@ class ConvBnAct(Function):
         if not WGRAD_FIRST:
             dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax, src_bn=src_bn, addend=pend) if ctx.needs_input_grad[0] else None
         if tgt is not None and 2.0 * M * C * w.shape[1] * w.shape[2] * w.shape[3] < WGRAD_SIDE_FLOPS and TIMER is None:
-            side, cur = _wgrad_side_stream(dy.device), torch.cuda.current_stream()
-            side.wait_stream(cur)                  # dy (and x) were produced on the current stream
-            with torch.cuda.stream(side):
-                conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"], accumulate=True)
-            dy.record_stream(side)
-            x.record_stream(side)
-            _WGRAD_SIDE_BUSY.add(side)
+            side = _wgrad_side_stream(dy.device)
+            hip.stream_wait(side, hip._stream())      # dy (and x) were produced on the current stream
+            keep = _WGRAD_SIDE_BUSY.setdefault(side, [])
+            keep.append((x, dy))
+            hip.STREAM_OVERRIDE = side
+            try:
+                conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"], accumulate=True, keep=keep)
+            finally:
+                hip.STREAM_OVERRIDE = None
             dw = None
         else:
             dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"], accumulate=tgt is not None)

@@ -98,6 +98,10 @@ int fs_inverse_index_maps(const float* grid, long long* u, long long* v, long n,
  * else the entry points need comes in through their arguments. */
 int fs_set_conv_precision(int mode);
 int fs_get_conv_precision(void);
+/* Stream ordering without a host round trip: everything enqueued on `waiter` after this call runs after everything enqueued on
+ * `signaller` before it (what torch's `waiter.wait_stream(signaller)` does: the reference gets the same ordering from the autograd
+ * engine's stream guards).  Used to run a small layer's weight gradient beside the bwd-data chain. */
+int fs_stream_wait(fs_stream_t waiter, fs_stream_t signaller);
 /* Deterministic mode -- the reference asks for it with torch.backends.cudnn.deterministic = True (train_deform_semantic.py:680-681).
  * By default the bwd-weight kernels add their split-K partial tiles with fp32 atomics, whose order is the workgroups' arrival order:
  * two runs of the same step differ in the last bits of the weight gradients.  on = 1 (or FS_DETERMINISTIC=1 in the environment at

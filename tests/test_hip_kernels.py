@@ -223,6 +223,10 @@ CONV_CASES_FULLRES = [
     (8, 80, 80, 64, 128, 3, 2),      # tap-class kernel, stride 2 (four classes)
     (8, 80, 80, 64, 256, 1, 1),      # plain kernel, 1x1
     (4, 80, 80, 960, 240, 3, 1),     # C1 cbr: 30 K-chunks
+    (64, 80, 80, 64, 64, 3, 2),      # round 4, at the bench batch: stride-2 forward over parity planes (64 columns), bwd-data with four parities per
+                                     # workgroup, bwd-weight as nine gathered-row GEMMs
+    (64, 20, 20, 256, 512, 3, 2),    # ... 128-column forward, bwd-weight on the nine-accumulator kernel + per-split slabs + ordered reduce
+    (16, 80, 80, 960, 512, 3, 4),    # the C1 classification head's stride-4 conv: bwd-weight as nine gathered-row GEMMs
 ]
 
 
