@@ -510,10 +510,19 @@ def test_training_trajectory_same_in_every_conv_mode():
         fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
     ref = curves["f32"]
     spread = float(((curves["f32_again"] - ref).abs() / ref.abs()).max())
-    assert spread <= 3e-2, ("two f32 runs of the same 40 steps drifted apart by more than atomics-order noise explains", spread)
-    bound = min(3.0 * max(spread, 1.5e-2), 8e-2)
+    # Training a 130 M-parameter net on ONE batch of four images is chaotic: the last-bit noise of the bwd-weight atomics grows from step
+    # to step (two f32 runs of the same 40 steps: spread 0.01-0.03 in most runs, 0.10 seen once; in deterministic mode they are bit-identical,
+    # tests/test_ddp_gloo.py).  So the check has two parts: (a) over the FIRST TEN steps, before the noise has grown, every mode stays
+    # within a fixed 2e-2 of the f32 curve (measured 1.4e-3 / 1.9e-3 / 4.4e-3) -- a wrong gradient anywhere separates the curves from step 2 on; (b) over all 40 steps within
+    # 3 x the measured spread, capped (the bound must not widen without limit, and the f32 noise itself has a ceiling).
+    assert spread <= 0.15, ("two f32 runs of the same 40 steps drifted apart by more than atomics-order noise explains", spread)
+    early = float(((curves["f32_again"] - ref).abs() / ref.abs())[:10].max())
+    assert early <= 2e-2, ("f32 twice, first ten steps", early)
+    bound = min(3.0 * max(spread, 1.5e-2), 0.2)
     for name, c in curves.items():
         assert torch.isfinite(c).all() and float(c[-3:].mean()) < (2.0 / 3.0) * float(c[:3].mean()), (name, c)
         assert abs(float(c[0]) - float(ref[0])) <= 1e-4 * float(ref[0]), (name, float(c[0]), float(ref[0]))      # same forward before any update
-        rel = float(((c - ref).abs() / ref.abs()).max())
-        assert rel <= bound, (name, rel, spread, bound, c, ref)
+        rel = (c - ref).abs() / ref.abs()
+        print(f"trajectory {name}: first ten steps {float(rel[:10].max()):.2e}, all {float(rel.max()):.2e} (f32 spread {spread:.2e}, bound {bound:.2e})")
+        assert float(rel[:10].max()) <= 2e-2, (name, "first ten steps", float(rel[:10].max()))
+        assert float(rel.max()) <= bound, (name, float(rel.max()), spread, bound, c, ref)
