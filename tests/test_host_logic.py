@@ -31,6 +31,28 @@ def test_library_exports_every_declared_symbol():
     assert exported == declared
 
 
+def test_stale_library_refuses_to_load(monkeypatch):
+    """the library is stamped with a content hash of the sources it was built from, and hip.load() refuses a library whose
+    stamp differs from the csrc/ beside it (a shipped .so can never silently be older than its sources)."""
+    from fovealseg import build
+    assert build.built_hash() == build.source_hash(), "run __graft_entry__.build(): the in-tree library is not built from these sources"
+    assert not build.needs_build()
+    monkeypatch.setattr(build, "source_hash", lambda flags=build.FLAGS: "0" * 64)
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.delenv("FS_HIP_LIB", raising=False)
+    with pytest.raises(hip.HipLibraryError, match="built from other sources"):
+        hip.load()
+
+
+def test_shipped_library_has_no_experiment_switches():
+    """Kernel A/B switches exist only in the -DFS_EXPERIMENTS build (csrc/common.h: FS_ENV_INT): the shipped library reads exactly two
+    environment variables, FS_CONV_PRECISION and FS_DETERMINISTIC."""
+    blob = open(hip.LIB_PATH, "rb").read()
+    names = set(re.findall(rb"FS_[A-Z0-9_]{3,}", blob))
+    assert names <= {b"FS_CONV_PRECISION", b"FS_DETERMINISTIC"}, sorted(names)
+    assert b"FS_CONV_PRECISION" in names and b"FS_DETERMINISTIC" in names
+
+
 def test_header_is_plain_c(tmp_path):
     """The drop-in boundary is a C ABI: include/fovealseg.h must compile as C99 on its own (no torch, no HIP headers)."""
     src = tmp_path / "t.c"
