@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_planes_kernel(MpArgs a) {
   // ---- loader constants: item i of a thread = (slot (tid >> 4) + 16 i, channel quad cq); the slot's plane by a compare chain over the
   // (wave-uniform) plane table, once per kernel ----
   const int cq = tid & 15;
-  int xcode[MP_NXI], xdelta[MP_NXI];     // (source row << 16 | source column) relative to the halo origin, -1 = unused; byte offset
+  int xcode[MP_NXI];                     // (source row << 16 | source column) relative to the halo origin, -1 = unused (its byte offset is formed per patch: ten fewer registers live across the MFMA loop, which is at the 256-register limit)
 #pragma unroll
   for (int i = 0; i < MP_NXI; ++i) {
     const int slot = (tid >> 4) + 16 * i;
@@ -330,8 +330,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_planes_kernel(MpArgs a) {
     const int hy = div_small1(local, mg), hx = local - hy * wc;
     const int ry = a.st * hy + pr, rx = a.st * hx + pc;
     xcode[i] = (slot < a.nslots && ci0 + 4 * cq < a.Cin) ? ((ry << 16) | rx) : -1;
-    xdelta[i] = ((ry * a.Wx + rx) * a.Cin + ci0 + 4 * cq) * 4;
   }
+  const int xchan = (ci0 + 4 * cq) * 4;
   int ycode[MP_NYI], ydelta[MP_NYI];
 #pragma unroll
   for (int i = 0; i < MP_NYI; ++i) {
@@ -391,9 +391,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_planes_kernel(MpArgs a) {
     const int ybase = ((b * a.H + y0) * a.W + x0) * a.Cout * 4;
 #pragma unroll
     for (int i = 0; i < MP_NXI; ++i) {
-      const int iy = iy0 + (xcode[i] >> 16), ix = ix0 + (xcode[i] & 0xffff);
+      const int ry_ = xcode[i] >> 16, rx_ = xcode[i] & 0xffff;
+      const int iy = iy0 + ry_, ix = ix0 + rx_;
       const bool ok = xcode[i] >= 0 && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx;
-      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? xbase + xdelta[i] : (int)OOB, 0, 0));
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? xbase + (ry_ * a.Wx + rx_) * a.Cin * 4 + xchan : (int)OOB, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < MP_NYI; ++i) {
