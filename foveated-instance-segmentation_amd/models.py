@@ -193,7 +193,9 @@ class DeformSegmentationModule(nn.Module):
         ops.reset_step_state()
         ops.DDP_ACTIVE = ops.under_torch_ddp(self)      # wrapped by torch DDP: weight gradients go through AccumulateGrad (ops.py)
         if segSize is not None:
-            raise NotImplementedError("segSize inference branch (models/models.py:621-631) is not on the default path")
+            raise NotImplementedError("forward(segSize=...): the reference has no inference branch left either -- its forward body is one "
+                                      "`if segSize is None:` block (models/models.py:828-1094) and falls off the end, returning None, which its only "
+                                      "caller (eval.py:178-180) cannot unpack; use is_inference=True (train.eval_step) for evaluation")
         cfg = self.cfg
         x = feed_dict["img_data"].contiguous()
         y = feed_dict["seg_label"]
