@@ -1114,6 +1114,7 @@ int launch_affine(const ConvArgs& c, long M) {
     return fs_pointwise_conv(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, (long)c.B * c.Hd * c.Wd, c.Cs, c.Cd,
                              c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key,
                              c.stream_);
+  if ((!c.transposed || c.stride == 1) && fs_ws_mode_tls != 0) return FS_ERR_ARG;      // the plain kernel has no weight pack
   if (!c.transposed || c.stride == 1) return launch_affine_one(a);
   if (use_s2bwd(c))
     return fs_s2bwd_conv(g_conv_precision, c.src, c.w, c.dst, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cd, c.Hs, c.Ws, c.Cs, c.stream_);
@@ -1121,6 +1122,7 @@ int launch_affine(const ConvArgs& c, long M) {
   // tap r iff (y + pad - r) % stride == 0, i.e. r = r0 + stride*t with r0 = (oy0 + pad) % stride, and then
   // reads dY row (y + pad - r)/stride = py + (oy0 + pad - r0)/stride - t.
   const int st = c.stride;
+  if (fs_ws_mode_tls != 0) return FS_ERR_ARG;      // the parity sub-problems below re-pack ws one after the other: no pack outlives the call
   // classes no tap reaches (stride > filter size: 7 of 16 for 3x3 stride 4, 15 of 16 for 1x1 stride 4) are zero-filled by one
   // store-only launch instead of one conv launch each (1x1 stride 4, 1.57 GB of dX: 1.13 -> 0.55 ms)
   const bool fill_ok = st * st <= 32 && c.Cd % 4 == 0 && c.bias == nullptr;
@@ -1276,6 +1278,41 @@ int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Co
   if (use_s2bwd(c)) return 6;
   if (transposed && stride > 1 && use_tapset(c)) return 3;     // the multi-tap parity sub-problems
   return 1;
+}
+
+// include/fovealseg.h: 1 when the scratch of this problem is ONE weight pack that depends on (w, shape, precision mode) only, so a caller
+// may keep it across calls (fs_conv2d_pack once per weight update, then FS_WS_RUN_ONLY calls); 0 = no pack, or one that does not outlive the call
+int fs_conv2d_pack_persistent(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                              int transposed, long ws_bytes) {
+  const int k = fs_conv2d_kernel_choice(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, ws_bytes);
+  if (k == 2 || k == 4 || k == 5 || k == 6 || k == 7) return 1;
+  return (k == 3 && !(transposed && stride > 1)) ? 1 : 0;
+}
+
+// include/fovealseg.h: set how the calling thread's next conv calls treat ws (0 pack + run, 1 run only: ws holds the pack); returns the old mode
+int fs_conv2d_ws_mode(int mode) {
+  const int old = fs_ws_mode_tls;
+  if (mode == 0 || mode == FS_WS_RUN_ONLY) fs_ws_mode_tls = mode;
+  return old;
+}
+
+// include/fovealseg.h: run only the weight pack of the kernel fs_conv2d_fwd* (transposed = 0) / fs_conv2d_bwd_data* (1) select for this problem
+int fs_conv2d_pack(const float* w, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                   int transposed, void* ws, long ws_bytes, const unsigned* w_amax, hipStream_t stream) {
+  FS_REQUIRE(w && ws && ws_bytes > 0 && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && dil >= 1);
+  FS_REQUIRE(Ho == (H + 2 * pad - dil * (R - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (S - 1) - 1) / stride + 1);
+  FS_REQUIRE(fs_conv2d_pack_persistent(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, ws_bytes) == 1);
+  // src / dst are never dereferenced: every family returns after its pack launch in this mode (the predicate above excludes the rest)
+  const float* nowhere = reinterpret_cast<const float*>(ws);
+  ConvArgs a = transposed ? ConvArgs{nowhere, w, nullptr, reinterpret_cast<float*>(ws), B, Ho, Wo, Cout, H, W, Cin, R, S, stride, pad, dil, 1, 1.f, 0u, 0u}
+                          : ConvArgs{nowhere, w, nullptr, reinterpret_cast<float*>(ws), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0, 1.f, 0u, 0u};
+  a.stream_ = stream;
+  a.ws_ = ws; a.ws_bytes_ = ws_bytes; a.w_amax_ = w_amax;
+  const int old = fs_ws_mode_tls;
+  fs_ws_mode_tls = FS_WS_PACK_ONLY;
+  const int e = launch_affine(a, 0);
+  fs_ws_mode_tls = old;
+  return e;
 }
 
 // include/fovealseg.h: fs_conv2d_stats_slabs -- number of [Cout][2] partial-sum slabs fs_conv2d_fwd_stats writes for

@@ -335,9 +335,12 @@ __global__ __launch_bounds__(256, (NW == 1 && P::NPL == 2) ? 3 : 2) void conv3x3
 
 }  // namespace
 
+thread_local int fs_ws_mode_tls = 0;
+
 const unsigned* fs_f16_weight_amax(const float* w, long n, void* ws, const unsigned* w_amax, hipStream_t stream, int* err) {
   *err = FS_OK;
   if (w_amax != nullptr) return w_amax;          // the caller keeps max|w| of this tensor up to date (fs_weight_amax_segments)
+  if (fs_ws_mode_tls == FS_WS_RUN_ONLY) return reinterpret_cast<const unsigned*>(ws);      // left there by the pack-only call
   hipError_t e = hipMemsetAsync(ws, 0, 4, stream);
   if (e != hipSuccess) { *err = (int)e; return nullptr; }
   int ab = cdiv(n, 256 * 8); if (ab > 256) ab = 256;
@@ -417,9 +420,12 @@ static int run_halo(HaloArgs& a, const float* w, void* ws, const unsigned* w_ama
   a.ew = P::SCALED ? fs_f16_weight_amax(w, (long)9 * Cin * Cout, ws, w_amax, stream, &e) : nullptr;
   if (e != FS_OK) return e;
   const long total = (long)a.nchunk * 18 * a.Npad;
-  hipLaunchKernelGGL((conv_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws),
-                     a.ew, Cin, Cout, transposed, a.Cs, a.Cd, a.Npad, total);
-  FS_LAUNCH_CHECK();
+  if (fs_ws_mode_tls != FS_WS_RUN_ONLY) {
+    hipLaunchKernelGGL((conv_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws),
+                       a.ew, Cin, Cout, transposed, a.Cs, a.Cd, a.Npad, total);
+    FS_LAUNCH_CHECK();
+  }
+  if (fs_ws_mode_tls == FS_WS_PACK_ONLY) return FS_OK;
   if (nw == 2) hipLaunchKernelGGL((conv3x3_halo_kernel<P, 2>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv3x3_halo_kernel<P, 1>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();

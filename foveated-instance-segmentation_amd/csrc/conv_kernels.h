@@ -19,6 +19,12 @@ int fs_halo_conv3x3(int mode, const float* src, const float* w, const float* bia
 // where the f16x2 kernels read max |w| (float bits) of a weight tensor: w_amax when the caller maintains it, else the first
 // word of ws, filled here by a memset + atomic-max kernel.
 const unsigned* fs_f16_weight_amax(const float* w, long n, void* ws, const unsigned* w_amax, hipStream_t stream, int* err);
+// How the calling thread's next conv entry point treats `ws` (fs_conv2d_ws_mode / fs_conv2d_pack, include/fovealseg.h): 0 = pack the
+// weights into ws, then run (the default); FS_WS_RUN_ONLY = ws already holds this layer's pack for this shape and precision (the pack
+// launch is skipped); FS_WS_PACK_ONLY = run the pack launch and return.  Every kernel family with a weight pack honours it.
+extern thread_local int fs_ws_mode_tls;
+#define FS_WS_RUN_ONLY 1
+#define FS_WS_PACK_ONLY 2
 int fs_weight_amax_segments_impl(const float* arena, const long* offsets, const long* sizes, int nparams, unsigned* out, hipStream_t stream);
 
 // ---- conv_wino.hip: the same problem class with F(2,3) minimal filtering along the row (12 MFMA steps per pixel pair instead of 18).

@@ -286,9 +286,12 @@ static int run_pointwise(PwArgs& a, const float* w, void* ws, const unsigned* w_
   a.ew = P::SCALED ? fs_f16_weight_amax(w, (long)Cin * Cout, ws, w_amax, stream, &e) : nullptr;
   if (e != FS_OK) return e;
   const long total = (long)a.nchunk * 2 * a.Npad;
-  hipLaunchKernelGGL((conv1x1_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws), a.ew,
-                     Cin, Cout, transposed, a.Cs, a.Cd, a.Npad, total);
-  FS_LAUNCH_CHECK();
+  if (fs_ws_mode_tls != FS_WS_RUN_ONLY) {
+    hipLaunchKernelGGL((conv1x1_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws), a.ew,
+                       Cin, Cout, transposed, a.Cs, a.Cd, a.Npad, total);
+    FS_LAUNCH_CHECK();
+  }
+  if (fs_ws_mode_tls == FS_WS_PACK_ONLY) return FS_OK;
   if (nw == 2) hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 2>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 1>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();

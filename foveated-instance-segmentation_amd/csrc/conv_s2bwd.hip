@@ -301,9 +301,12 @@ int run_s2bwd(S2Args& a, const float* w, void* ws, const unsigned* w_amax, int C
   a.ew = P::SCALED ? fs_f16_weight_amax(w, 9L * Cin * Cout, ws, w_amax, stream, &e) : nullptr;
   if (e != FS_OK) return e;
   const long total = (long)a.nchunk * 18 * a.Npad;
-  hipLaunchKernelGGL((conv_s2bwd_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws), a.ew,
-                     Cin, Cout, a.Npad, total);
-  FS_LAUNCH_CHECK();
+  if (fs_ws_mode_tls != FS_WS_RUN_ONLY) {
+    hipLaunchKernelGGL((conv_s2bwd_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws), a.ew,
+                       Cin, Cout, a.Npad, total);
+    FS_LAUNCH_CHECK();
+  }
+  if (fs_ws_mode_tls == FS_WS_PACK_ONLY) return FS_OK;
   hipLaunchKernelGGL((conv_s2bwd_kernel<P>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;

@@ -325,9 +325,12 @@ int run_s2fwd(F2Args& a, const float* w, void* ws, const unsigned* w_amax, int C
   a.ew = P::SCALED ? fs_f16_weight_amax(w, 9L * Cin * Cout, ws, w_amax, stream, &e) : nullptr;
   if (e != FS_OK) return e;
   const long total = (long)a.nchunk * 18 * a.Npad;
-  hipLaunchKernelGGL((conv_s2fwd_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws), a.ew,
-                     Cin, Cout, a.Npad, total);
-  FS_LAUNCH_CHECK();
+  if (fs_ws_mode_tls != FS_WS_RUN_ONLY) {
+    hipLaunchKernelGGL((conv_s2fwd_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws), a.ew,
+                       Cin, Cout, a.Npad, total);
+    FS_LAUNCH_CHECK();
+  }
+  if (fs_ws_mode_tls == FS_WS_PACK_ONLY) return FS_OK;
   constexpr int lds = P::NPL * PLANE * 2;
   {
     static unsigned long long done[2] = {0ull, 0ull};        // the dynamic-LDS opt-in (above 64 KB) is a per-device function attribute

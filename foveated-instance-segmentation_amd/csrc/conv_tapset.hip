@@ -382,10 +382,13 @@ int run_tapset(TsArgs& a, const FsTapsetProblem& p, hipStream_t stream) {
   a.ew = P::SCALED ? fs_f16_weight_amax(p.w, (long)p.R * p.S * p.Cin * p.Cout, p.ws, p.w_amax, stream, &e) : nullptr;
   if (e != FS_OK) return e;
   const long total = (long)a.ttot * 2 * a.Npad;
-  hipLaunchKernelGGL((conv_tapset_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.w,
-                     reinterpret_cast<unsigned char*>(p.ws), a.ew, p.Cin, p.Cout, p.S, p.transposed, p.Cs, p.Cd, a.Npad, a.nchunk, a.ncls,
-                     a.cls[0], a.cls[1], a.cls[2], a.cls[3], a.cls[4], a.cls[5], a.cls[6], a.cls[7], a.cls[8], total);
-  FS_LAUNCH_CHECK();
+  if (fs_ws_mode_tls != FS_WS_RUN_ONLY) {
+    hipLaunchKernelGGL((conv_tapset_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.w,
+                       reinterpret_cast<unsigned char*>(p.ws), a.ew, p.Cin, p.Cout, p.S, p.transposed, p.Cs, p.Cd, a.Npad, a.nchunk, a.ncls,
+                       a.cls[0], a.cls[1], a.cls[2], a.cls[3], a.cls[4], a.cls[5], a.cls[6], a.cls[7], a.cls[8], total);
+    FS_LAUNCH_CHECK();
+  }
+  if (fs_ws_mode_tls == FS_WS_PACK_ONLY) return FS_OK;
 #ifdef FS_EXPERIMENTS          // the 128-column form is measured-and-rejected (below): only the A/B build carries it
   if (a.nw == 2) hipLaunchKernelGGL((conv_tapset_kernel<P, 2>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
   else

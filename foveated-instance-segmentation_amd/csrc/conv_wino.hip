@@ -958,9 +958,12 @@ int run_wino(WinoArgs& a, const float* w, void* ws, const unsigned* w_amax, int 
   a.ew = P::SCALED ? fs_f16_weight_amax(w, (long)9 * Cin * Cout, ws, w_amax, stream, &e) : nullptr;
   if (e != FS_OK) return e;
   const long total = (long)a.nchunk * 12 * a.Npad;
-  hipLaunchKernelGGL((wino_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws),
-                     a.ew, Cin, Cout, transposed, a.Cs, a.Cd, a.Npad, total);
-  FS_LAUNCH_CHECK();
+  if (fs_ws_mode_tls != FS_WS_RUN_ONLY) {
+    hipLaunchKernelGGL((wino_pack_kernel<P>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, reinterpret_cast<unsigned char*>(ws),
+                       a.ew, Cin, Cout, transposed, a.Cs, a.Cd, a.Npad, total);
+    FS_LAUNCH_CHECK();
+  }
+  if (fs_ws_mode_tls == FS_WS_PACK_ONLY) return FS_OK;
   const long ntile = (long)a.nx * a.ny;
   const int slots = wino_grid_slots();
   // the dynamic-LDS opt-in (above the 64 KB default) is a per-device function attribute: set it once on every device used

@@ -42,6 +42,7 @@ SIGNATURES = {
     "fs_conv2d_bwd_data": "pppiiiiiiiiiiiiplp",
     "fs_conv2d_bwd_data_bnsum": "pppiiiiiiiiiiiiplp" + "ppppp" + "pp",
     "fs_weight_amax_segments": "pppip",
+    "fs_conv2d_pack": "p" + "iiiiiiiiiiii" + "i" + "plp",
     "fs_conv2d_bwd_weight": "pppiiiiiiiiiiiii" + "pl",
     "fs_linear_bwd_weight_bias": "pppp" + "lii" + "ii" + "pl",
     "fs_bn_stats": "pliffppppp",
@@ -97,7 +98,8 @@ HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_worksp
              "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes", "fs_conv2d_bwd_data_bnsum_slabs",
              "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes", "fs_attention_bwd_split_ws_bytes", "fs_attention_mask_words", "fs_attention_bwd_split_parts_offset",
              "fs_stream_wait", "fs_set_deterministic", "fs_get_deterministic", "fs_conv2d_bwd_weight_ws_bytes", "fs_linear_bwd_weight_bias_ws_bytes",
-             "fs_colsum_scratch_floats", "fs_bn_stats_scratch_doubles", "fs_mask_head_bwd_scratch_floats", "fs_layernorm_bwd_scratch_floats")
+             "fs_colsum_scratch_floats", "fs_bn_stats_scratch_doubles", "fs_mask_head_bwd_scratch_floats", "fs_layernorm_bwd_scratch_floats",
+             "fs_conv2d_pack_persistent", "fs_conv2d_ws_mode")
 
 
 class HipLibraryError(RuntimeError):
@@ -154,6 +156,10 @@ def load():
     lib.fs_conv2d_stats_slabs.argtypes = [_I] * 12 + [_L]
     lib.fs_conv2d_kernel_choice.restype = _I
     lib.fs_conv2d_kernel_choice.argtypes = [_I] * 13 + [_L]
+    lib.fs_conv2d_pack_persistent.restype = _I
+    lib.fs_conv2d_pack_persistent.argtypes = [_I] * 13 + [_L]
+    lib.fs_conv2d_ws_mode.restype = _I
+    lib.fs_conv2d_ws_mode.argtypes = [_I]
     lib.fs_bn_bwd_slabs.restype = _I
     lib.fs_bn_bwd_slabs.argtypes = [_L, _I]
     lib.fs_dwconv3_wgrad_lanes.restype = _I
@@ -326,6 +332,16 @@ def stream_wait(waiter, signaller):
     err = lib.fs_stream_wait(waiter, signaller)
     if err != 0:
         raise HipLibraryError(f"fs_stream_wait: hipError {err}")
+
+
+def call_packed(name, *args):
+    """`call` for a conv entry point whose scratch already holds this layer's weight pack (fs_conv2d_ws_mode, ops.PackCache)."""
+    lib = _lib if _lib is not None else load()
+    lib.fs_conv2d_ws_mode(1)
+    try:
+        call(name, *args)
+    finally:
+        lib.fs_conv2d_ws_mode(0)
 
 
 def call(name, *args):

@@ -6,6 +6,7 @@ reference's logical (Cout,Cin,R,S) shape with RSCK strides, so `w.permute(2,3,1,
 """
 import ctypes
 import os
+import weakref
 import zlib
 
 import torch
@@ -168,19 +169,129 @@ def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1, w_amax=No
         return torch.cat([conv2d_fwd(x[b0:b1], w, bias, stride, pad, 0.0, 0, dil, w_amax) for b0, b1 in ranges])
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
     kind = _conv_kind(Cin, Cout, R, S, stride, pad, dil)
-    ws, ws_bytes = _conv_workspace(x.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0)
-    _launch(kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd", hip.ptr(x), hip.ptr(rsck(w)), hip.ptr(bias),
+    ws, ws_bytes, packed = _pack_for(w, x.device, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0)
+    _launch_conv(packed, kind, 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd", hip.ptr(x), hip.ptr(rsck(w)), hip.ptr(bias),
             hip.ptr(y), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, float(drop_p), int(drop_key), hip.ptr(ws), ws_bytes,
             hip.ptr(w_amax))
     return y
 
 
-def _conv_workspace(device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed):
-    """Scratch for the pre-split weight pack of the halo-tiled 3x3 kernel (None, 0 when the shape does not use it)."""
+# ---- weight packs that outlive the call ------------------------------------------------------------------------------------------
+# Every split-precision conv kernel starts with a small launch that writes the layer's weights, split into their 16-bit terms in
+# consumption order, into its scratch (438 + 186 such launches per HRNet step, 5-8 us each, on the critical path of a stream whose
+# other kernels fill the chip).  The weights of a parameter that lives in an optimiser arena (train.FlatParams) only change when that
+# arena is rewritten -- FlatAdam.step, a broadcast, load_state_dict; each bumps the arena's epoch word -- so such a parameter keeps one
+# scratch per (problem, direction, precision mode): `train_step` refills the scratches used in the last step on a side stream right
+# after the optimiser step (repack_weights: they overlap the next step's front end), and the conv entry points are told the scratch is
+# already packed (fs_conv2d_ws_mode).  Parameters without an arena (bare tensors in tests, derived weights built per call) keep the
+# pack-then-run call.  FS_PACK_PERSIST=0 (read once) restores that for every layer.
+PACK_PERSIST = os.environ.get("FS_PACK_PERSIST", "1") != "0"
+PACK_GROUP = 32           # packs per hand-over event of the prefetch
+_PACK_ORDER = []          # weak references to every live pack, in first-use order (= the order the next step needs them)
+_PACK_SIDE = {}           # device index -> torch Stream of the prefetch
+
+
+class _PackGroup:
+    __slots__ = ("event", "waited")
+
+    def __init__(self):
+        self.event, self.waited = None, set()
+
+
+class _Pack:
+    __slots__ = ("w", "args", "transposed", "ws", "n", "mode", "cell", "epoch", "version", "used", "group", "stream", "ready", "__weakref__")
+
+
+def _pack_for(w, device, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed):
+    """(scratch | None, bytes, already packed?) for a conv entry point on weight tensor `w`."""
     n = hip.conv_workspace_bytes(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed)
     if n == 0:
-        return None, 0
-    return torch.empty(n, device=device, dtype=torch.uint8), n
+        return None, 0, False
+    cell = getattr(w, "_fs_epoch", None) if PACK_PERSIST else None
+    if cell is None or not hip.query("fs_conv2d_pack_persistent", B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, n):
+        return torch.empty(n, device=device, dtype=torch.uint8), n, False
+    packs = w.__dict__.get("_fs_packs")
+    if packs is None:
+        packs = w.__dict__["_fs_packs"] = {}
+    mode = hip.get_conv_precision()
+    key = (transposed, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, mode)
+    e = packs.get(key)
+    if e is None:
+        e = packs[key] = _Pack()
+        e.w, e.args, e.transposed, e.n, e.mode = weakref.ref(w), key[1:13], transposed, n, mode
+        e.ws = torch.empty(n, device=device, dtype=torch.uint8)
+        e.cell, e.epoch, e.version, e.group, e.stream, e.ready = cell, -1, -1, None, None, set()
+        _PACK_ORDER.append(weakref.ref(e))
+    e.used = True
+    cur = hip.STREAM_OVERRIDE if hip.STREAM_OVERRIDE is not None else hip._stream()
+    if e.cell is cell and e.epoch == cell[0] and e.version == w._version:
+        if cur not in e.ready:          # first use on this stream since the pack was enqueued: order the stream behind it
+            g = e.group
+            if g is not None:
+                if cur not in g.waited:
+                    torch.cuda.current_stream().wait_event(g.event)
+                    g.waited.add(cur)
+            elif e.stream is not None and e.stream != cur:
+                hip.stream_wait(cur, e.stream)
+            e.ready.add(cur)
+        return e.ws, n, True
+    # stale (or new): this call packs on its own stream, later calls of the same epoch run on the result
+    e.cell, e.epoch, e.version, e.group, e.stream, e.ready = cell, cell[0], w._version, None, cur, {cur}
+    return e.ws, n, False
+
+
+def repack_weights():
+    """Refill, on a side stream, every weight pack that was used since the last call and whose arena has been rewritten since it was
+    packed (train.train_step calls this right after the optimiser steps; a frozen optimiser's packs stay valid and are skipped).  The
+    consuming streams wait for the event of the pack's group at first use (_pack_for)."""
+    if not PACK_PERSIST or not _PACK_ORDER or TIMER is not None:
+        return
+    mode = hip.get_conv_precision()
+    todo, live = [], []
+    for r in _PACK_ORDER:
+        e = r()
+        if e is None:
+            continue
+        live.append(r)
+        w = e.w()
+        if w is None or not e.used or e.mode != mode:
+            continue
+        e.used = False
+        cell = getattr(w, "_fs_epoch", None)
+        if cell is None or (e.cell is cell and e.epoch == cell[0] and e.version == w._version):
+            continue
+        todo.append((e, w, cell))
+    _PACK_ORDER[:] = live
+    if not todo:
+        return
+    dev = todo[0][1].device
+    side = _PACK_SIDE.get(dev.index)
+    if side is None:
+        side = _PACK_SIDE[dev.index] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())          # the optimiser step (and the arena's max|w| refresh) come first
+    raw = side.cuda_stream
+    hip.STREAM_OVERRIDE = raw
+    try:
+        group = _PackGroup()
+        for i, (e, w, cell) in enumerate(todo):
+            hip.call("fs_conv2d_pack", hip.ptr(rsck(w)), *e.args, e.transposed, hip.ptr(e.ws), e.n, hip.ptr(weight_amax(w)))
+            e.cell, e.epoch, e.version, e.group, e.stream, e.ready = cell, cell[0], w._version, group, raw, set()
+            if (i + 1) % PACK_GROUP == 0 or i + 1 == len(todo):
+                group.event = torch.cuda.Event()
+                group.event.record(side)
+                group = _PackGroup()
+    finally:
+        hip.STREAM_OVERRIDE = None
+
+
+def _launch_conv(packed, kind, flops, name, *args):
+    """_launch for the conv entry points; packed = their scratch already holds the weight pack (fs_conv2d_ws_mode)."""
+    if not packed:
+        return _launch(kind, flops, name, *args)
+    if TIMER is None:
+        hip.call_packed(name, *args)
+    else:
+        TIMER.launch(kind, flops, lambda: hip.call_packed(name, *args), tag=(name,) + tuple(a for a in args if type(a) is int and a < (1 << 20)))
 
 
 FUSE_BN_STATS = True     # BatchNorm batch statistics come out of the conv epilogue (fs_conv2d_fwd_stats)
@@ -201,10 +312,10 @@ def conv2d_fwd_stats(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1, w_a
         parts = [conv2d_fwd_stats(x[b0:b1], w, bias, stride, pad, 0.0, 0, dil, w_amax) for b0, b1 in ranges]
         return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]), sum(p[2] for p in parts)
     y = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=torch.float32)
-    ws, ws_bytes = _conv_workspace(x.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0)
+    ws, ws_bytes, packed = _pack_for(w, x.device, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0)
     nwg = hip.conv_stats_slabs(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_bytes)
     slab = torch.empty(nwg * Cout * 2, device=x.device, dtype=torch.float32)
-    _launch(_conv_kind(Cin, Cout, R, S, stride, pad, dil), 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd_stats", hip.ptr(x), hip.ptr(rsck(w)),
+    _launch_conv(packed, _conv_kind(Cin, Cout, R, S, stride, pad, dil), 2.0 * B * Ho * Wo * Cout * R * S * Cin, "fs_conv2d_fwd_stats", hip.ptr(x), hip.ptr(rsck(w)),
             hip.ptr(bias), hip.ptr(y), hip.ptr(slab), B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, float(drop_p), int(drop_key),
             hip.ptr(ws), ws_bytes, hip.ptr(w_amax))
     return y, slab, nwg
@@ -235,7 +346,7 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1, w_amax=None, src_bn=None
         return dx
     dx = torch.empty(B, H, W, Cin, device=dy.device, dtype=torch.float32)
     kind = _conv_kind(Cout, Cin, R, S, stride, pad, dil)
-    ws, ws_bytes = _conv_workspace(dy.device, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 1)
+    ws, ws_bytes, packed = _pack_for(w, dy.device, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 1)
     flops = 2.0 * B * Ho * Wo * Cout * R * S * Cin
     if src_bn is not None and not (FUSE_BN_BWD_SUMS and FANOUT and tuple(src_bn[0].shape) == (B, H, W, Cin)):
         src_bn = None
@@ -245,13 +356,13 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1, w_amax=None, src_bn=None
             y, amask, mean, invstd = src_bn[:4] if src_bn is not None else (None, None, None, None)
             slab = torch.empty(rows * Cin * 2, device=dy.device, dtype=torch.float32) if src_bn is not None else None
             a_src, a_mask = addend if addend is not None else (None, None)
-            _launch(kind, flops, "fs_conv2d_bwd_data_bnsum", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx), B, H, W, Cin, Ho, Wo, Cout, R, S,
+            _launch_conv(packed, kind, flops, "fs_conv2d_bwd_data_bnsum", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx), B, H, W, Cin, Ho, Wo, Cout, R, S,
                     stride, pad, dil, hip.ptr(ws), ws_bytes, hip.ptr(w_amax), hip.ptr(y), hip.ptr(amask), hip.ptr(mean), hip.ptr(invstd),
                     hip.ptr(slab), hip.ptr(a_src), hip.ptr(a_mask))
             if slab is not None:
                 BN_SLABS[dx.data_ptr()] = (slab, rows, dx)
             return dx
-    _launch(kind, flops, "fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx),
+    _launch_conv(packed, kind, flops, "fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx),
             B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, hip.ptr(ws), ws_bytes, hip.ptr(w_amax))
     if addend is not None:          # the library no longer takes the addend for this shape (precision mode changed since the stash): add here
         a_src, a_mask = addend
@@ -559,13 +670,14 @@ class ConvBnAct(Function):
             B_, H_, W_, _ = x.shape
             R_, S_ = w.shape[2], w.shape[3]
             Ho_, Wo_ = _out_hw(H_, W_, R_, S_, meta["stride"], meta["pad"], dil)
-            ws, ws_bytes = _conv_workspace(x.device, H_, W_, Cin, Ho_, Wo_, Cout, R_, S_, meta["stride"], meta["pad"], dil, 0)
+            ws_bytes = hip.conv_workspace_bytes(H_, W_, Cin, Ho_, Wo_, Cout, R_, S_, meta["stride"], meta["pad"], dil, 0)
             if hip.fwd_affine_act_ok(B_, H_, W_, Cin, Ho_, Wo_, Cout, R_, S_, meta["stride"], meta["pad"], dil, ws_bytes):
                 coef = torch.empty(2, Cout, device=x.device, dtype=torch.float32)
                 hip.call("fs_bn_eval_affine", hip.ptr(meta["running_mean"]), hip.ptr(meta["running_var"]), hip.ptr(gamma), hip.ptr(beta), Cout,
                          BN_EPS, hip.ptr(coef[0]), hip.ptr(coef[1]))
                 z = torch.empty(B_, Ho_, Wo_, Cout, device=x.device, dtype=torch.float32)
-                _launch(_conv_kind(Cin, Cout, R_, S_, meta["stride"], meta["pad"], dil), 2.0 * B_ * Ho_ * Wo_ * Cout * R_ * S_ * Cin,
+                ws, ws_bytes, packed = _pack_for(w, x.device, B_, H_, W_, Cin, Ho_, Wo_, Cout, R_, S_, meta["stride"], meta["pad"], dil, 0)
+                _launch_conv(packed, _conv_kind(Cin, Cout, R_, S_, meta["stride"], meta["pad"], dil), 2.0 * B_ * Ho_ * Wo_ * Cout * R_ * S_ * Cin,
                         "fs_conv2d_fwd_affine_act", hip.ptr(x), hip.ptr(rsck(w)), hip.ptr(bias), hip.ptr(coef[0]), hip.ptr(coef[1]), hip.ptr(res),
                         hip.ptr(z), B_, H_, W_, Cin, Ho_, Wo_, Cout, R_, S_, meta["stride"], meta["pad"], dil, meta["act"], hip.ptr(ws), ws_bytes,
                         hip.ptr(wa))

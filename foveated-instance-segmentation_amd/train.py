@@ -27,6 +27,7 @@ class FlatParams:
         self.params = [p for p in params]
         assert self.params, "empty parameter list"
         dev = self.params[0].device
+        self._epoch = [0]          # bumped whenever the arena is rewritten behind the parameters' version counters (refresh_amax)
         offs, n = [], 0
         for p in self.params:
             assert p.dtype == torch.float32
@@ -43,6 +44,7 @@ class FlatParams:
             p.data = view
             p.grad = self.grad.as_strided(size, dense, o)
             p._fs_grad_home = (self.grad, o)          # ops._direct_grad_target: kernels may add into this slice while .grad points at it
+            p._fs_epoch = self._epoch                  # ops._pack_for: a weight pack of p is valid while this word has not moved
             del stride
         self.offsets = offs
         # max|w| bits per parameter, kept current by refresh_amax(): the f16x2 conv kernels scale the weights by it
@@ -55,6 +57,7 @@ class FlatParams:
     def refresh_amax(self):
         """One launch: max|w| of every parameter of the arena.  Parameters remember their word and the torch version counter
         at this moment (ops.weight_amax drops the word if the tensor is modified through torch afterwards)."""
+        self._epoch[0] += 1
         if not self.data.is_cuda:
             return
         hip.call("fs_weight_amax_segments", hip.ptr(self.data), hip.ptr(self._offs_dev), hip.ptr(self._sizes_dev), len(self.params),
@@ -331,6 +334,8 @@ def train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=0):
             if not zoom:            # segmentation module frozen
                 continue
         opt.step()
+    from . import ops
+    ops.repack_weights()      # the conv layers' weight packs of the next step, on a side stream beside its front end
     return out
 
 

@@ -125,6 +125,20 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
  * aligned kernels address the source with 32-bit byte offsets, so they are chosen only below 4 GB.  Host-side predicate. */
 int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                             int transposed, long ws_bytes);
+/* Weight packs that outlive the call.  The kernels of families 2-7 above start with a small launch that writes the layer's weights,
+ * split into their 16-bit terms in consumption order, into ws; the weights only change at the optimiser step, so a caller may keep one
+ * scratch per (layer, direction), fill it once per weight update -- on any stream, e.g. beside the first kernels of the next step
+ * -- and run the convolutions on it (every nn.Conv2d on the path, e.g. models/hrnetv2_nodownsp.py:49-55).
+ *   fs_conv2d_pack_persistent: 1 when ws of this problem is ONE pack that depends on (w, shape, precision mode) only, else 0.
+ *   fs_conv2d_pack: run only that pack launch (FS_ERR_ARG when the predicate is 0; nothing is launched then).
+ *   fs_conv2d_ws_mode(1): the calling thread's following conv entry points take ws as already packed for their problem and skip the
+ *     pack launch, until fs_conv2d_ws_mode(0); returns the previous mode.  A problem whose kernel has no persistent pack fails with
+ *     FS_ERR_ARG in mode 1 instead of running on stale scratch.  Host-side, thread-local. */
+int fs_conv2d_pack_persistent(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                              int transposed, long ws_bytes);
+int fs_conv2d_pack(const float* w, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                   int transposed, void* ws, long ws_bytes, const unsigned* w_amax, fs_stream_t stream);
+int fs_conv2d_ws_mode(int mode);
 /* Number of [Cout][2] partial-sum slabs fs_conv2d_fwd_stats writes for this shape given ws_bytes of scratch. */
 int fs_conv2d_stats_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                           long ws_bytes);

@@ -2,6 +2,7 @@
 the committed golden fixtures.  Run on the MI355X box:  python -m pytest tests -m gpu -x -q
 Tolerances: bit-exact for integer/index work and grid_sample forward; fp32 otherwise, stated per test.
 """
+import copy
 import os
 
 import numpy as np
@@ -211,6 +212,133 @@ def test_bwd_weight_deterministic_mode(case, prec):
         H_.set_deterministic(False)
     if not (k == 3 and s in (2, 3) and prec != "f32"):          # (strided 3x3 layers take the store + ordered-reduce route in every mode)
         assert int(H_.load().fs_conv2d_bwd_weight_ws_bytes(Ci, Co, k, k, s, pad, 1)) == 0
+
+
+# Weight packs that outlive the call (include/fovealseg.h: fs_conv2d_pack / fs_conv2d_ws_mode; ops._pack_for, ops.repack_weights).
+PACK_CASES = [
+    (4, 16, 16, 64, 64, 3, 1),       # F(2,3) kernel (even width)
+    (2, 15, 15, 64, 64, 3, 1),       # halo-tiled kernel (odd width)
+    (2, 20, 20, 256, 256, 3, 1),     # eight-wave F(2,3) form in bf16x3
+    (4, 16, 16, 64, 128, 3, 2),      # stride 2: parity-plane forward, four-parity bwd-data
+    (4, 16, 16, 64, 256, 1, 1),      # 1x1 GEMM kernel
+    (2, 16, 16, 32, 64, 5, 1),       # tap-class kernel (5x5)
+    (2, 16, 16, 64, 64, 3, 3),       # stride 3: bwd-data re-packs per parity class -> no persistent pack
+]
+
+
+@pytest.mark.parametrize("case", PACK_CASES)
+def test_persistent_weight_pack(case, prec):
+    """fs_conv2d_pack once, then run-only calls: bit-identical to the pack-then-run call; the run-only call really reads the scratch
+    (new weights, old pack -> old result); a problem without a persistent pack refuses the run-only mode."""
+    B, H, W, Ci, Co, k, s = case
+    H_ = fovealseg.hip
+    lib = H_.load()
+    g = torch.Generator().manual_seed(Ci + 3 * Co + k + s)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    x = torch.randn(B, H, W, Ci, generator=g).to(DEV)
+    dy = torch.randn(B, Ho, Wo, Co, generator=g).to(DEV)
+    w = (torch.randn(k, k, Ci, Co, generator=g) / (k * Ci ** 0.5)).to(DEV)
+    w2 = w * 1.5
+    shape = (B, H, W, Ci, Ho, Wo, Co, k, k, s, pad, 1)
+    for transposed in (0, 1):
+        n = H_.conv_workspace_bytes(*shape[1:], transposed)
+        if prec == "f32":
+            assert n == 0
+            continue
+        src, dst = (dy, torch.empty(B, H, W, Ci, device=DEV)) if transposed else (x, torch.empty(B, Ho, Wo, Co, device=DEV))
+
+        def run(weights, ws, packed):
+            out = torch.empty_like(dst)
+            if transposed:
+                args = ("fs_conv2d_bwd_data", H_.ptr(src), H_.ptr(weights), H_.ptr(out), *shape, H_.ptr(ws), n, None)
+            else:
+                args = ("fs_conv2d_fwd", H_.ptr(src), H_.ptr(weights), None, H_.ptr(out), *shape, 0.0, 0, H_.ptr(ws), n, None)
+            (H_.call_packed if packed else H_.call)(*args)
+            return out
+
+        if n == 0:
+            continue
+        ref = run(w, torch.empty(n, device=DEV, dtype=torch.uint8), False)
+        persistent = int(lib.fs_conv2d_pack_persistent(*shape, transposed, n))
+        choice = int(lib.fs_conv2d_kernel_choice(*shape, transposed, n))
+        if not persistent:
+            assert choice in (0, 1, 3), choice
+            with pytest.raises(H_.HipLibraryError):
+                run(w, torch.empty(n, device=DEV, dtype=torch.uint8), True)
+            with pytest.raises(H_.HipLibraryError):
+                H_.call("fs_conv2d_pack", H_.ptr(w), *shape, transposed, H_.ptr(torch.empty(n, device=DEV, dtype=torch.uint8)), n, None)
+            assert int(lib.fs_conv2d_ws_mode(0)) == 0          # call_packed put the mode back although the call raised
+            continue
+        ws = torch.full((n,), 0xA5, device=DEV, dtype=torch.uint8)
+        H_.call("fs_conv2d_pack", H_.ptr(w), *shape, transposed, H_.ptr(ws), n, None)
+        a = run(w, ws, True)
+        b = run(w, ws, True)
+        assert torch.equal(a, ref) and torch.equal(b, ref), (choice, transposed)
+        stale = run(w2, ws, True)                                # the pack is what the kernel reads
+        assert torch.equal(stale, ref)
+        fresh = run(w2, ws, False)                               # the default mode re-packs
+        assert relerr(fresh, 1.5 * ref) <= 1e-5
+        assert int(lib.fs_conv2d_ws_mode(0)) == 0
+
+
+def test_weight_packs_follow_every_arena_rewrite():
+    """ops._pack_for / ops.repack_weights against the pack-per-call path, in deterministic mode (bit-identical or wrong): three training
+    steps (the prefetch after each optimiser step, the frozen-optimiser window, an eval pass between steps), then load_state_dict and a
+    torch-side in-place edit of one weight -- every way the weights change has to invalidate the packs."""
+    from fovealseg import train
+    H_ = fovealseg.hip
+    dev = torch.device("cuda", 0)
+    cfg = fovealseg.lvis50_cfg()
+    batch = train.synthetic_batch(4, 256, 256, seed=5, device=dev)
+
+    def run(persist):
+        ops.PACK_PERSIST = persist
+        module, nets = train.build_module(cfg, device=dev)
+        module.train()
+        optimizers = train.create_optimizers(nets, cfg)
+        ops.DropoutState.seed, ops.DropoutState.step = 11, 0
+        outs = []
+        for it in range(3):
+            outs.append(float(train.train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=it)[0]))
+        module.eval()
+        outs.append(float(train.eval_step(module, batch)[0]))
+        module.train()
+        outs.append(float(train.train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=3)[0]))
+        frozen = copy.deepcopy(cfg)                # deformation module frozen: only two of the four arenas are rewritten by this step
+        frozen.TRAIN.fix_deform_aft_pretrain, frozen.TRAIN.fix_deform_start_epoch, frozen.TRAIN.fix_deform_end_epoch = True, 1, 1
+        outs.append(float(train.train_step(module, optimizers, batch, frozen, epoch=1, cur_iter=4)[0]))
+        outs.append(float(train.train_step(module, optimizers, batch, cfg, epoch=1, cur_iter=5)[0]))
+        sd = {k: v.clone() for k, v in module.state_dict().items()}
+        for k in sd:
+            if sd[k].dtype == torch.float32 and sd[k].dim() == 4:
+                sd[k] = sd[k] * 0.5
+        module.load_state_dict(sd)
+        for o in optimizers:
+            o.flat.refresh_amax()          # what train.load_checkpoint does after rewriting the parameters
+        module.eval()
+        outs.append(float(train.eval_step(module, batch)[0]))
+        with torch.no_grad():
+            next(p for p in module.encoder.parameters() if p.dim() == 4 and p.shape[-1] == 3).mul_(2.0)      # torch-side edit: version counter
+        outs.append(float(train.eval_step(module, batch)[0]))
+        torch.cuda.synchronize()
+        npacks = sum(len(p.__dict__.get("_fs_packs", ())) for p in module.parameters())
+        return outs, [o.flat.data.clone() for o in optimizers], npacks
+
+    assert not H_.get_deterministic()
+    H_.set_deterministic(True)
+    keep = ops.PACK_PERSIST
+    try:
+        la, pa, na = run(True)
+        lb, pb, nb = run(False)
+    finally:
+        ops.PACK_PERSIST = keep
+        H_.set_deterministic(False)
+    assert na > 300 and nb == 0, (na, nb)          # the packs exist (forward and bwd-data of every conv layer) / the switch turns them off
+    assert la == lb, (la, lb)
+    assert len(set(la)) == len(la), la             # every stage really changed the result
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)
 
 
 # Production spatial sizes (ADVICE r1): many pixel tiles per image, image borders inside tiles, the stacked-batch tiling of the
