@@ -178,14 +178,17 @@ def conv2d_fwd(x, w, bias, stride, pad, drop_p=0.0, drop_key=0, dil=1, w_amax=No
 
 # ---- weight packs that outlive the call ------------------------------------------------------------------------------------------
 # Every split-precision conv kernel starts with a small launch that writes the layer's weights, split into their 16-bit terms in
-# consumption order, into its scratch (438 + 186 such launches per HRNet step, 5-8 us each, on the critical path of a stream whose
-# other kernels fill the chip).  The weights of a parameter that lives in an optimiser arena (train.FlatParams) only change when that
-# arena is rewritten -- FlatAdam.step, a broadcast, load_state_dict; each bumps the arena's epoch word -- so such a parameter keeps one
-# scratch per (problem, direction, precision mode): `train_step` refills the scratches used in the last step on a side stream right
-# after the optimiser step (repack_weights: they overlap the next step's front end), and the conv entry points are told the scratch is
-# already packed (fs_conv2d_ws_mode).  Parameters without an arena (bare tensors in tests, derived weights built per call) keep the
-# pack-then-run call.  FS_PACK_PERSIST=0 (read once) restores that for every layer.
-PACK_PERSIST = os.environ.get("FS_PACK_PERSIST", "1") != "0"
+# consumption order, into its scratch (438 + 186 such launches per HRNet step).  The library can keep a pack across calls
+# (fs_conv2d_pack / fs_conv2d_ws_mode): a parameter whose owner says when it changes -- an optimiser arena (train.FlatParams bumps
+# its epoch word at FlatAdam.step, a broadcast, load_state_dict) or static_weight_packs(module) for a serving process -- then keeps one
+# scratch per (problem, direction, precision mode); with an arena, `train_step` refills the scratches used in the last step on a side
+# stream right after the optimiser step (repack_weights) and the conv entry points are told the scratch is already packed.
+# Measured on the headline step (profiles/r04/pack_persist_ab.txt): +-0 (374.7 / 372.7 / 372.9 -> 374.6 / 373.5 / 372.7 img/s); with NO
+# pack launch at all (stale packs, timing only) 172.0 -> 170.7 ms -- the 4.5 ms the packs take when the kernels are serialised is
+# hidden in the real step, and packs on a side stream still need the CUs the persistent conv kernels fill.  configs[4] +1-2 %,
+# configs[3] -0.7 % (19 ms more host time per step).  So: OFF for arena parameters unless FS_PACK_PERSIST=1 (read once); always on
+# for parameters marked static.  Parameters with neither (bare tensors in tests, derived weights built per call) pack per call.
+PACK_PERSIST = os.environ.get("FS_PACK_PERSIST", "0") == "1"
 PACK_GROUP = 32           # packs per hand-over event of the prefetch
 _PACK_ORDER = []          # weak references to every live pack, in first-use order (= the order the next step needs them)
 _PACK_SIDE = {}           # device index -> torch Stream of the prefetch
@@ -207,7 +210,7 @@ def _pack_for(w, device, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, tra
     n = hip.conv_workspace_bytes(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed)
     if n == 0:
         return None, 0, False
-    cell = getattr(w, "_fs_epoch", None) if PACK_PERSIST else None
+    cell = getattr(w, "_fs_epoch", None) if (PACK_PERSIST or getattr(w, "_fs_static", False)) else None
     if cell is None or not hip.query("fs_conv2d_pack_persistent", B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, n):
         return torch.empty(n, device=device, dtype=torch.uint8), n, False
     packs = w.__dict__.get("_fs_packs")
@@ -224,7 +227,7 @@ def _pack_for(w, device, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, tra
         _PACK_ORDER.append(weakref.ref(e))
     e.used = True
     cur = hip.STREAM_OVERRIDE if hip.STREAM_OVERRIDE is not None else hip._stream()
-    if e.cell is cell and e.epoch == cell[0] and e.version == w._version:
+    if (e.cell is cell and e.epoch == cell[0] and e.version == w._version):
         if cur not in e.ready:          # first use on this stream since the pack was enqueued: order the stream behind it
             g = e.group
             if g is not None:
@@ -240,11 +243,28 @@ def _pack_for(w, device, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, tra
     return e.ws, n, False
 
 
+def static_weight_packs(module, on=True):
+    """Serving: the parameters of `module` do not change between forwards (no optimiser): keep every conv layer's weight pack after its
+    first forward -- no pack launch from the second forward on.  Call again after rewriting the weights through anything that does not
+    move torch's version counters; load_state_dict and in-place torch ops are seen without it."""
+    for p in module.parameters():
+        if on:
+            cell = p.__dict__.get("_fs_epoch")
+            if cell is None:
+                p._fs_epoch = [0]
+            else:
+                cell[0] += 1
+            p._fs_static = True
+        else:
+            p.__dict__.pop("_fs_static", None)
+            p.__dict__.pop("_fs_packs", None)
+
+
 def repack_weights():
     """Refill, on a side stream, every weight pack that was used since the last call and whose arena has been rewritten since it was
     packed (train.train_step calls this right after the optimiser steps; a frozen optimiser's packs stay valid and are skipped).  The
     consuming streams wait for the event of the pack's group at first use (_pack_for)."""
-    if not PACK_PERSIST or not _PACK_ORDER or TIMER is not None:
+    if not _PACK_ORDER or TIMER is not None:
         return
     mode = hip.get_conv_precision()
     todo, live = [], []

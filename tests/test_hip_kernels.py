@@ -341,6 +341,37 @@ def test_weight_packs_follow_every_arena_rewrite():
         assert torch.equal(x, y)
 
 
+def test_static_weight_packs_for_serving():
+    """ops.static_weight_packs: a serving process (no optimiser) keeps every conv layer's pack after the first forward; the results are
+    those of the pack-per-call path, before and after the weights are replaced through load_state_dict."""
+    from fovealseg import train
+    dev = torch.device("cuda", 0)
+    cfg = fovealseg.lvis50_cfg()
+    batch = train.synthetic_batch(2, 256, 256, seed=7, device=dev)
+    module, _ = train.build_module(cfg, device=dev)
+    module.eval()
+    assert not ops.PACK_PERSIST
+    ref0 = [float(v) for v in train.eval_step(module, batch)]
+    sd = {k: (v * 0.5 if v.dtype == torch.float32 and v.dim() == 4 else v.clone()) for k, v in module.state_dict().items()}
+    keep = {k: v.clone() for k, v in module.state_dict().items()}
+    module.load_state_dict(sd)
+    ref1 = [float(v) for v in train.eval_step(module, batch)]
+    module.load_state_dict(keep)
+    assert sum(len(p.__dict__.get("_fs_packs", ())) for p in module.parameters()) == 0
+    ops.static_weight_packs(module)
+    a = [float(v) for v in train.eval_step(module, batch)]
+    n1 = sum(len(p.__dict__.get("_fs_packs", ())) for p in module.parameters())
+    b = [float(v) for v in train.eval_step(module, batch)]           # second forward: every pack is reused
+    assert n1 > 100 and n1 == sum(len(p.__dict__.get("_fs_packs", ())) for p in module.parameters())
+    assert a == ref0 and b == ref0, (a, b, ref0)
+    module.load_state_dict(sd)
+    c = [float(v) for v in train.eval_step(module, batch)]
+    assert c == ref1 and ref1 != ref0, (c, ref1, ref0)
+    ops.static_weight_packs(module, on=False)
+    assert sum(len(p.__dict__.get("_fs_packs", ())) for p in module.parameters()) == 0
+    assert [float(v) for v in train.eval_step(module, batch)] == ref1
+
+
 # Production spatial sizes (ADVICE r1): many pixel tiles per image, image borders inside tiles, the stacked-batch tiling of the
 # small maps -- the multi-tile paths the <= 24x24 cases above barely touch.  fp64 reference, max-norm over every element.
 CONV_CASES_FULLRES = [
