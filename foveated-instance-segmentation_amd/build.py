@@ -64,7 +64,7 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, experiments: bool = False) -> str:
-    flags = FLAGS + (["-DFS_EXPERIMENTS"] if experiments else [])
+    flags = FLAGS + (["-DFS_EXPERIMENTS"] + os.environ.get("FS_BUILD_DEFINES", "").split() if experiments else [])
     lib = LIB
     objdir = CSRC
     if experiments:

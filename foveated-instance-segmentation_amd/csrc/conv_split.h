@@ -81,6 +81,40 @@ struct PrecX3 {
     p[1] = (T)r;
     p[2] = (T)(r - (float)p[1]);
   }
+#ifdef FS_SPLIT_CVT
+  // kernel A/B builds only (measured +-0 against the integer form below, profiles/r04/split_ab.txt): planes by v_cvt_pk_bf16_f32,
+  // remainders either by v_dot2c_f32_bf16 with the packed constants (-1, 0) / (0, -1) (FS_SPLIT_CVT=2: 7 VALU per value pair, three
+  // wait states per dot) or by unpack + subtract (FS_SPLIT_CVT=1: 11 per pair)
+  static __device__ __forceinline__ void split4(f32x4 v, x4 (&p)[NPL]) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 pk[NPL];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f2 x = {v[2 * h], v[2 * h + 1]};
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        const b2 q = __builtin_convertvector(x, b2);
+        const unsigned qu = __builtin_bit_cast(unsigned, q);
+        pk[pl][h] = qu;
+        if (pl + 1 < NPL) {
+#if FS_SPLIT_CVT == 2
+          const b2 sel0 = {(__bf16)-1.0f, (__bf16)0.0f}, sel1 = {(__bf16)0.0f, (__bf16)-1.0f};
+          const float r0 = __builtin_amdgcn_fdot2_f32_bf16(q, sel0, x[0], false);
+          const float r1 = __builtin_amdgcn_fdot2_f32_bf16(q, sel1, x[1], false);
+#else
+          const float r0 = x[0] - __builtin_bit_cast(float, qu << 16);
+          const float r1 = x[1] - __builtin_bit_cast(float, qu & 0xffff0000u);
+#endif
+          x[0] = r0; x[1] = r1;
+        }
+      }
+    }
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) p[pl] = __builtin_bit_cast(x4, pk[pl]);
+  }
+#else
   // the same decomposition on 4 values in integer arithmetic: a plane is the fp32 value rounded to its top 16 bits
   // ((bits + 0x8000) & 0xffff0000, ties away from zero), the remainder x - plane is exact in fp32, and the third plane takes
   // what is left (<= 8 significant bits: exact).  x = p0 + p1 + p2 holds exactly, as for split(); the planes can differ from
@@ -107,6 +141,7 @@ struct PrecX3 {
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) p[pl] = __builtin_bit_cast(x4, pk[pl]);
   }
+#endif
   static constexpr int NTERM = 6;            // (0,2) (1,1) (2,0) (0,1) (1,0) (0,0)
   static __device__ __forceinline__ constexpr int ta(int t) { return t < 3 ? t : (t == 4 ? 1 : 0); }
   static __device__ __forceinline__ constexpr int tb(int t) { return t < 3 ? 2 - t : (t == 3 ? 1 : 0); }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-shape table of the conv C-ABI calls of the serialised headline step (HIP events per call, branch streams off):
 entry point, integer arguments, calls per step, total ms per step, us per call, algorithmic TF.
-Usage: python tools/shape_table.py [steps] [kinds comma list, default conv_affine,conv_wgrad]"""
+Usage: python tools/shape_table.py [steps] [kinds comma list, default conv_affine,conv_wgrad]
+FS_SHAPE_CONFIG=config3|config4 and FS_SHAPE_BATCH select another BASELINE configuration."""
 import os
 import sys
 
@@ -17,12 +18,18 @@ def main():
     fovealseg.hip.set_conv_precision(os.environ.get("FS_CONV_PRECISION", "bf16x3"))
     dev = torch.device("cuda", 0)
     cfg = fovealseg.lvis50_cfg()
+    which, size, nb = os.environ.get("FS_SHAPE_CONFIG", "headline"), 1024, int(os.environ.get("FS_SHAPE_BATCH", "64"))
+    if which == "config3":
+        cfg.MODEL.arch_encoder, cfg.MODEL.fc_dim = "segformer", 1024
+        cfg.TRAIN.task_input_size = (160, 160)
+    elif which == "config4":
+        cfg.MODEL.arch_encoder, size = "deeplab", 2048
     module, nets = T.build_module(cfg, device=dev)
     module.train()
     opts = T.create_optimizers(nets, cfg)
     for o in opts:
         o.flat.refresh_amax()
-    batch = T.synthetic_batch(64, 1024, 1024, seed=1, device=dev)
+    batch = T.synthetic_batch(nb, size, size, seed=1, device=dev)
     Mods.PARALLEL_BRANCHES = False
     for i in range(2):
         T.train_step(module, opts, batch, cfg, epoch=1, cur_iter=i)
