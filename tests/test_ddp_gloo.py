@@ -248,17 +248,22 @@ def _gpu_torch_ddp_worker(rank, world, port, out):
     loss_b = fwd_bwd(ddp)
     assert ops.DDP_ACTIVE is True                 # the forward saw the wrapper
     torch.cuda.synchronize()
-    errs = []
+    errs, worst = [], []
     for o, w in zip(optimizers, want):
         o.check_grads_in_arena()                  # the reducer wrote INTO the arena views, .grad was never re-pointed
         errs.append(float((o.flat.grad - w).norm() / w.norm().clamp_min(1e-30)))
+        if errs[-1] > 1e-5:                       # diagnostics for the assertion message: which parameters of the arena differ
+            d = (o.flat.grad - w).abs()
+            per = sorted(((float(d[off:off + p.numel()].max()), float(w[off:off + p.numel()].abs().max()), i, tuple(p.shape))
+                          for i, (p, off) in enumerate(zip(o.flat.params, o.flat.offsets))), reverse=True)[:4]
+            worst.append((len(o.flat.params), sum(1 for x in per if x[0] > 0), per))
     # a whole train_step through the wrapper: no second exchange, Adam sees grad_scale 1, replicas stay identical
     ops.DropoutState.step = 0
     p_before = [o.flat.data.clone() for o in optimizers]
     train.train_step(ddp, optimizers, batch, cfg, epoch=1, cur_iter=0)
     torch.cuda.synchronize()
     moved = [float((o.flat.data - p0).abs().max()) for o, p0 in zip(optimizers, p_before)]
-    out[rank] = dict(errs=errs, loss_a=loss_a, loss_b=loss_b, scales=[o.grad_scale for o in optimizers], moved=moved,
+    out[rank] = dict(errs=errs, worst=worst, loss_a=loss_a, loss_b=loss_b, scales=[o.grad_scale for o in optimizers], moved=moved,
                      digest=[float(o.flat.data.double().sum()) for o in optimizers])
     dist.barrier()
     dist.destroy_process_group()
@@ -272,8 +277,8 @@ def test_reference_ddp_wrapper_line_on_gpu():
     mp.spawn(_gpu_torch_ddp_worker, args=(world, port, out), nprocs=world, join=True)
     a, b = out[0], out[1]
     for r in (a, b):
-        assert max(r["errs"]) <= 1e-5, r["errs"]             # reducer average == explicit arena all-reduce x 1/world (float atomics: 1e-5)
-        assert abs(r["loss_a"] - r["loss_b"]) <= 1e-5 * max(1.0, abs(r["loss_a"]))
+        assert abs(r["loss_a"] - r["loss_b"]) <= 1e-5 * max(1.0, abs(r["loss_a"])), (a["loss_a"], a["loss_b"], b["loss_a"], b["loss_b"])
+        assert max(r["errs"]) <= 1e-5, (a["errs"], b["errs"], r["worst"])   # reducer average == explicit arena all-reduce x 1/world (float atomics: 1e-5)
         assert r["scales"] == [1.0] * 4                      # DDP already averaged: nothing folded into Adam
         assert all(m > 0 for m in r["moved"][:2])
     assert a["digest"] == b["digest"]                        # replicas bit-identical after the optimiser step
