@@ -36,7 +36,20 @@ constexpr int Y_HALF = YP * 64;
 constexpr int Y_PLANE = 2 * Y_HALF;
 constexpr int NXI = XS * 16 / 256;    // 7 float4 loads per thread for the X halo
 constexpr int NYI = YP * 16 / 256;    // 4 for the dY patch
+// -DFS_WGRAD_TRACE (kernel A/B builds only; tools/wgrad_trace.sh): time stamps of every wave of the 3x3 class kernel around the phases of
+// its patch rounds 2..5 -- loads issued | barrier | loads landed | split + LDS stores | barrier | MFMA loop -- averaged per launch on stderr.
+#ifdef FS_WGRAD_TRACE
+#include <cstdio>
+#define WG_TRACE_FIELD long long* dbg;
+#define WG_STAMP(i) do { if (a.dbg != nullptr && lane == 0 && it >= 2 && it < 6) a.dbg[(((long)blockIdx.x * 4 + wave) * 4 + (it - 2)) * 8 + (i)] = clock64(); } while (0)
+#define WG_WAIT_LOADS() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define WG_TRACE_FIELD
+#define WG_STAMP(i) do { } while (0)
+#define WG_WAIT_LOADS() do { } while (0)
+#endif
 struct WgArgs {
+  WG_TRACE_FIELD
   const float* x;    // (B,Hx,Wx,Cin)
   const float* dy;   // (B,H,W,Cout)
   float* dw;         // [R][S][Cin][Cout], zero-initialised or accumulated into
@@ -47,6 +60,7 @@ struct WgArgs {
   int tiles_ci, tiles_co;
   unsigned x_bytes, dy_bytes;
   unsigned magic_wh, magic_pw;      // 2^32 / (Pw + NS - 1) + 1, 2^32 / Pw + 1: slot / pixel index -> (row, column) without integer division
+  int prio;                         // 1: issue priority rises through the MFMA loop (see the kernel)
   FsPart part;                      // deterministic mode: slab `split` takes this workgroup's tile (conv_kernels.h)
 };
 
@@ -153,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
     if (++ptx >= a.tiles_x) { ptx = 0; if (++pty >= a.tiles_y) { pty = 0; ++pb_; } }
 
     f32x4 rx[NXI], ry[NYI];
+    WG_STAMP(0);
     const int iy0 = a.sm * y0 + a.cy, ix0 = a.sm * x0 + a.cx;                       // source pixel of halo slot (0, 0)
     const int xbase = ((b * a.Hx + iy0) * a.Wx + ix0) * a.Cin * 4;                  // may be negative (padding); base + delta is not, where valid
     const int ybase = ((b * a.H + y0) * a.W + x0) * a.Cout * 4;
@@ -168,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
       const bool ok = pvalid && ycode[i] >= 0 && y < a.H && x < a.W;
       ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, ok ? ybase + ydelta[i] : (int)OOB, 0, 0));
     }
+    WG_STAMP(1);
     float sx = 1.f, sy = 1.f;
     if (P::SCALED) {   // tile maxima -> LDS cells of this patch's parity
       float mx = 0.f, my = 0.f;
@@ -183,6 +199,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
       if (lane == 0) { atomicMax(&amax_cell[par][0], __builtin_bit_cast(unsigned, mx)); atomicMax(&amax_cell[par][1], __builtin_bit_cast(unsigned, my)); }
     }
     __syncthreads();     // maxima complete; every wave has finished reading the previous patch
+    WG_STAMP(2);
+    WG_WAIT_LOADS();
+    WG_STAMP(3);
     if (P::SCALED) {
       const int ex = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[par][0]));
       const int ey = __builtin_amdgcn_readfirstlane(exponent_of_bits(amax_cell[par][1]));
@@ -212,11 +231,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Yl[yw + i * 1024 + pl * Y_PLANE]) = p[pl];
     }
+    WG_STAMP(4);
     __syncthreads();
+    WG_STAMP(5);
 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       if (ks < nk) {
+        // a.prio (A/B builds): issue priority rises through the MFMA loop and drops to 0 for the load / split phase.  The SIMD arbitrates
+        // by priority, then AGE: at equal priority the older of the two resident waves takes the matrix pipe whenever it wants it and
+        // the younger workgroup only progresses in the older one's load / split windows (FS_WGRAD_TRACE: MFMA loop 8 500 cycles in wave
+        // slot 0, 18 400 in slot 1; once the older workgroup has left, the younger runs alone with the pipe idle during its own
+        // load / split).  With the priority growing, the wave that entered its MFMA loop first finishes it at full rate and the two
+        // workgroups alternate (both 9 700) -- see launch_class for why that is not the default.
+        if (a.prio) {
+          if (ks == 0) __builtin_amdgcn_s_setprio(1);
+          else if (ks == 1) __builtin_amdgcn_s_setprio(2);
+          else if (ks == 2) __builtin_amdgcn_s_setprio(3);
+        }
         X8 fb[NPL], fa[2][NPL];
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) fb[pl] = cat(tr(Yl, yb + ks * 1024 + pl * Y_PLANE), tr(Yl, yb + ks * 1024 + 256 + pl * Y_PLANE));
@@ -239,6 +271,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_class_kernel(WgArgs a) {
         }
       }
     }
+    if (a.prio) __builtin_amdgcn_s_setprio(0);
+    WG_STAMP(6);
+#ifdef FS_WGRAD_TRACE
+    if (a.dbg != nullptr && lane == 0 && it == 2) a.dbg[(((long)blockIdx.x * 4 + wave) * 4) * 8 + 7] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
   }
 
   const int co = co0 + 32 * wn + (lane & 31);
@@ -1017,8 +1054,86 @@ int launch_class(WgArgs a, int ntile, FsPartHost* ph, hipStream_t stream) {
   a.patches_per_split = cdiv(a.npatch, nsplit);
   nsplit = cdiv(a.npatch, a.patches_per_split);
   if (part_claim(ph, nsplit, a.part) != FS_OK) return FS_ERR_ARG;
+  {
+    // kernel A/B builds only.  Measured (profiles/r04/wgrad_phase_trace.txt): the rounds of the two workgroups of a CU even out (14 500 /
+    // 25 000 -> 15 900 cycles each) and the MFMA loops of the launch end 18 % earlier -- but then all 512 workgroups reach their split-K
+    // atomics together instead of half of them early, the launch takes 4 % LONGER alone and the training step is unchanged (the
+    // step is power-limited): off.
+    static const int prio = FS_ENV_INT("FS_WGRAD_PRIO", 0);
+    a.prio = prio;
+  }
+#ifdef FS_WGRAD_TRACE
+  static long long* dbg = nullptr;
+  const long nwg = (long)ntile * nsplit;
+  const bool traced = NR == 3 && NS == 3 && nwg <= 4096 && a.patches_per_split >= 6;
+  if (traced) {
+    if (dbg == nullptr && hipMalloc(&dbg, sizeof(long long) * 4096 * 4 * 4 * 8) != hipSuccess) return FS_ERR_ARG;
+    if (hipMemsetAsync(dbg, 0, sizeof(long long) * nwg * 4 * 4 * 8, stream) != hipSuccess) return FS_ERR_ARG;
+  }
+  a.dbg = traced ? dbg : nullptr;
+#endif
   hipLaunchKernelGGL((conv_wgrad_class_kernel<P, NR, NS>), dim3((unsigned)(ntile * nsplit)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
+#ifdef FS_WGRAD_TRACE
+  if (traced) {
+    static long long host[4096 * 4 * 4 * 8];
+    if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(host, dbg, sizeof(long long) * nwg * 128, hipMemcpyDeviceToHost) != hipSuccess) return FS_ERR_ARG;
+    // phases: [0->1] address + issue loads, [1->2] barrier (partners still multiplying), [2->3] loads landed, [3->4] split + LDS stores,
+    // [4->5] barrier, [5->6] MFMA loop, [6->0'] loop overhead to the next round's top; per wave, rounds 2..4 (round 5 has no successor stamp)
+    double sum[8] = {0}, skew_mfma = 0, round_len = 0; long n = 0, nr = 0;
+    double par_mfma[2] = {0, 0}, par_round[2] = {0, 0}, par_start[2] = {0, 0}; long par_n[2] = {0, 0};
+    long long tmin = 0;
+    for (long w_ = 0; w_ < nwg; ++w_) { const long long v = host[(w_ * 4 * 4) * 8]; if (v != 0 && (tmin == 0 || v < tmin)) tmin = v; }
+    for (long w_ = 0; w_ < nwg; ++w_) {
+      for (int it = 0; it < 3; ++it) {
+        long long end_min = 0, end_max = 0;
+        for (int wv = 0; wv < 4; ++wv) {
+          const long long* t = host + ((w_ * 4 + wv) * 4 + it) * 8;
+          const long long* tn = t + 8;
+          if (t[0] == 0 || t[6] == 0 || tn[0] == 0) continue;
+          for (int i = 0; i < 6; ++i) sum[i] += (double)(t[i + 1] - t[i]);
+          sum[6] += (double)(tn[0] - t[6]);
+          round_len += (double)(tn[0] - t[0]);
+          {
+            const int par = (int)((unsigned)host[((w_ * 4 + wv) * 4) * 8 + 7] & 1u);
+            par_mfma[par] += (double)(t[6] - t[5]); par_round[par] += (double)(tn[0] - t[0]); ++par_n[par];
+            if (it == 0) par_start[par] += (double)(t[0] - tmin);
+          }
+          ++n;
+          if (wv == 0 || t[6] < end_min) end_min = t[6];
+          if (wv == 0 || t[6] > end_max) end_max = t[6];
+        }
+        skew_mfma += (double)(end_max - end_min); ++nr;
+      }
+    }
+    {
+      long hist[16] = {0}; long same = 0, pairs = 0;
+      static int cu_slot[8][16][16][4];      // [xcc guess = wg % 8][se][cu][simd] -> last wave_id seen
+      for (auto& a0 : cu_slot) for (auto& a1 : a0) for (auto& a2 : a1) for (int& v : a2) v = -1;
+      for (long w_ = 0; w_ < nwg; ++w_)
+        for (int wv = 0; wv < 4; ++wv) {
+          const unsigned id = (unsigned)host[((w_ * 4 + wv) * 4) * 8 + 7];
+          const int wid = id & 15, simd = (id >> 4) & 3, cu = (id >> 8) & 15, se = (id >> 13) & 7;
+          ++hist[wid];
+          int& prev = cu_slot[w_ % 8][se][cu][simd];
+          if (prev >= 0) { ++pairs; if ((prev & 1) == (wid & 1)) ++same; }
+          prev = wid;
+        }
+      fprintf(stderr, "wgrad trace: wave_id histogram");
+      for (int i = 0; i < 16; ++i) if (hist[i]) fprintf(stderr, " %d:%ld", i, hist[i]);
+      fprintf(stderr, " | SIMDs with two traced waves %ld, of them with EQUAL slot parity %ld\n", pairs, same);
+    }
+    if (n > 0) {
+      fprintf(stderr, "wgrad trace B%d %dx%d %d->%d patches/split %d grid %ld: round %.0f cyc =", a.B, a.H, a.W, a.Cin, a.Cout, a.patches_per_split, nwg, round_len / n);
+      const char* nm[7] = {"issue", "barrier1", "loads", "split", "barrier2", "mfma", "next"};
+      for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.0f", nm[i], sum[i] / n);
+      fprintf(stderr, " | spread of the four waves' MFMA-loop ends %.0f", skew_mfma / nr);
+      for (int par = 0; par < 2; ++par)
+        if (par_n[par]) fprintf(stderr, " | slot %d: mfma %.0f round %.0f round-2 top at +%.0f", par, par_mfma[par] / par_n[par], par_round[par] / par_n[par], par_start[par] * 3 / par_n[par]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   return FS_OK;
 }
 
