@@ -228,6 +228,11 @@ def broadcast_parameters(optimizers, module=None, src=0):
         opt.flat.refresh_amax()          # the arena was rewritten behind the parameters' version counters
     if module is not None:
         broadcast_buffers(module, src=src)
+    if optimizers and optimizers[0].flat.data.is_cuda:
+        # once, at construction: every rank holds rank 0's parameters before anything reads them on any stream (a device-tensor
+        # broadcast on the gloo backend lands through the backend's own copy stream; one red run of the 2-rank wrapper test in eight
+        # had the two small arenas that are broadcast last differ between a forward right after this call and a later one)
+        torch.cuda.synchronize()
 
 
 class FlatBuffers:
