@@ -1058,7 +1058,7 @@ int launch_class(WgArgs a, int ntile, FsPartHost* ph, hipStream_t stream) {
     // kernel A/B builds only.  Measured (profiles/r04/wgrad_phase_trace.txt): the rounds of the two workgroups of a CU even out (14 500 /
     // 25 000 -> 15 900 cycles each) and the MFMA loops of the launch end 18 % earlier -- but then all 512 workgroups reach their split-K
     // atomics together instead of half of them early, the launch takes 4 % LONGER alone and the training step is unchanged (the
-    // step is power-limited): off.
+    // step follows its switching work, not its stalls: DESIGN.md 4c): off.
     static const int prio = FS_ENV_INT("FS_WGRAD_PRIO", 0);
     a.prio = prio;
   }
