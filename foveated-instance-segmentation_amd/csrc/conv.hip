@@ -1056,6 +1056,15 @@ bool use_pointwise(const ConvArgs& c) {
          (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL && (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;
 }
 
+// forward of stride >= filter layers (3x3 / stride 4, 1x1 / stride 4): the 1x1 GEMM kernel over gathered rows (conv_pointwise.hip)
+static const bool g_pw_gather = FS_ENV_INT("FS_PW_GATHER", 1) != 0;      // kernel A/B builds only
+bool use_pw_gather(const ConvArgs& c) {
+  return g_pw_gather && g_conv_precision >= 1 && !c.transposed && c.ws_ != nullptr && c.bn_ == nullptr &&
+         fs_pointwise_gather_eligible(c.Cs, c.Cd, c.R, c.S, c.stride, c.dil) &&
+         c.ws_bytes_ >= fs_pointwise_pack_bytes(g_conv_precision, c.R * c.S * c.Cs, c.Cd) &&
+         (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL && (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;
+}
+
 // The channel-aligned kernels (plain / halo / tap-class) address the SOURCE tensor with 32-bit BYTE offsets into a raw buffer
 // resource (AffArgs::src_bytes), so the source must stay below 4 GB -- 2^30 elements, not 2^31; larger problems take the
 // 64-bit-indexed conv_igemm_kernel.
@@ -1114,6 +1123,9 @@ int launch_affine(const ConvArgs& c, long M) {
     return fs_pointwise_conv(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, (long)c.B * c.Hd * c.Wd, c.Cs, c.Cd,
                              c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key,
                              c.stream_);
+  if (use_pw_gather(c))
+    return fs_pointwise_gather_conv(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, c.B, c.Hs, c.Ws, c.Cs, c.Hd, c.Wd, c.Cd,
+                                    c.R, c.S, c.stride, c.pad, c.drop_scale, c.drop_thresh, c.drop_key, c.stream_);
   if ((!c.transposed || c.stride == 1) && fs_ws_mode_tls != 0) return FS_ERR_ARG;      // the plain kernel has no weight pack
   if (!c.transposed || c.stride == 1) return launch_affine_one(a);
   if (use_s2bwd(c))
@@ -1250,6 +1262,10 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
     const long t = fs_s2fwd_pack_bytes(g_conv_precision, Cin, Cout);
     if (t > need) need = t;
   }
+  if (g_pw_gather && !transposed && fs_pointwise_gather_eligible(Cin, Cout, R, S, stride, dil)) {
+    const long t = fs_pointwise_pack_bytes(g_conv_precision, R * S * Cin, Cout);
+    if (t > need) need = t;
+  }
   if (g_s2bwd && transposed && fs_s2bwd_eligible(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)) {
     const long t = fs_s2bwd_pack_bytes(g_conv_precision, Cin, Cout);
     if (t > need) need = t;
@@ -1274,7 +1290,7 @@ int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Co
   if (transposed && stride == 1 && use_tapset(c) && !use_halo(c)) return 3;
   if (use_wino(c)) return 5;
   if (use_halo(c)) return 2;
-  if (use_pointwise(c)) return 4;
+  if (use_pointwise(c) || use_pw_gather(c)) return 4;
   if (use_s2bwd(c)) return 6;
   if (transposed && stride > 1 && use_tapset(c)) return 3;     // the multi-tap parity sub-problems
   return 1;

@@ -45,6 +45,11 @@ int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bia
 // ---- conv_pointwise.hip: 1x1 / stride 1 / pad 0 as a GEMM with pre-split weights (forward and bwd-data).  mode: 1 = bf16x3, 2 = f16x2 ----
 bool fs_pointwise_eligible(int Cs, int Cd, int R, int S, int stride, int pad, int dil);
 long fs_pointwise_pack_bytes(int mode, int Cs, int Cd);
+// forward of a stride >= filter convolution as one GEMM over gathered rows (K = R*S*Cin; pack bytes = fs_pointwise_pack_bytes(mode, K, Cout))
+bool fs_pointwise_gather_eligible(int Cin, int Cout, int R, int S, int stride, int dil);
+int fs_pointwise_gather_conv(int mode, const float* x, const float* w, const float* bias, float* y, float* stats, void* ws, const unsigned* w_amax,
+                             int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, float drop_scale,
+                             uint32_t drop_thresh, uint32_t drop_key, hipStream_t stream);
 // M = B*H*W rows; transposed = 1: bwd-data (src = dY with Cs = Cout channels, dst = dX with Cd = Cin).  stats: [ceil(M/128)][Cd][2] or null.
 int fs_pointwise_conv(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
                       long M, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,

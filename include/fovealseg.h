@@ -119,7 +119,8 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
 /* Which kernel family fs_conv2d_fwd (transposed=0) / fs_conv2d_bwd_data (transposed=1) select for this problem under the
  * current precision mode with ws_bytes of scratch: 0 = generic 64-bit-indexed implicit GEMM (any channel count, sources of
  * 4 GB and more), 1 = plain channel-aligned implicit GEMM, 2 = halo-tiled 3x3 stride-1 kernel, 3 = tap-class kernel,
- * 4 = 1x1 / stride-1 GEMM kernel with pre-split weights, 5 = halo-tiled 3x3 stride-1 kernel with F(2,3) minimal filtering along
+ * 4 = 1x1 / stride-1 GEMM kernel with pre-split weights (also the forward of stride >= filter layers with 64-aligned input channels,
+ * as that GEMM over gathered rows), 5 = halo-tiled 3x3 stride-1 kernel with F(2,3) minimal filtering along
  * the row (even widths; 12 instead of 18 matrix steps per pixel pair), 6 = bwd-data of a 3x3 / stride-2 / pad-1 layer with the four
  * output parities in one launch, 7 = its forward with the four input parity planes in one LDS refill per chunk.  The
  * aligned kernels address the source with 32-bit byte offsets, so they are chosen only below 4 GB.  Host-side predicate. */

@@ -130,6 +130,10 @@ CONV_CASES = [
     (2, 23, 17, 3, 64, 7, 2, False),        # ResNet stem 7x7 stride 2 (generic kernel)
     (3, 21, 19, 48, 64, 3, 2, False),       # one channel tile, stride 2: bwd-weight with all nine taps in one launch (parity planes), ragged
     (2, 40, 40, 64, 64, 3, 2, True),        # the HRNet fuse down-path shape of that kernel
+    (2, 20, 20, 128, 96, 3, 4, True),       # stride >= filter with 64-aligned input channels: forward = the 1x1 GEMM kernel over gathered rows
+    (3, 19, 22, 64, 512, 3, 4, False),      # ... ragged size, 128-column workgroups
+    (2, 16, 16, 64, 64, 1, 4, True),        # ... 1x1 stride 4
+    (2, 17, 17, 192, 32, 3, 3, False),      # ... stride = filter size, three rounds per tap
 ]
 
 
