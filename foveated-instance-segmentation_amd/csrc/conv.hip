@@ -1065,6 +1065,14 @@ bool use_pw_gather(const ConvArgs& c) {
          (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL && (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;
 }
 
+// ... and their bwd-data: one 1x1 GEMM per tap, rows scattered to the tap's residue class of dX
+bool use_pw_scatter(const ConvArgs& c) {
+  return g_pw_gather && g_conv_precision >= 1 && c.transposed && c.ws_ != nullptr && c.bias == nullptr && c.bn_ == nullptr &&
+         c.stride * c.stride <= 32 && fs_pointwise_scatter_eligible(c.Cd, c.Cs, c.R, c.S, c.stride, c.dil) &&
+         c.ws_bytes_ >= fs_pointwise_pack_bytes(g_conv_precision, c.Cs, c.Cd) &&
+         (size_t)c.B * c.Hd * c.Wd * c.Cd * 4 < 4294967000UL && (size_t)c.B * c.Hs * c.Ws * c.Cs * 4 < 4294967000UL;
+}
+
 // The channel-aligned kernels (plain / halo / tap-class) address the SOURCE tensor with 32-bit BYTE offsets into a raw buffer
 // resource (AffArgs::src_bytes), so the source must stay below 4 GB -- 2^30 elements, not 2^31; larger problems take the
 // 64-bit-indexed conv_igemm_kernel.
@@ -1135,6 +1143,21 @@ int launch_affine(const ConvArgs& c, long M) {
   // reads dY row (y + pad - r)/stride = py + (oy0 + pad - r0)/stride - t.
   const int st = c.stride;
   if (fs_ws_mode_tls != 0) return FS_ERR_ARG;      // the parity sub-problems below re-pack ws one after the other: no pack outlives the call
+  if (use_pw_scatter(c)) {
+    unsigned empty = 0u;
+    for (int oy0 = 0; oy0 < st; ++oy0)
+      for (int ox0 = 0; ox0 < st; ++ox0)
+        if ((oy0 + c.pad) % st >= c.R || (ox0 + c.pad) % st >= c.S) empty |= 1u << (oy0 * st + ox0);
+    if (empty != 0u) {
+      const long n4 = (long)c.B * c.Hd * c.Wd * (c.Cd / 4);
+      long blocks = (n4 + 255) / 256;
+      if (blocks > 65536) blocks = 65536;
+      hipLaunchKernelGGL(zero_classes_kernel, dim3((unsigned)blocks), dim3(256), 0, c.stream_, c.dst, n4, c.Hd, c.Wd, c.Cd / 4, st, empty);
+      FS_LAUNCH_CHECK();
+    }
+    return fs_pointwise_scatter_conv(g_conv_precision, c.src, c.w, c.dst, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cd, c.Hs, c.Ws, c.Cs, c.R, c.S,
+                                     c.stride, c.pad, c.stream_);
+  }
   // classes no tap reaches (stride > filter size: 7 of 16 for 3x3 stride 4, 15 of 16 for 1x1 stride 4) are zero-filled by one
   // store-only launch instead of one conv launch each (1x1 stride 4, 1.57 GB of dX: 1.13 -> 0.55 ms)
   const bool fill_ok = st * st <= 32 && c.Cd % 4 == 0 && c.bias == nullptr;
@@ -1264,6 +1287,10 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
   }
   if (g_pw_gather && !transposed && fs_pointwise_gather_eligible(Cin, Cout, R, S, stride, dil)) {
     const long t = fs_pointwise_pack_bytes(g_conv_precision, R * S * Cin, Cout);
+    if (t > need) need = t;
+  }
+  if (g_pw_gather && transposed && fs_pointwise_scatter_eligible(Cin, Cout, R, S, stride, dil)) {
+    const long t = fs_pointwise_pack_bytes(g_conv_precision, Cout, Cin);
     if (t > need) need = t;
   }
   if (g_s2bwd && transposed && fs_s2bwd_eligible(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)) {

@@ -50,6 +50,11 @@ bool fs_pointwise_gather_eligible(int Cin, int Cout, int R, int S, int stride, i
 int fs_pointwise_gather_conv(int mode, const float* x, const float* w, const float* bias, float* y, float* stats, void* ws, const unsigned* w_amax,
                              int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, float drop_scale,
                              uint32_t drop_thresh, uint32_t drop_key, hipStream_t stream);
+// bwd-data of those layers: one GEMM per tap whose rows are scattered to the tap's residue class of dX (the caller zero-fills the classes no
+// tap reaches); pack bytes = fs_pointwise_pack_bytes(mode, Cout, Cin)
+bool fs_pointwise_scatter_eligible(int Cin, int Cout, int R, int S, int stride, int dil);
+int fs_pointwise_scatter_conv(int mode, const float* dy, const float* w, float* dx, void* ws, const unsigned* w_amax, int B, int H, int W,
+                              int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, hipStream_t stream);
 // M = B*H*W rows; transposed = 1: bwd-data (src = dY with Cs = Cout channels, dst = dX with Cd = Cin).  stats: [ceil(M/128)][Cd][2] or null.
 int fs_pointwise_conv(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
                       long M, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,

@@ -35,6 +35,10 @@ struct PwArgs {
   // gathered rows (forward of a stride >= filter convolution as ONE GEMM with K = taps x Cin): row m = output pixel (b, oy, ox); the
   // K range of tap (r, s) reads input pixel (oy * st + r - pad, ox * st + s - pad), zeros outside the image.  ntap = 0: plain rows.
   int ntap, S, Hx, Wx, Ho, Wo, st, pad, Cin, rounds_per_tap;
+  // scattered rows (bwd-data of the same layers, one launch per tap): row m = (b, oy, ox) of the dY grid extended to sc_Ho' x sc_Wo' =
+  // (Ho, Wo above; rows past the real grid read zeros) is written to dX pixel (oy * sc_st + sc_dy, ox * sc_st + sc_dx) when that is inside
+  // sc_H x sc_W: every pixel of the tap's residue class is written exactly once, the classes no tap reaches are zero-filled by the caller.
+  int sc_on, sc_st, sc_dy, sc_dx, sc_H, sc_W;
 };
 
 // Wp[g = 2 * chunk + s][plane][n][j] = plane-th term of Wt[k = 32 * chunk + 16 * s + j][n] (scaled by 2^(14-Ew) in f16x2), behind a
@@ -262,6 +266,20 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(PwArgs a) {
     f2 = one ? 1.f : pow2f(Ew - 14);
   }
   const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
+  int* const rowtab = reinterpret_cast<int*>(&Ah[0]);      // scattered rows: element offset of each of the 128 rows' pixel, -1 = no pixel
+  if (a.sc_on) {
+    if (tid < ROWS) {
+      const long row = m0 + tid;
+      int off = -1;
+      if (row < a.M) {
+        const int ox = (int)(row % a.Wo), t = (int)(row / a.Wo), oy = t % a.Ho, b = t / a.Ho;
+        const int iy = oy * a.sc_st + a.sc_dy, ix = ox * a.sc_st + a.sc_dx;
+        if (iy >= 0 && iy < a.sc_H && ix >= 0 && ix < a.sc_W) off = ((b * a.sc_H + iy) * a.sc_W + ix) * a.Cd;
+      }
+      rowtab[tid] = off;
+    }
+    __syncthreads();
+  }
   float csum[NW], csq[NW];
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
@@ -276,8 +294,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(PwArgs a) {
         // accumulator row r of tile mi = tile row (r&3) + 8 (r>>2) + 4 lh; LDS row permutation: tile row t holds pixel row_perm(t)
         const int trow = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const long row = m0 + 64 * wm + 32 * mi + row_perm(trow);
-        const bool live = row < a.M;
-        const unsigned e = (unsigned)(row * a.Cd + n);                 // element index (< 2^30: dst_bytes < 4 GB)
+        const int ro = a.sc_on ? rowtab[64 * wm + 32 * mi + row_perm(trow)] : 0;
+        const bool live = a.sc_on ? ro >= 0 : row < a.M;
+        const unsigned e = a.sc_on ? (unsigned)(ro + n) : (unsigned)(row * a.Cd + n);      // element index (< 2^30: dst_bytes < 4 GB)
         float v = P::SCALED ? fmaf(acc[mi][j][r] * f2, f1, bv) : acc[mi][j][r] + bv;
         if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
         v = live ? v : 0.f;
@@ -364,6 +383,7 @@ int fs_pointwise_conv(int mode, const float* src, const float* w, const float* b
   a.ws_bytes = (unsigned)pack_bytes;
   a.drop_scale = drop_scale; a.drop_thresh = drop_thresh; a.drop_key = drop_key;
   a.ntap = 0; a.S = 1; a.Hx = a.Wx = a.Ho = a.Wo = 1; a.st = 1; a.pad = 0; a.Cin = Cs; a.rounds_per_tap = 1;
+  a.sc_on = 0; a.sc_st = 1; a.sc_dy = a.sc_dx = 0; a.sc_H = a.sc_W = 1;
   return mode == 2 ? run_pointwise<PrecF16>(a, w, ws, w_amax, Cin, Cout, transposed, nw, stream)
                    : run_pointwise<PrecX3>(a, w, ws, w_amax, Cin, Cout, transposed, nw, stream);
 }
@@ -397,6 +417,47 @@ int fs_pointwise_gather_conv(int mode, const float* x, const float* w, const flo
   a.ws_bytes = (unsigned)pack_bytes;
   a.drop_scale = drop_scale; a.drop_thresh = drop_thresh; a.drop_key = drop_key;
   a.ntap = R * S; a.S = S; a.Hx = H; a.Wx = W; a.Ho = Ho; a.Wo = Wo; a.st = stride; a.pad = pad; a.Cin = Cin; a.rounds_per_tap = Cin / (32 * RC);
+  a.sc_on = 0; a.sc_st = 1; a.sc_dy = a.sc_dx = 0; a.sc_H = a.sc_W = 1;
   return mode == 2 ? run_pointwise<PrecF16>(a, w, ws, w_amax, K, Cout, 0, nw, stream)
                    : run_pointwise<PrecX3>(a, w, ws, w_amax, K, Cout, 0, nw, stream);
+}
+
+// bwd-data of the same layers: an input pixel receives at most ONE tap, so dX = nine (R*S) GEMMs  dY[rows][Cout] W_tap^T[Cout][Cin]  whose
+// result rows land on the tap's residue class of dX.  One launch per tap (each packs its W_tap^T into ws; the launches are in stream order).
+bool fs_pointwise_scatter_eligible(int Cin, int Cout, int R, int S, int stride, int dil) {
+  return stride >= R && stride >= S && stride > 1 && dil == 1 && Cout % 64 == 0 && Cin % 4 == 0 && Cin >= 32 && R * S <= 9;
+}
+
+int fs_pointwise_scatter_conv(int mode, const float* dy, const float* w, float* dx, void* ws, const unsigned* w_amax, int B, int H, int W,
+                              int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, hipStream_t stream) {
+  if (!fs_pointwise_scatter_eligible(Cin, Cout, R, S, stride, 1)) return FS_ERR_ARG;
+  const long pack_bytes = fs_pointwise_pack_bytes(mode, Cout, Cin);
+  if (pack_bytes >= 2147483647L || (size_t)B * H * W * Cin * 4 >= 4294967000UL || (size_t)B * Ho * Wo * Cout * 4 >= 4294967000UL) return FS_ERR_ARG;
+  for (int r = 0; r < R; ++r)
+    for (int s_ = 0; s_ < S; ++s_) {
+      // rows: every (oy, ox) whose pixel (oy * st + r - pad, ox * st + s - pad) can lie inside dX, also past the last real dY row / column
+      const int dyo = r - pad, dxo = s_ - pad;
+      const int He = dyo > H - 1 ? 0 : (H - 1 - dyo) / stride + 1, We = dxo > W - 1 ? 0 : (W - 1 - dxo) / stride + 1;
+      if (He <= 0 || We <= 0) continue;
+      PwArgs a;
+      a.src = dy; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = nullptr; a.dst = dx; a.stats = nullptr;
+      a.M = (long)B * He * We; a.Cs = Cout; a.Cd = Cin;
+      const int nwp = pw_nw(Cin);
+      a.Npad = ((Cin + 64 * nwp - 1) / (64 * nwp)) * 64 * nwp;
+      a.nchunk = Cout / 32;
+      a.nx = cdiv(a.M, ROWS);
+      a.ny = nwp == 2 ? a.Npad / 128 : (Cin + 63) / 64;
+      a.src_bytes = (unsigned)((size_t)B * Ho * Wo * Cout * 4);
+      a.dst_bytes = (unsigned)((size_t)B * H * W * Cin * 4);
+      a.ws_bytes = (unsigned)pack_bytes;
+      a.drop_scale = 1.f; a.drop_thresh = 0u; a.drop_key = 0u;
+      // the A rows: the (Ho x Wo) dY image read on the extended (He x We) grid, "stride 1, pad 0, one tap"
+      a.ntap = 1; a.S = 1; a.Hx = Ho; a.Wx = Wo; a.Ho = He; a.Wo = We; a.st = 1; a.pad = 0; a.Cin = Cout; a.rounds_per_tap = Cout / (32 * RC);
+      a.sc_on = 1; a.sc_st = stride; a.sc_dy = dyo; a.sc_dx = dxo; a.sc_H = H; a.sc_W = W;
+      const float* wt = w + (long)(r * S + s_) * Cin * Cout;
+      const int e = mode == 2 ? run_pointwise<PrecF16>(a, wt, ws, w_amax, Cin, Cout, 1, nwp, stream)
+                              : run_pointwise<PrecX3>(a, wt, ws, w_amax, Cin, Cout, 1, nwp, stream);
+      if (e != FS_OK) return e;
+    }
+  return FS_OK;
 }

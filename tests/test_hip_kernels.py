@@ -134,6 +134,7 @@ CONV_CASES = [
     (3, 19, 22, 64, 512, 3, 4, False),      # ... ragged size, 128-column workgroups
     (2, 16, 16, 64, 64, 1, 4, True),        # ... 1x1 stride 4
     (2, 17, 17, 192, 32, 3, 3, False),      # ... stride = filter size, three rounds per tap
+    (2, 18, 21, 96, 128, 3, 3, False),      # bwd-data of such layers with 64-aligned OUTPUT channels: one GEMM per tap, rows scattered to dX
 ]
 
 
