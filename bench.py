@@ -582,7 +582,7 @@ def family_entries(mode, timer, nsteps):
         else:
             tf = work / (ms * 1e-3) / 1e12
             out["roofline_" + name] = {"kernel": "strided 3x3 convolutions" + (" bwd-weight (conv_wgrad_class / conv_wgrad_planes / gathered linear_wgrad kernels)" if "wgrad" in name
-                                                 else " forward + bwd-data (conv_s2fwd_kernel, conv_s2bwd_kernel; the stride-4 head conv on conv_igemm_split_kernel)"),
+                                                 else " forward + bwd-data (conv_s2fwd_kernel, conv_s2bwd_kernel; the stride-4 head conv on conv1x1_gemm_kernel over gathered / scattered rows)"),
                                        "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                                        "launches_per_step": n // nsteps, "avg_launch_us": round(1e3 * ms / n, 2), "ms_per_step": round(ms / nsteps, 3)}
     return out
