@@ -72,8 +72,12 @@ __global__ __launch_bounds__(256) void conv1x1_pack_kernel(const float* __restri
   }
 }
 
-template <class P, int NW>
+// DB (bf16x3, kernel A/B builds only -- measured slower, see run_pointwise): the two LDS chunk images are a double buffer -- while the
+// MFMAs of 32-channel chunk c run on one image, chunk c + 1 (loaded one round earlier) is split and stored into the other, half of it
+// behind each k16 step; ONE barrier per chunk instead of load -> barrier -> split + store -> barrier -> MFMAs per pair of chunks.
+template <class P, int NW, bool DB>
 __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(PwArgs a) {
+  static_assert(!DB || !P::SCALED, "the double-buffered loop has no running-exponent step");
   typedef typename P::x8 X8;
   typedef typename P::x4 X4;
   constexpr int NPL = P::NPL;
@@ -193,6 +197,86 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(PwArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][j][r] = 0.f;
   int E = EMIN;
+  if constexpr (DB) {
+    f32x4 rq[2][NITEM];          // chunk c + 1 (being split) and chunk c + 2 (in flight)
+    auto load_chunk = [&](int c, f32x4 (&dst)[NITEM]) {
+      const bool in_k = c < a.nchunk;
+      if (a.ntap > 0) {
+        const int cpt = RC * a.rounds_per_tap, tap = c / cpt, cbase = (c - tap * cpt) * 32;
+        const int r = tap / a.S, s_ = tap - r * a.S;
+#pragma unroll
+        for (int i = 0; i < NITEM; ++i) {
+          const int iy = giy[i] + r, ix = gix[i] + s_;
+          const bool ok = in_k && goff[i] >= 0 && iy >= 0 && iy < a.Hx && ix >= 0 && ix < a.Wx;
+          const unsigned base = ((unsigned)((gb[i] + iy) * a.Wx + ix) * (unsigned)a.Cin + (unsigned)(cbase + 4 * q)) * 4u;
+          dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? (int)base : (int)OOB, 0, 0));
+        }
+        return;
+      }
+      const int c0 = c * 32;
+      const bool cok = in_k && c0 + 4 * q < a.Cs;
+#pragma unroll
+      for (int i = 0; i < NITEM; ++i) {
+        const bool ok = cok && goff[i] >= 0;
+        dst[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? (int)((unsigned)(goff[i] + c0) * 4u) : (int)OOB, 0, 0));
+      }
+    };
+    auto store_items = [&](const f32x4 (&src)[NITEM], int buf, int i0, int i1) {
+#pragma unroll
+      for (int i = i0; i < i1; ++i) {
+        X4 p[NPL];
+        P::split4(src[i], p);
+        const int o = buf * NPL * IMG + ((tid >> 3) + 32 * i) * XLD + 4 * q;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Ah[o + pl * IMG]) = p[pl];
+      }
+    };
+    load_chunk(0, rq[0]);
+    load_chunk(1, rq[1]);
+    store_items(rq[0], 0, 0, NITEM);
+    load_chunk(2, rq[0]);
+    load_b(0, fb[0]); load_b(1, fb[1]);
+    __syncthreads();
+    // six chunks per trip: buffer, register set and B ring slot are compile-time constants (6 even, 12 steps % 3 == 0)
+    for (int c6 = 0; c6 < a.nchunk; c6 += 6) {
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) {
+        const int c = c6 + cc;
+        if (c < a.nchunk) {
+          const int bo = (cc & 1) * NPL * IMG;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) fa[0][mi][pl] = *reinterpret_cast<const X8*>(&Ah[bo + pl * IMG + rowbase[mi]]);
+#pragma unroll
+          for (int step = 0; step < 2; ++step) {
+            const int gl = cc * 2 + step;
+            if (step == 0) {
+#pragma unroll
+              for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) fa[1][mi][pl] = *reinterpret_cast<const X8*>(&Ah[bo + pl * IMG + rowbase[mi] + 16]);
+            }
+            load_b(c * 2 + step + 2, fb[(gl + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            const X8(&A)[2][NPL] = fa[step];
+            const X8(&Bf)[NW][NPL] = fb[gl % 3];
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+#pragma unroll
+              for (int t = 0; t < P::NTERM; ++t) {
+                acc[0][j] = P::mfma(A[0][P::ta(t)], Bf[j][P::tb(t)], acc[0][j]);
+                acc[1][j] = P::mfma(A[1][P::ta(t)], Bf[j][P::tb(t)], acc[1][j]);
+              }
+            if (c + 1 < a.nchunk) store_items(rq[(cc + 1) & 1], (cc + 1) & 1, 2 * step, 2 * step + 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          __syncthreads();
+          load_chunk(c + 3, rq[(cc + 1) & 1]);
+        }
+      }
+    }
+  } else {
   load_round(0);
   __syncthreads();                        // amax cells zeroed before the first atomic
   // rounds are processed three at a time so that the B ring slot (g % 3) is a compile-time constant: 3 rounds = 12 steps
@@ -253,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(PwArgs a) {
         }
       }
     }
+  }
   }
 
   // ---- epilogue ----
@@ -336,8 +421,23 @@ static int run_pointwise(PwArgs& a, const float* w, void* ws, const unsigned* w_
     FS_LAUNCH_CHECK();
   }
   if (fs_ws_mode_tls == FS_WS_PACK_ONLY) return FS_OK;
-  if (nw == 2) hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 2>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 1>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+#ifdef FS_EXPERIMENTS
+  // the double-buffered chunk loop (bf16x3), measured and rejected (profiles/r04/pw_db_ab.txt: 960 -> 512 3x3 s4 forward 1 273 -> 1 360 us,
+  // configs[3] -1.2 %, configs[4] -4 %: the split + store lands behind each step's 24 MFMAs instead of between them, and the loop has
+  // one barrier per 48 MFMAs where the two-barrier loop has two per 96): only the A/B build carries it (FS_PW_DB=1 from three chunks up, 2 always)
+  static const int db_pol = FS_ENV_INT("FS_PW_DB", 0);
+  const bool db = !P::SCALED && (db_pol == 2 || (db_pol == 1 && a.nchunk >= 3));
+  if constexpr (!P::SCALED) {
+    if (db) {
+      if (nw == 2) hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 2, true>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 1, true>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+      FS_LAUNCH_CHECK();
+      return FS_OK;
+    }
+  }
+#endif
+  if (nw == 2) hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 2, false>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 1, false>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
