@@ -268,7 +268,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(PwArgs a) {
                 acc[0][j] = P::mfma(A[0][P::ta(t)], Bf[j][P::tb(t)], acc[0][j]);
                 acc[1][j] = P::mfma(A[1][P::ta(t)], Bf[j][P::tb(t)], acc[1][j]);
               }
-            if (c + 1 < a.nchunk) store_items(rq[(cc + 1) & 1], (cc + 1) & 1, 2 * step, 2 * step + 2);
+            store_items(rq[(cc + 1) & 1], (cc + 1) & 1, 2 * step, 2 * step + 2);      // (past the last chunk: zeros into a dead image)
+            // ask for the split between the MFMAs, not behind them: 2 MFMAs, 6 vector instructions, and an LDS store every other pair
+#pragma unroll
+            for (int i = 0; i < 6 * NW; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+              if (i & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
           __syncthreads();
@@ -423,8 +430,9 @@ static int run_pointwise(PwArgs& a, const float* w, void* ws, const unsigned* w_
   if (fs_ws_mode_tls == FS_WS_PACK_ONLY) return FS_OK;
 #ifdef FS_EXPERIMENTS
   // the double-buffered chunk loop (bf16x3), measured and rejected (profiles/r04/pw_db_ab.txt: 960 -> 512 3x3 s4 forward 1 273 -> 1 360 us,
-  // configs[3] -1.2 %, configs[4] -4 %: the split + store lands behind each step's 24 MFMAs instead of between them, and the loop has
-  // one barrier per 48 MFMAs where the two-barrier loop has two per 96): only the A/B build carries it (FS_PW_DB=1 from three chunks up, 2 always)
+  // configs[3] -1.2 %, configs[4] -4 % with the split + store behind each step's 24 MFMAs; 1 225 -> 1 284 us, -2 %, -3 % with it interleaved
+  // between the MFMAs by sched_group_barrier, the form kept here): two workgroups per CU alternating whole phases beat one wave
+  // interleaving its own.  Only the A/B build carries it (FS_PW_DB=1 from three chunks up, 2 always)
   static const int db_pol = FS_ENV_INT("FS_PW_DB", 0);
   const bool db = !P::SCALED && (db_pol == 2 || (db_pol == 1 && a.nchunk >= 3));
   if constexpr (!P::SCALED) {
