@@ -54,6 +54,7 @@ struct WinoArgs {
   // the epilogue, so the separate normalise / activate pass over the conv output disappears (ep_scale NULL = off)
   const float* ep_scale; const float* ep_shift; const float* ep_res; int ep_act;
   float drop_scale; uint32_t drop_thresh, drop_key;
+  int prio;                        // 1: issue priority rises through a chunk's MFMA steps (4-wave kernel; see its main loop)
   WINO_DIAG_FIELDS                 // empty in the shipped build (conv_wino_diag.h: diagnostic builds -DFS_WINO_TRACE / -DFS_WINO_CLOCK)
 };
 
@@ -342,6 +343,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       read_a(0, fa[0]);
 #pragma unroll
       for (int step = 0; step < 12; ++step) {
+        // a.prio: the SIMD arbitrates its two resident waves by priority, then age -- at equal priority the workgroup placed first takes the
+        // matrix pipe whenever it wants it (conv_wgrad.hip, FS_WGRAD_TRACE); a priority that grows through the chunk lets the wave that
+        // entered its MFMA steps first finish them, and the two workgroups of the CU alternate
+        if (a.prio && (step & 3) == 0) {
+          if (step == 0) __builtin_amdgcn_s_setprio(1);
+          else if (step == 4) __builtin_amdgcn_s_setprio(2);
+          else __builtin_amdgcn_s_setprio(3);
+        }
         if (step + 1 < 12) read_a(step + 1, fa[(step + 1) & 1]);
         if (step == 0 && chunk + 1 < a.nchunk) load_halo(chunk + 1);     // (at step 10, behind the chunk's last own fragment: +-0 on the step)
         {
@@ -362,6 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         ++g;
       }
+      if (a.prio) __builtin_amdgcn_s_setprio(0);
       if (chunk < 4) WINO_STAMP(6 + 5 * chunk);
     }
 
@@ -1047,6 +1057,10 @@ int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bia
   a.dst_bytes = (unsigned)((size_t)B * H * W * Cd * 4);
   a.ws_bytes = (unsigned)pack_bytes;
   a.drop_scale = drop_scale; a.drop_thresh = drop_thresh; a.drop_key = drop_key;
+  {
+    static const int prio = FS_ENV_INT("FS_WINO_PRIO", 0);      // kernel A/B builds only
+    a.prio = prio;
+  }
   return mode == 2 ? run_wino<PrecF16>(a, w, ws, w_amax, Cin, Cout, transposed, stream)
                    : run_wino<PrecX3>(a, w, ws, w_amax, Cin, Cout, transposed, stream);
 }
