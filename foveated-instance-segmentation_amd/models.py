@@ -207,15 +207,16 @@ class DeformSegmentationModule(nn.Module):
 
         xs, _ = self.saliency(x, focus)
         self._note_nan(xs)
-        grid = self.create_grid(xs)
+        xs = ops.grad_probe(xs, "dxs_sum")                              # (ops.GRAD_TRACE: no-ops unless a test switched the recorder on)
+        grid = ops.grad_probe(self.create_grid(ops.grad_probe(xs, "dxs_grid", alias=True)), "dgrid")
 
         joint = cfg.TRAIN.deform_joint_loss
         if joint:
             target = ops.area_pool(y, hs, ws)
-            edge_loss = ops.EdgeLoss.apply(xs, target, 0.05 * float(cfg.TRAIN.edge_loss_scale))
+            edge_loss = ops.EdgeLoss.apply(ops.grad_probe(xs, "dxs_edge", alias=True), target, 0.05 * float(cfg.TRAIN.edge_loss_scale))
 
         label = ops.grid_sample_label(y, grid.detach())
-        x_sampled = ops.GridSample.apply(x, grid)                      # (B,hs,ws,3) NHWC
+        x_sampled = ops.grad_probe(ops.GridSample.apply(x, grid), "dx_sampled")      # (B,hs,ws,3) NHWC
         feat = self.encoder.forward_nhwc(x_sampled)
         pred = self.decoder.forward_nhwc(feat)                         # (B,K,hs,ws)
         feed_dict["seg_label"] = label                                  # models/models.py:951

@@ -106,6 +106,28 @@ TIMER = None      # set to a KernelTimer by bench.py around the timed region
 # Parity-test instrument: when a list, every activation site appends (BatchNorm module | (HighResolutionModule, i), act kind,
 # activated output), so a test can replay the branch each activation took in the CPU oracle (oracle ACT_REPLAY).
 ACT_TRACE = None
+# Flight recorder of the front-end backward (tests / probes): when a dict, DeformSegmentationModule.forward hooks the cotangents that
+# reach x_sampled, the sampling grid and xs -- the grid path's and the edge loss's contributions to xs separately, and their sum -- and
+# every hook leaves {name: (fp64 norm, int64 sum of the bit patterns)} there as DEVICE scalars (no host read inside backward).  Every
+# kernel on that chain is order-fixed, so two passes over the same inputs must agree bit for bit, whichever way the weight gradients
+# travel (arena-direct + side stream, or AccumulateGrad under torch DDP): a mismatch names the stage (tests/test_ddp_gloo.py).
+GRAD_TRACE = None
+
+
+def grad_probe(t, name, alias=False):
+    """Record the gradient arriving at `t` under `name` in GRAD_TRACE; alias=True returns a view of t so that ONE consumer's
+    contribution is seen on its own."""
+    if GRAD_TRACE is None or not t.requires_grad:
+        return t
+    trace = GRAD_TRACE
+    if alias:
+        t = t.view_as(t)
+
+    def hook(g):
+        gd = g.detach()
+        trace[name] = (gd.double().norm(), gd.contiguous().view(torch.int32).to(torch.int64).sum())
+    t.register_hook(hook)
+    return t
 
 
 def _launch(kind, flops, name, *args):
@@ -232,13 +254,22 @@ def _pack_for(w, device, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, tra
             g = e.group
             if g is not None:
                 if cur not in g.waited:
-                    torch.cuda.current_stream().wait_event(g.event)
+                    # the wait goes on `cur`, the stream the launch uses (which is STREAM_OVERRIDE when that is set), not on torch's
+                    # current stream
+                    (torch.cuda.current_stream() if cur == hip._stream() else torch.cuda.ExternalStream(cur)).wait_event(g.event)
                     g.waited.add(cur)
             elif e.stream is not None and e.stream != cur:
                 hip.stream_wait(cur, e.stream)
             e.ready.add(cur)
         return e.ws, n, True
-    # stale (or new): this call packs on its own stream, later calls of the same epoch run on the result
+    # stale (or new): this call packs on its own stream, later calls of the same epoch run on the result.  The scratch is rewritten IN
+    # PLACE: consumers of the previous pack on other streams (HRNet branch streams, the autograd streams of the bwd-data packs) must
+    # have finished reading it first
+    for s_prev in e.ready:
+        if s_prev != cur:
+            hip.stream_wait(cur, s_prev)
+    if e.stream is not None and e.stream != cur and e.stream not in e.ready:
+        hip.stream_wait(cur, e.stream)
     e.cell, e.epoch, e.version, e.group, e.stream, e.ready = cell, cell[0], w._version, None, cur, {cur}
     return e.ws, n, False
 
@@ -530,8 +561,12 @@ FANOUT = os.environ.get("FS_FANOUT", "1") != "0"
 WGRAD_SIDE_FLOPS = float(os.environ.get("FS_WGRAD_SIDE_GFLOP", "4")) * 1e9
 _WGRAD_SIDE = {}            # device index -> (torch Stream, raw handle)
 _WGRAD_SIDE_BUSY = {}       # raw handle of a side stream with launches since the last join -> tensors those launches read or write
-                            # (kept alive until the join: they were allocated on the main stream's pool, so freeing them earlier would let
-                            # the allocator hand them out again while the side stream still uses them; cheaper than three record_stream calls)
+                            # (kept alive while the side stream may still use them: they were allocated on the launching stream's pool,
+                            # so freeing them earlier would let the allocator hand them out again; cheaper than three record_stream calls)
+_WGRAD_RETIRED = []         # (event recorded on the side stream, tensors): kept lists that were joined or rotated out; dropped once the
+                            # event has COMPLETED -- a join only enqueues a wait, the side stream may still be reading the tensors
+_WGRAD_ROTATE = 64          # side launches per kept list before it is rotated out (bounds what a long backward holds on to)
+_WGRAD_JOIN_QUEUED = [False]
 
 
 def _wgrad_side_stream(device):
@@ -543,13 +578,58 @@ def _wgrad_side_stream(device):
     return s[1]
 
 
+def _wgrad_stream_obj(raw):
+    for st, h in _WGRAD_SIDE.values():
+        if h == raw:
+            return st
+    return None
+
+
+def _wgrad_retire(raw, keep):
+    """The kept tensors of side stream `raw` may be dropped once everything enqueued there so far has run: remember them under an event."""
+    st = _wgrad_stream_obj(raw)
+    if st is None or not keep:
+        return
+    ev = torch.cuda.Event()
+    ev.record(st)
+    _WGRAD_RETIRED.append((ev, keep))
+
+
+def _wgrad_reap():
+    if _WGRAD_RETIRED:
+        _WGRAD_RETIRED[:] = [(ev, keep) for ev, keep in _WGRAD_RETIRED if not ev.query()]
+
+
 def join_wgrad_streams():
-    """The current stream waits for every weight-gradient launch that went to a side stream since the last join."""
+    """The current stream waits for every weight-gradient launch that went to a side stream since the last join.  Since round 5 this runs
+    as a final callback of the autograd engine at the end of every backward that used the side stream (_queue_wgrad_join), i.e. with the
+    CALLER's current stream -- the stream backward() returns on -- so any reader of .grad / the gradient arena after backward() is ordered
+    behind the side stream like behind every other gradient.  FlatAdam.step / zero_grad and train.allreduce_gradients still call it as a
+    backstop (no-ops then)."""
     if _WGRAD_SIDE_BUSY:
         cur = hip._stream()
-        for h in _WGRAD_SIDE_BUSY:
+        for h, keep in _WGRAD_SIDE_BUSY.items():
             hip.stream_wait(cur, h)
+            _wgrad_retire(h, keep)
         _WGRAD_SIDE_BUSY.clear()
+    _wgrad_reap()
+
+
+def _wgrad_join_callback():
+    _WGRAD_JOIN_QUEUED[0] = False
+    join_wgrad_streams()
+
+
+def _queue_wgrad_join():
+    """First side launch of a backward pass: have the engine run the join when the pass ends (torch runs final callbacks after it has
+    ordered the caller's stream behind the leaf streams, with the caller's current streams set)."""
+    if _WGRAD_JOIN_QUEUED[0]:
+        return
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_wgrad_join_callback)
+        _WGRAD_JOIN_QUEUED[0] = True
+    except RuntimeError:          # not inside an engine run (a Function.backward called by hand): the explicit joins remain
+        pass
 
 
 # BatchNorm-backward column sums that the PRODUCER of a gradient tensor already formed (FanOut.backward below):
@@ -622,6 +702,7 @@ def reset_step_state():
     BN_SLABS.clear()
     FAN_GEOM.clear()
     FAN_DONE.clear()
+    _WGRAD_JOIN_QUEUED[0] = False      # (a backward that raised never ran its final callbacks)
 
 
 def fan_out(x, n):
@@ -807,8 +888,13 @@ class ConvBnAct(Function):
             dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax, src_bn=src_bn, addend=pend) if ctx.needs_input_grad[0] else None
         if tgt is not None and 2.0 * M * C * w.shape[1] * w.shape[2] * w.shape[3] < WGRAD_SIDE_FLOPS and TIMER is None:
             side = _wgrad_side_stream(dy.device)
+            _queue_wgrad_join()                       # backward() returns with its stream ordered behind the side stream
             hip.stream_wait(side, hip._stream())      # dy (and x) were produced on the current stream
             keep = _WGRAD_SIDE_BUSY.setdefault(side, [])
+            if len(keep) >= _WGRAD_ROTATE:            # a long backward (configs[4]: every layer is small) does not hold on to all of its
+                _wgrad_retire(side, keep)             # activations and gradients: lists retire under an event and go when it has completed
+                keep = _WGRAD_SIDE_BUSY[side] = []
+                _wgrad_reap()
             keep.append((x, dy))
             hip.STREAM_OVERRIDE = side
             try:

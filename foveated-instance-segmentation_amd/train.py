@@ -228,11 +228,11 @@ def broadcast_parameters(optimizers, module=None, src=0):
         opt.flat.refresh_amax()          # the arena was rewritten behind the parameters' version counters
     if module is not None:
         broadcast_buffers(module, src=src)
-    if optimizers and optimizers[0].flat.data.is_cuda:
-        # once, at construction: every rank holds rank 0's parameters before anything reads them on any stream (a device-tensor
-        # broadcast on the gloo backend lands through the backend's own copy stream; one red run of the 2-rank wrapper test in eight
-        # had the two small arenas that are broadcast last differ between a forward right after this call and a later one)
-        torch.cuda.synchronize()
+    # (No device-wide synchronise here.  Round 4 added one on the guess that a gloo broadcast of the last two arenas "had not landed" in one
+    # red run of the 2-rank wrapper test; the record of that run refutes it -- the encoder / decoder arenas agreed to 2e-7, so both passes
+    # ran the same parameters and the same forward -- and a synchronous collective already orders the CURRENT stream behind the backend's
+    # copy-back (gloo: events on its copy streams; RCCL: its own stream), which is the stream refresh_amax and the next forward run on,
+    # and every side stream of this package forks from that stream by an event.  DESIGN.md 6 has the launch-by-launch ordering table.)
 
 
 class FlatBuffers:
