@@ -1304,7 +1304,8 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
 // precision mode and `ws_bytes` of scratch (host-side predicate, no launch; the dispatch below uses the same functions).
 // 0 = generic 64-bit-indexed kernel, 1 = plain aligned implicit GEMM, 2 = halo-tiled 3x3, 3 = tap-class kernel, 4 = 1x1 GEMM kernel,
 // 5 = halo-tiled 3x3 with F(2,3) minimal filtering along the row, 6 = stride-2 bwd-data with the four output parities in one launch,
-// 7 = stride-2 forward with the four input parity planes in one LDS refill.
+// 7 = stride-2 forward with the four input parity planes in one LDS refill, 8 = halo-tiled 3x3 with F(4,3) minimal filtering along the
+// row (conv_wino4.hip: bf16x3, widths that are multiples of 4).
 int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                             int transposed, long ws_bytes) {
   ConvArgs c{nullptr, nullptr, nullptr, nullptr, B, transposed ? Ho : H, transposed ? Wo : W, transposed ? Cout : Cin,
@@ -1315,7 +1316,7 @@ int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Co
   if (use_s2fwd(c)) return 7;
   if (!transposed && use_tapset(c) && !use_halo(c)) return 3;
   if (transposed && stride == 1 && use_tapset(c) && !use_halo(c)) return 3;
-  if (use_wino(c)) return 5;
+  if (use_wino(c)) return fs_wino_takes_f43(g_conv_precision, c.B, c.Hd, c.Wd, c.Cs, c.Cd) ? 8 : 5;
   if (use_halo(c)) return 2;
   if (use_pointwise(c) || use_pw_gather(c)) return 4;
   if (use_s2bwd(c)) return 6;
@@ -1328,7 +1329,7 @@ int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Co
 int fs_conv2d_pack_persistent(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                               int transposed, long ws_bytes) {
   const int k = fs_conv2d_kernel_choice(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, ws_bytes);
-  if (k == 2 || k == 4 || k == 5 || k == 6 || k == 7) return 1;
+  if (k == 2 || k == 4 || k == 5 || k == 6 || k == 7 || k == 8) return 1;
   return (k == 3 && !(transposed && stride > 1)) ? 1 : 0;
 }
 

@@ -42,6 +42,16 @@ int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bia
                     int B, int H, int W, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh,
                     uint32_t drop_key, const FsBnSums* bn, hipStream_t stream);
 
+// ---- conv_wino4.hip (round 5): the same problem class with F(4,3) along the row (18 MFMA steps per four output pixels instead of 24):
+// bf16x3 only, W a multiple of 4.  fs_wino_conv3x3 / fs_wino_pack_bytes / fs_wino_stats_slabs route to it where fs_wino4_selected holds.
+bool fs_wino_takes_f43(int mode, int B, int H, int W, int Cs, int Cd);      // conv_wino.hip: this problem goes to the F(4,3) kernel
+bool fs_wino4_eligible(int mode, int B, int H, int W, int Cs, int Cd);
+long fs_wino4_pack_bytes(int mode, int Cs, int Cd);
+int fs_wino4_stats_slabs(int B, int H, int W);
+int fs_wino4_conv3x3(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, int B, int H, int W, int Cs,
+                     int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key, const FsBnSums* bn,
+                     hipStream_t stream);
+
 // ---- conv_pointwise.hip: 1x1 / stride 1 / pad 0 as a GEMM with pre-split weights (forward and bwd-data).  mode: 1 = bf16x3, 2 = f16x2 ----
 bool fs_pointwise_eligible(int Cs, int Cd, int R, int S, int stride, int pad, int dil);
 long fs_pointwise_pack_bytes(int mode, int Cs, int Cd);
@@ -67,7 +77,13 @@ int fs_pointwise_conv(int mode, const float* src, const float* w, const float* b
 // slabs in index order.  base == nullptr selects the atomics.
 struct FsPart { float* base; long stride; };
 __device__ __forceinline__ void fs_wgrad_out(float* dw, const FsPart p, int slab, long idx, float v) {
+#ifdef FS_WGRAD_NT
+  // kernel A/B builds only (-DFS_WGRAD_NT): the partial tiles leave with non-temporal stores, so that 75 MB of slab lines per launch do
+  // not displace the layer's dY / X from L2 between its bwd-weight and its bwd-data (measured in profiles/r05/wgrad_nt_ab.txt)
+  if (p.base != nullptr) __builtin_nontemporal_store(v, p.base + (long)slab * p.stride + idx);
+#else
   if (p.base != nullptr) p.base[(long)slab * p.stride + idx] = v;
+#endif
   else atomicAdd(dw + idx, v);
 }
 bool fs_deterministic();

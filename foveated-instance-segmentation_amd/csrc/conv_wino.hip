@@ -1018,13 +1018,32 @@ bool fs_wino_eligible(int mode, int B, int H, int W, int Cs, int Cd) {
   return g_wino && (mode == 1 || mode == 2) && W % 2 == 0 && W >= 4 && (long)B * (H + 1) < 65536 && Cs % 4 == 0 && Cd % 4 == 0 && Cs >= 32;
 }
 
+// Which of the eligible layers take the F(4,3) kernel of conv_wino4.hip (policy from the same-box A/B of round 5, profiles/r05/wino4_ab.txt;
+// FS_WINO4 in kernel A/B builds: 0 none, 1 the measured policy, 2 every eligible layer)
+static bool wino4_selected(int mode, int B, int H, int W, int Cs, int Cd) {
+  static const int pol = FS_ENV_INT("FS_WINO4", 1);
+  if (pol == 0 || !fs_wino4_eligible(mode, B, H, W, Cs, Cd)) return false;
+  // B = 64, us per call F(2,3) -> F(4,3): 64 -> 64 @ 80x80 167 -> 141 (fwd) / 165 -> 141 (bwd-data), 128 -> 128 @ 40x40 150 -> 132 / 151 -> 134,
+  // 192 -> 192 @ 80x80 1 090 -> 962, 960 -> 240 @ 80x80 5 810 -> 5 430 / 6 980 -> 6 530; against the eight-wave kernel on 256 -> 256 @ 20x20
+  // 142 -> 142 / 149 -> 145: a tie, which stays with the kernel of the lower error
+  if (pol == 1 && wino_use8(mode, Cs, Cd) && W <= 20) return false;
+  return true;
+}
+
+bool fs_wino_takes_f43(int mode, int B, int H, int W, int Cs, int Cd) {
+  return fs_wino_eligible(mode, B, H, W, Cs, Cd) && wino4_selected(mode, B, H, W, Cs, Cd);
+}
+
 long fs_wino_pack_bytes(int mode, int Cs, int Cd) {
   const int npl = mode == 2 ? 2 : 3;
   const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 127) / 128) * 128;       // room for either column tiling
-  return HDR + nchunk * 24 * npl * Npad * 16 * 2;
+  const long f23 = HDR + nchunk * 24 * npl * Npad * 16 * 2;
+  const long f43 = mode == 1 ? fs_wino4_pack_bytes(mode, Cs, Cd) : 0;         // (shape-independent bound: either kernel fits)
+  return f23 > f43 ? f23 : f43;
 }
 
 int fs_wino_stats_slabs(int mode, int B, int H, int W, int Cs, int Cd) {
+  if (wino4_selected(mode, B, H, W, Cs, Cd)) return fs_wino4_stats_slabs(B, H, W);
   int Ph, PP, tx, nx;
   wino_plan(B, H, W, Ph, PP, tx, nx);
   return wino_use8(mode, Cs, Cd) ? 2 * nx : nx;        // the eight-wave kernel writes one row per (pixel tile, pixel parity)
@@ -1033,6 +1052,8 @@ int fs_wino_stats_slabs(int mode, int B, int H, int W, int Cs, int Cd) {
 int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
                     int B, int H, int W, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh,
                     uint32_t drop_key, const FsBnSums* bn, hipStream_t stream) {
+  if (wino4_selected(mode, B, H, W, Cs, Cd))
+    return fs_wino4_conv3x3(mode, src, w, bias, dst, stats, ws, B, H, W, Cs, Cd, Cin, Cout, transposed, drop_scale, drop_thresh, drop_key, bn, stream);
   WinoArgs a;
   a.bn_y = bn ? bn->y : nullptr; a.bn_mask = bn ? bn->mask : nullptr; a.bn_mean = bn ? bn->mean : nullptr; a.bn_invstd = bn ? bn->invstd : nullptr;
   a.add_src = bn ? bn->add_src : nullptr; a.add_mask = bn ? bn->add_mask : nullptr;
@@ -1049,7 +1070,7 @@ int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bia
   a.magic_pp = div_magic(a.PP);
   a.magic_ny = div_magic1(a.ny);
   a.magic_tx = div_magic1(a.tiles_x);
-  const long pack_bytes = fs_wino_pack_bytes(mode, Cs, Cd);
+  const long pack_bytes = HDR + (long)a.nchunk * 24 * (mode == 2 ? 2 : 3) * (((Cd + 127) / 128) * 128) * 16 * 2;
   if (!fs_wino_eligible(mode, B, H, W, Cs, Cd) || pack_bytes >= 2147483647L || (size_t)B * H * W * Cs * 4 >= 4294967000UL ||
       (size_t)B * H * W * Cd * 4 >= 4294967000UL || (long)a.nx * a.ny >= 65536)
     return FS_ERR_ARG;

@@ -79,53 +79,55 @@ __global__ __launch_bounds__(1024) void compress_softmax_fwd_kernel(const float*
 }
 
 // dlogit = xs * (g - sum(g*xs)); ds[p][c] = dlogit*w[c]*(s>0); dw[c] += sum dlogit*relu(s); db += sum dlogit
-__global__ __launch_bounds__(1024) void compress_softmax_bwd_kernel(const float* __restrict__ g, const float* __restrict__ xs,
-                                                                    const float* __restrict__ s, const float* __restrict__ w,
-                                                                    float* __restrict__ ds, float* __restrict__ part /* [B][C], then [B] */,
-                                                                    int HW, int C) {
+// Round 5: CS_SLICES workgroups per image (round 4: one -- 64 workgroups on a 256-CU chip walked 78 MB at 0.36 TB/s).  Every workgroup of
+// an image forms the image's softmax dot product itself (6 400 products: cheaper than a launch), then owns a contiguous slice of the pixels;
+// the slice is walked as float4 channel quads (768 threads = a multiple of the C/4 quads of a pixel, so a thread keeps its channel quad
+// and four dw accumulators).  Each workgroup leaves one record of C + 1 partial sums; fs_slab_reduce adds the records in index order.
+constexpr int CS_SLICES = 8;
+constexpr int CS_THREADS = 768;
+__global__ __launch_bounds__(CS_THREADS) void compress_softmax_bwd_kernel(const float* __restrict__ g, const float* __restrict__ xs,
+                                                                          const float* __restrict__ s, const float* __restrict__ w,
+                                                                          float* __restrict__ ds, float* __restrict__ part /* [B*S][C], then [B*S] */,
+                                                                          int HW, int C) {
   __shared__ float red[16];
-  __shared__ float dwacc[16 * 32];
-  const int b = blockIdx.x;
+  __shared__ f32x4 dwq[CS_THREADS];
+  const int b = blockIdx.x / CS_SLICES, sl = blockIdx.x - b * CS_SLICES;
   const float* gb = g + (long)b * HW;
   const float* xb = xs + (long)b * HW;
-  const float* sb = s + (long)b * HW * C;
-  float* dsb = ds + (long)b * HW * C;
   float dot = 0.f;
   for (int p = threadIdx.x; p < HW; p += blockDim.x) dot += gb[p] * xb[p];
   dot = block_sum<float>(dot, red);
+  const int Q = C >> 2;                                    // channel quads per pixel (blockDim.x % Q == 0: checked by the launcher)
+  const int per = (HW + CS_SLICES - 1) / CS_SLICES;
+  const int p0 = sl * per, p1 = p0 + per < HW ? p0 + per : HW;
+  const int cq = threadIdx.x % Q;
+  const f32x4 wq = *reinterpret_cast<const f32x4*>(w + 4 * cq);
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(s + (long)b * HW * C);
+  f32x4* ds4 = reinterpret_cast<f32x4*>(ds + (long)b * HW * C);
+  f32x4 dwl = {0.f, 0.f, 0.f, 0.f};
   float dbl = 0.f;
-  float dwl[32];
-#pragma unroll
-  for (int c = 0; c < 32; ++c) dwl[c] = 0.f;
-  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+  for (long e = (long)p0 * Q + threadIdx.x; e < (long)p1 * Q; e += blockDim.x) {
+    const int p = (int)(e / Q);
     const float dl = xb[p] * (gb[p] - dot);
-    dbl += dl;
+    const f32x4 v = s4[e];
+    f32x4 o;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      if (c < C) {
-        const float v = sb[(long)p * C + c];
-        dsb[(long)p * C + c] = v > 0.f ? dl * w[c] : 0.f;
-        dwl[c] += dl * (v < 0.f ? 0.f : v);
-      }
+    for (int j = 0; j < 4; ++j) {
+      o[j] = v[j] > 0.f ? dl * wq[j] : 0.f;
+      dwl[j] += dl * (v[j] < 0.f ? 0.f : v[j]);
     }
+    ds4[e] = o;
+    if (cq == 0) dbl += dl;
   }
-  // per-wave sums into their own LDS row, rows added in wave order; the image's record goes to part[b], summed in image order by
-  // fs_slab_reduce (no atomics anywhere: the result does not depend on which wave or workgroup finishes first)
-#pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    if (c < C) {
-      const float v = wave_sum(dwl[c]);
-      if ((threadIdx.x & 63) == 0) dwacc[(threadIdx.x >> 6) * 32 + c] = v;
-    }
-  }
-  dbl = block_sum<float>(dbl, red);
-  __syncthreads();
+  dwq[threadIdx.x] = dwl;
+  dbl = block_sum<float>(dbl, red);                        // (its barriers also publish dwq)
   if (threadIdx.x < C) {
+    const int q = threadIdx.x >> 2, j = threadIdx.x & 3;
     float a = 0.f;
-    for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) a += dwacc[wv * 32 + threadIdx.x];
-    part[(long)b * C + threadIdx.x] = a;
+    for (int t = q; t < (int)blockDim.x; t += Q) a += dwq[t][j];      // threads with this channel quad, in thread order
+    part[(long)blockIdx.x * C + threadIdx.x] = a;
   }
-  if (threadIdx.x == 0) part[(long)gridDim.x * C + b] = dbl;
+  if (threadIdx.x == 0) part[(long)gridDim.x * C + blockIdx.x] = dbl;
 }
 
 // CompressNet.forward on its own (models/models.py:360-372): logit[p] = w . relu(s[p]) + bias, one thread per pixel (C <= 32: the
@@ -230,40 +232,86 @@ __global__ __launch_bounds__(256) void area_pool_kernel(const float* __restrict_
 }
 
 // edge loss = coef * mean(((xs-min)/(max-min) - (t-tmin)/(tmax-tmin))^2), whole-batch min/max.
-// stats out: [xs_min, xs_max, t_min, t_max, n_argmin, n_argmax]; single workgroup (n ~ 4e5).
-__global__ __launch_bounds__(1024) void edge_loss_fwd_kernel(const float* __restrict__ xs, const float* __restrict__ t, long n,
-                                                             float coef, float* __restrict__ loss, float* __restrict__ stats) {
-  __shared__ float red[4][16];
-  __shared__ double dred[16];
+// stats out: [xs_min, xs_max, t_min, t_max, n_argmin, n_argmax] (+ scratch behind them, fs_edge_loss_stats_floats).
+// Round 5: every pass over the batch is spread over EL_WGS(n) workgroups (round 4: ONE workgroup walked the 3.3 MB twice, 150 us forward
+// and 259 us backward on a 256-CU chip).  A whole-batch statistic is two launches -- per-workgroup partials, then every workgroup of the
+// next pass adds ALL partials itself in index order (<= 256 records: cheaper than a launch, and no result depends on workgroup timing):
+//   forward : [min/max partials] -> [min/max, squared-error + arg-count partials] -> [sum, loss + stats]        (3 launches)
+//   backward: [sum g (u - 1), sum g u partials] -> [sums, dxs]                                                   (2 launches)
+// scratch layout (floats, behind the 6 stats + 2 pad): mm[G][4] | sums[G][4] doubles (acc, cmin, cmax, -) | bsum[G][2] doubles
+constexpr int EL_THREADS = 256;
+static int el_wgs(long n) {
+  const long w = (n / 4 + EL_THREADS * 4 - 1) / (EL_THREADS * 4);          // >= 4 float4 per thread
+  return (int)(w < 1 ? 1 : (w > 256 ? 256 : w));
+}
+struct ElPtrs { float* mm; double* sums; double* bsum; };
+__host__ __device__ __forceinline__ ElPtrs el_ptrs(float* stats, int G) {
+  ElPtrs p;
+  p.mm = stats + 8;
+  p.sums = reinterpret_cast<double*>(stats + 8 + 4 * G);
+  p.bsum = p.sums + 4 * G;
+  return p;
+}
+
+__global__ __launch_bounds__(EL_THREADS) void edge_minmax_kernel(const float* __restrict__ xs, const float* __restrict__ t, long n, float* __restrict__ stats) {
+  __shared__ float red[4][4];
+  const int G = gridDim.x;
   float mn = INFINITY, mx = -INFINITY, tmn = INFINITY, tmx = -INFINITY;
-  // one workgroup walks the whole batch twice: 16-byte loads, two of each operand in flight per trip
   const long n4 = ((((size_t)xs | (size_t)t) & 15) == 0) ? n / 4 : 0;
   const f32x4* xs4 = reinterpret_cast<const f32x4*>(xs);
   const f32x4* t4 = reinterpret_cast<const f32x4*>(t);
-  for (long i = threadIdx.x; i < n4; i += 2 * blockDim.x) {
-    const long i2 = i + blockDim.x < n4 ? i + blockDim.x : i;
-    const f32x4 a0 = xs4[i], b0 = t4[i], a1 = xs4[i2], b1 = t4[i2];
+  for (long i = (long)blockIdx.x * EL_THREADS + threadIdx.x; i < n4; i += (long)G * EL_THREADS) {
+    const f32x4 a = xs4[i], b = t4[i];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      mn = fminf(mn, fminf(a0[e], a1[e])); mx = fmaxf(mx, fmaxf(a0[e], a1[e]));
-      tmn = fminf(tmn, fminf(b0[e], b1[e])); tmx = fmaxf(tmx, fmaxf(b0[e], b1[e]));
-    }
+    for (int e = 0; e < 4; ++e) { mn = fminf(mn, a[e]); mx = fmaxf(mx, a[e]); tmn = fminf(tmn, b[e]); tmx = fmaxf(tmx, b[e]); }
   }
-  for (long i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
+  for (long i = 4 * n4 + (long)blockIdx.x * EL_THREADS + threadIdx.x; i < n; i += (long)G * EL_THREADS) {
     const float a = xs[i], b = t[i];
     mn = fminf(mn, a); mx = fmaxf(mx, a); tmn = fminf(tmn, b); tmx = fmaxf(tmx, b);
   }
   mn = wave_min(mn); mx = wave_max(mx); tmn = wave_min(tmn); tmx = wave_max(tmx);
-  const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { red[0][wv] = mn; red[1][wv] = mx; red[2][wv] = tmn; red[3][wv] = tmx; }
   __syncthreads();
-  mn = red[0][0]; mx = red[1][0]; tmn = red[2][0]; tmx = red[3][0];
-  for (int i = 1; i < nw; ++i) {
-    mn = fminf(mn, red[0][i]); mx = fmaxf(mx, red[1][i]); tmn = fminf(tmn, red[2][i]); tmx = fmaxf(tmx, red[3][i]);
+  if (threadIdx.x == 0) {
+    float* mm = el_ptrs(stats, G).mm + 4 * blockIdx.x;
+    mm[0] = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+    mm[1] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    mm[2] = fminf(fminf(red[2][0], red[2][1]), fminf(red[2][2], red[2][3]));
+    mm[3] = fmaxf(fmaxf(red[3][0], red[3][1]), fmaxf(red[3][2], red[3][3]));
   }
+}
+
+// whole-batch min / max from the G partial records (min / max are order-independent); every thread ends up with all four
+__device__ __forceinline__ void edge_global_minmax(const float* __restrict__ mm, int G, float (*red)[4], float& mn, float& mx, float& tmn, float& tmx) {
+  mn = INFINITY; mx = -INFINITY; tmn = INFINITY; tmx = -INFINITY;
+  for (int i = threadIdx.x; i < G; i += EL_THREADS) {
+    mn = fminf(mn, mm[4 * i]); mx = fmaxf(mx, mm[4 * i + 1]); tmn = fminf(tmn, mm[4 * i + 2]); tmx = fmaxf(tmx, mm[4 * i + 3]);
+  }
+  mn = wave_min(mn); mx = wave_max(mx); tmn = wave_min(tmn); tmx = wave_max(tmx);
+  const int wv = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = mn; red[1][wv] = mx; red[2][wv] = tmn; red[3][wv] = tmx; }
+  __syncthreads();
+  mn = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+  mx = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  tmn = fminf(fminf(red[2][0], red[2][1]), fminf(red[2][2], red[2][3]));
+  tmx = fmaxf(fmaxf(red[3][0], red[3][1]), fmaxf(red[3][2], red[3][3]));
+}
+
+__global__ __launch_bounds__(EL_THREADS) void edge_sums_kernel(const float* __restrict__ xs, const float* __restrict__ t, long n, float* __restrict__ stats) {
+  __shared__ float red[4][4];
+  __shared__ double dred[16];
+  const int G = gridDim.x;
+  const ElPtrs P = el_ptrs(stats, G);
+  float mn, mx, tmn, tmx;
+  edge_global_minmax(P.mm, G, red, mn, mx, tmn, tmx);
   const float r = mx - mn, tr = tmx - tmn;
   double acc = 0.0, cmin = 0.0, cmax = 0.0;
-  for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+  const long n4 = ((((size_t)xs | (size_t)t) & 15) == 0) ? n / 4 : 0;
+  const f32x4* xs4 = reinterpret_cast<const f32x4*>(xs);
+  const f32x4* t4 = reinterpret_cast<const f32x4*>(t);
+  for (long i = (long)blockIdx.x * EL_THREADS + threadIdx.x; i < n4; i += (long)G * EL_THREADS) {
     const f32x4 a4 = xs4[i], b4 = t4[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -274,7 +322,7 @@ __global__ __launch_bounds__(1024) void edge_loss_fwd_kernel(const float* __rest
       cmax += (a4[e] == mx) ? 1.0 : 0.0;
     }
   }
-  for (long i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
+  for (long i = 4 * n4 + (long)blockIdx.x * EL_THREADS + threadIdx.x; i < n; i += (long)G * EL_THREADS) {
     const float a = xs[i];
     const float u = (a - mn) / r, v = (t[i] - tmn) / tr;
     const float d = u - v;
@@ -286,23 +334,33 @@ __global__ __launch_bounds__(1024) void edge_loss_fwd_kernel(const float* __rest
   cmin = block_sum<double>(cmin, dred);
   cmax = block_sum<double>(cmax, dred);
   if (threadIdx.x == 0) {
-    loss[0] = coef * (float)(acc / (double)n);
-    stats[0] = mn; stats[1] = mx; stats[2] = tmn; stats[3] = tmx; stats[4] = (float)cmin; stats[5] = (float)cmax;
+    double* o = P.sums + 4 * blockIdx.x;
+    o[0] = acc; o[1] = cmin; o[2] = cmax; o[3] = 0.0;
+    if (blockIdx.x == 0) { stats[0] = mn; stats[1] = mx; stats[2] = tmn; stats[3] = tmx; }
   }
 }
 
-__global__ __launch_bounds__(1024) void edge_loss_bwd_kernel(const float* __restrict__ xs, const float* __restrict__ t, long n,
-                                                             float coef, const float* __restrict__ gout,
-                                                             const float* __restrict__ stats, float* __restrict__ dxs) {
+__global__ __launch_bounds__(64) void edge_finish_kernel(long n, float coef, int G, float* __restrict__ loss, float* __restrict__ stats) {
+  if (threadIdx.x != 0) return;
+  const double* sums = el_ptrs(stats, G).sums;
+  double acc = 0.0, cmin = 0.0, cmax = 0.0;
+  for (int i = 0; i < G; ++i) { acc += sums[4 * i]; cmin += sums[4 * i + 1]; cmax += sums[4 * i + 2]; }      // index order
+  loss[0] = coef * (float)(acc / (double)n);
+  stats[4] = (float)cmin; stats[5] = (float)cmax;
+}
+
+__global__ __launch_bounds__(EL_THREADS) void edge_bwd_sums_kernel(const float* __restrict__ xs, const float* __restrict__ t, long n, float coef,
+                                                                  const float* __restrict__ gout, float* __restrict__ stats) {
   __shared__ double dred[16];
+  const int G = gridDim.x;
   const float mn = stats[0], mx = stats[1], tmn = stats[2], tmx = stats[3];
   const float r = mx - mn, tr = tmx - tmn;
   const float k = 2.f * coef * gout[0] / (float)n;
   double s_gu1 = 0.0, s_gu = 0.0;    // sum g*(u-1), sum g*u
-  const long n4 = ((((size_t)xs | (size_t)t | (size_t)dxs) & 15) == 0) ? n / 4 : 0;
+  const long n4 = ((((size_t)xs | (size_t)t) & 15) == 0) ? n / 4 : 0;
   const f32x4* xs4 = reinterpret_cast<const f32x4*>(xs);
   const f32x4* t4 = reinterpret_cast<const f32x4*>(t);
-  for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+  for (long i = (long)blockIdx.x * EL_THREADS + threadIdx.x; i < n4; i += (long)G * EL_THREADS) {
     const f32x4 a4 = xs4[i], b4 = t4[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -312,7 +370,7 @@ __global__ __launch_bounds__(1024) void edge_loss_bwd_kernel(const float* __rest
       s_gu += (double)(g * u);
     }
   }
-  for (long i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
+  for (long i = 4 * n4 + (long)blockIdx.x * EL_THREADS + threadIdx.x; i < n; i += (long)G * EL_THREADS) {
     const float u = (xs[i] - mn) / r, v = (t[i] - tmn) / tr;
     const float g = k * (u - v);
     s_gu1 += (double)(g * (u - 1.f));
@@ -320,9 +378,33 @@ __global__ __launch_bounds__(1024) void edge_loss_bwd_kernel(const float* __rest
   }
   s_gu1 = block_sum<double>(s_gu1, dred);
   s_gu = block_sum<double>(s_gu, dred);
-  const float dmn = (float)(s_gu1 / (double)r) / stats[4];
-  const float dmx = (float)(-s_gu / (double)r) / stats[5];
-  for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+  if (threadIdx.x == 0) {
+    double* o = el_ptrs(stats, G).bsum + 2 * blockIdx.x;
+    o[0] = s_gu1; o[1] = s_gu;
+  }
+}
+
+__global__ __launch_bounds__(EL_THREADS) void edge_bwd_apply_kernel(const float* __restrict__ xs, const float* __restrict__ t, long n, float coef,
+                                                                   const float* __restrict__ gout, const float* __restrict__ stats_c,
+                                                                   float* __restrict__ dxs) {
+  __shared__ double tot[2];
+  const int G = gridDim.x;
+  const float mn = stats_c[0], mx = stats_c[1], tmn = stats_c[2], tmx = stats_c[3];
+  const float r = mx - mn, tr = tmx - tmn;
+  const float k = 2.f * coef * gout[0] / (float)n;
+  if (threadIdx.x == 0) {
+    const double* bs = el_ptrs(const_cast<float*>(stats_c), G).bsum;
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < G; ++i) { a += bs[2 * i]; b += bs[2 * i + 1]; }      // index order
+    tot[0] = a; tot[1] = b;
+  }
+  __syncthreads();
+  const float dmn = (float)(tot[0] / (double)r) / stats_c[4];
+  const float dmx = (float)(-tot[1] / (double)r) / stats_c[5];
+  const long n4 = ((((size_t)xs | (size_t)t | (size_t)dxs) & 15) == 0) ? n / 4 : 0;
+  const f32x4* xs4 = reinterpret_cast<const f32x4*>(xs);
+  const f32x4* t4 = reinterpret_cast<const f32x4*>(t);
+  for (long i = (long)blockIdx.x * EL_THREADS + threadIdx.x; i < n4; i += (long)G * EL_THREADS) {
     const f32x4 a4 = xs4[i], b4 = t4[i];
     f32x4 d4;
 #pragma unroll
@@ -335,7 +417,7 @@ __global__ __launch_bounds__(1024) void edge_loss_bwd_kernel(const float* __rest
     }
     reinterpret_cast<f32x4*>(dxs)[i] = d4;
   }
-  for (long i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
+  for (long i = 4 * n4 + (long)blockIdx.x * EL_THREADS + threadIdx.x; i < n; i += (long)G * EL_THREADS) {
     const float a = xs[i];
     const float u = (a - mn) / r, v = (t[i] - tmn) / tr;
     float d = k * (u - v) / r;
@@ -354,15 +436,21 @@ __global__ __launch_bounds__(1024) void edge_loss_bwd_kernel(const float* __rest
 // and a column pass (91 taps) with double accumulators instead of an 8281-tap direct conv.
 // ------------------------------------------------------------------------------------------
 constexpr int GMAX = 6400;   // hs*ws upper bound of the LDS layout (80x80)
+// Round 5: GG_BANDS workgroups per image, each owning a band of grid COLUMNS (round 4: one workgroup per image -- 64 workgroups on a
+// 256-CU chip, 258 us for the backward, bound by the LDS reads of its 91-tap passes).  A row pass needs every column of its source row
+// but produces only the band's columns; a column pass needs every row of the band's columns only -- so forward (row pass, column pass)
+// is one launch of B x GG_BANDS workgroups with nothing exchanged, and backward (row, column, transposed row, transposed column) is two:
+// the transposed row pass reads the (dp, dax, day) of ALL columns, which the first launch leaves in a scratch of 3 floats per grid point.
+constexpr int GG_BANDS = 4;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// row pass: R0[y][ox] = sum_s g[s] xs[y][clamp(ox+s-pad)],  R1 = same * cx(ox+s)
-__device__ void gauss_rows(const float* xs, const double* g, int hs, int ws, int pad, float* R0, float* R1) {
+// row pass on the band [x0, x0 + bw): R0[y][ox - x0] = sum_s g[s] xs[y][clamp(ox+s-pad)],  R1 = same * cx(ox+s)
+__device__ void gauss_rows(const float* xs, const double* g, int hs, int ws, int pad, int x0, int bw, float* R0, float* R1) {
   const int K = 2 * pad + 1;
   const double inv = 1.0 / (double)(ws - 1);
-  for (int i = threadIdx.x; i < hs * ws; i += blockDim.x) {
-    const int y = i / ws, ox = i - y * ws;
+  for (int i = threadIdx.x; i < hs * bw; i += blockDim.x) {
+    const int y = i / bw, ox = x0 + (i - y * bw);
     double a0 = 0.0, a1 = 0.0;
     for (int s = 0; s < K; ++s) {
       const int j = ox + s;
@@ -374,73 +462,106 @@ __device__ void gauss_rows(const float* xs, const double* g, int hs, int ws, int
   }
 }
 
-__device__ __forceinline__ void gauss_cols_at(const float* R0, const float* R1, const double* g, int hs, int ws, int pad,
-                                              int oy, int ox, double& p, double& ax, double& ay) {
+// column pass at (oy, band column xb): R0 / R1 are [hs][bw]
+__device__ __forceinline__ void gauss_cols_at(const float* R0, const float* R1, const double* g, int hs, int bw, int pad,
+                                              int oy, int xb, double& p, double& ax, double& ay) {
   const int K = 2 * pad + 1;
   const double inv = 1.0 / (double)(hs - 1);
   p = 0.0; ax = 0.0; ay = 0.0;
   for (int r = 0; r < K; ++r) {
     const int i = oy + r;
     const int y = clampi(i - pad, 0, hs - 1);
-    const double v0 = g[r] * (double)R0[y * ws + ox];
+    const double v0 = g[r] * (double)R0[y * bw + xb];
     p += v0;
-    ax += g[r] * (double)R1[y * ws + ox];
+    ax += g[r] * (double)R1[y * bw + xb];
     ay += v0 * ((double)(i - pad) * inv);
   }
+}
+
+__device__ __forceinline__ void gg_band(int ws, int& x0, int& bw, int& b) {
+  b = blockIdx.x / GG_BANDS;
+  const int band = blockIdx.x - b * GG_BANDS;
+  const int w = (ws + GG_BANDS - 1) / GG_BANDS;
+  x0 = band * w;
+  bw = x0 >= ws ? 0 : (x0 + w <= ws ? w : ws - x0);
 }
 
 __global__ __launch_bounds__(1024) void gauss_grid_fwd_kernel(const float* __restrict__ xs_g, const double* __restrict__ g1d,
                                                               float* __restrict__ grid, int hs, int ws, int pad) {
   extern __shared__ float sm[];
-  float* X = sm; float* R0 = sm + GMAX; float* R1 = sm + 2 * GMAX;
+  float* X = sm; float* R0 = sm + GMAX; float* R1 = sm + 2 * GMAX;       // (R0 / R1 hold the band only)
   __shared__ double g[256];
-  const int b = blockIdx.x, n = hs * ws;
+  int x0, bw, b;
+  gg_band(ws, x0, bw, b);
+  if (bw == 0) return;                                                   // workgroup-uniform
+  const int n = hs * ws;
   for (int i = threadIdx.x; i < 2 * pad + 1; i += blockDim.x) g[i] = g1d[i];
   for (int i = threadIdx.x; i < n; i += blockDim.x) X[i] = xs_g[(long)b * n + i];
   __syncthreads();
-  gauss_rows(X, g, hs, ws, pad, R0, R1);
+  gauss_rows(X, g, hs, ws, pad, x0, bw, R0, R1);
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int oy = i / ws, ox = i - oy * ws;
+  for (int i = threadIdx.x; i < hs * bw; i += blockDim.x) {
+    const int oy = i / bw, xb = i - oy * bw;
     double p, ax, ay;
-    gauss_cols_at(R0, R1, g, hs, ws, pad, oy, ox, p, ax, ay);
+    gauss_cols_at(R0, R1, g, hs, bw, pad, oy, xb, p, ax, ay);
     float gx = (float)(ax / p * 2.0 - 1.0), gy = (float)(ay / p * 2.0 - 1.0);
     gx = fminf(fmaxf(gx, -1.f), 1.f);
     gy = fminf(fmaxf(gy, -1.f), 1.f);
-    grid[((long)b * n + i) * 2 + 0] = gx;
-    grid[((long)b * n + i) * 2 + 1] = gy;
+    const long o = ((long)b * n + oy * ws + x0 + xb) * 2;
+    grid[o + 0] = gx;
+    grid[o + 1] = gy;
   }
 }
 
-// backward: dgrid (B,hs,ws,2) -> dxs (B,hs,ws).  Recomputes p/ax/ay, then runs the transposed
-// separable filter and folds the replication padding back onto the border pixels.
-__global__ __launch_bounds__(1024) void gauss_grid_bwd_kernel(const float* __restrict__ xs_g, const double* __restrict__ g1d,
-                                                              const float* __restrict__ dgrid, float* __restrict__ dxs,
-                                                              int hs, int ws, int pad) {
+// backward, launch 1 of 2: dgrid (B,hs,ws,2) -> (dp, dax, day) per grid point of the band -> scratch [B][3][n]
+__global__ __launch_bounds__(1024) void gauss_grid_bwd1_kernel(const float* __restrict__ xs_g, const double* __restrict__ g1d,
+                                                               const float* __restrict__ dgrid, float* __restrict__ scratch,
+                                                               int hs, int ws, int pad) {
   extern __shared__ float sm[];
-  float* A = sm; float* Bf = sm + GMAX; float* Cf = sm + 2 * GMAX; float* D = sm + 3 * GMAX; float* E = sm + 4 * GMAX;
+  float* X = sm; float* R0 = sm + GMAX; float* R1 = sm + 2 * GMAX;
+  __shared__ double g[256];
+  int x0, bw, b;
+  gg_band(ws, x0, bw, b);
+  if (bw == 0) return;
+  const int n = hs * ws;
+  for (int i = threadIdx.x; i < 2 * pad + 1; i += blockDim.x) g[i] = g1d[i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) X[i] = xs_g[(long)b * n + i];
+  __syncthreads();
+  gauss_rows(X, g, hs, ws, pad, x0, bw, R0, R1);
+  __syncthreads();
+  float* S = scratch + (long)b * 3 * n;
+  for (int i = threadIdx.x; i < hs * bw; i += blockDim.x) {
+    const int oy = i / bw, xb = i - oy * bw;
+    const int pt = oy * ws + x0 + xb;
+    double p, ax, ay;
+    gauss_cols_at(R0, R1, g, hs, bw, pad, oy, xb, p, ax, ay);
+    const double ux = ax / p * 2.0 - 1.0, uy = ay / p * 2.0 - 1.0;
+    // clamp(-1,1) passes the gradient where the un-clamped value lies inside [-1,1] (bounds included)
+    const double dgx = (ux >= -1.0 && ux <= 1.0) ? (double)dgrid[((long)b * n + pt) * 2 + 0] : 0.0;
+    const double dgy = (uy >= -1.0 && uy <= 1.0) ? (double)dgrid[((long)b * n + pt) * 2 + 1] : 0.0;
+    const double dax = 2.0 * dgx / p, day = 2.0 * dgy / p;
+    const double dp = -(dax * ax + day * ay) / p;
+    S[pt] = (float)dp; S[n + pt] = (float)dax; S[2 * n + pt] = (float)day;
+  }
+}
+
+// backward, launch 2 of 2: the transposed separable filter on (dp, dax, day), the replication padding folded back onto the border pixels;
+// the band's columns of dxs.
+__global__ __launch_bounds__(1024) void gauss_grid_bwd2_kernel(const float* __restrict__ scratch, const double* __restrict__ g1d,
+                                                               float* __restrict__ dxs, int hs, int ws, int pad) {
+  extern __shared__ float sm[];
+  float* A = sm; float* D = sm + GMAX; float* E = sm + 2 * GMAX; float* Bf = sm + 3 * GMAX; float* Cf = sm + 4 * GMAX;    // Bf / Cf: [hs][bw]
   __shared__ double g[256];
   constexpr int BT = 128;                              // largest grid side the border tables cover
   __shared__ double gx_lo[2 * BT], gx_hi[2 * BT], gy_lo[2 * BT], gy_hi[2 * BT];
-  const int b = blockIdx.x, n = hs * ws, K = 2 * pad + 1;
+  int x0, bw, b;
+  gg_band(ws, x0, bw, b);
+  if (bw == 0) return;
+  const int n = hs * ws, K = 2 * pad + 1;
   for (int i = threadIdx.x; i < K; i += blockDim.x) g[i] = g1d[i];
-  for (int i = threadIdx.x; i < n; i += blockDim.x) A[i] = xs_g[(long)b * n + i];
+  const float* S = scratch + (long)b * 3 * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { A[i] = S[i]; D[i] = S[n + i]; E[i] = S[2 * n + i]; }
   __syncthreads();
-  gauss_rows(A, g, hs, ws, pad, Bf, Cf);
-  __syncthreads();
-  // D0 -> A, D1 -> D, D2 -> E   (gradients w.r.t. p, ax, ay)
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int oy = i / ws, ox = i - oy * ws;
-    double p, ax, ay;
-    gauss_cols_at(Bf, Cf, g, hs, ws, pad, oy, ox, p, ax, ay);
-    const double ux = ax / p * 2.0 - 1.0, uy = ay / p * 2.0 - 1.0;
-    // clamp(-1,1) passes the gradient where the un-clamped value lies inside [-1,1] (bounds included)
-    const double dgx = (ux >= -1.0 && ux <= 1.0) ? (double)dgrid[((long)b * n + i) * 2 + 0] : 0.0;
-    const double dgy = (uy >= -1.0 && uy <= 1.0) ? (double)dgrid[((long)b * n + i) * 2 + 1] : 0.0;
-    const double dax = 2.0 * dgx / p, day = 2.0 * dgy / p;
-    const double dp = -(dax * ax + day * ay) / p;
-    A[i] = (float)dp; D[i] = (float)dax; E[i] = (float)day;   // A (xs) is dead after the row pass
-  }
   // The two border columns (rows) collect the pad+1 padded positions that replicate them.  Summed tap by tap that is
   // (pad+1) x K products for 2/ws of the pixels -- the threads that own them run ~pad times longer than the rest -- so the
   // sums over the padded positions are folded into per-source weights first:
@@ -468,10 +589,10 @@ __global__ __launch_bounds__(1024) void gauss_grid_bwd_kernel(const float* __res
     }
   }
   __syncthreads();
-  // row pass (transposed, folded): for every source row oy and folded column x:
+  // row pass (transposed, folded): for every source row oy and folded column x of the band:
   //   Va[oy][x] = sum_{j -> x} sum_ox g[j-ox] (D0 + cx(j) D1)[oy][ox],   Vb[oy][x] = sum_{j->x} sum_ox g[j-ox] D2[oy][ox]
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int oy = i / ws, x = i - oy * ws;
+  for (int i = threadIdx.x; i < hs * bw; i += blockDim.x) {
+    const int oy = i / bw, x = x0 + (i - oy * bw);
     if (tables && (x == 0 || x == ws - 1)) {
       const double* T = x == 0 ? gx_lo : gx_hi;
       double va = 0.0, vb = 0.0;
@@ -502,13 +623,14 @@ __global__ __launch_bounds__(1024) void gauss_grid_bwd_kernel(const float* __res
   }
   __syncthreads();
   // column pass (transposed, folded): dxs[y][x] = sum_{i -> y} sum_oy g[i-oy] (Va + cy(i) Vb)[oy][x]
-  for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
-    const int y = idx / ws, x = idx - y * ws;
+  for (int idx = threadIdx.x; idx < hs * bw; idx += blockDim.x) {
+    const int y = idx / bw, xb = idx - y * bw;
+    const long o = (long)b * n + y * ws + x0 + xb;
     if (tables && (y == 0 || y == hs - 1)) {
       const double* T = y == 0 ? gy_lo : gy_hi;
       double acc = 0.0;
-      for (int oy = 0; oy < hs; ++oy) acc += T[2 * oy] * (double)Bf[oy * ws + x] + T[2 * oy + 1] * (double)Cf[oy * ws + x];
-      dxs[(long)b * n + idx] = (float)acc;
+      for (int oy = 0; oy < hs; ++oy) acc += T[2 * oy] * (double)Bf[oy * bw + xb] + T[2 * oy + 1] * (double)Cf[oy * bw + xb];
+      dxs[o] = (float)acc;
       continue;
     }
     const int i_lo = (y == 0) ? 0 : y + pad, i_hi = (y == hs - 1) ? hs + 2 * pad - 1 : y + pad;
@@ -520,12 +642,12 @@ __global__ __launch_bounds__(1024) void gauss_grid_bwd_kernel(const float* __res
       double s0 = 0.0, s1 = 0.0;
       for (int oy = o_lo; oy <= o_hi; ++oy) {
         const double gv = g[i - oy];
-        s0 += gv * (double)Bf[oy * ws + x];
-        s1 += gv * (double)Cf[oy * ws + x];
+        s0 += gv * (double)Bf[oy * bw + xb];
+        s1 += gv * (double)Cf[oy * bw + xb];
       }
       acc += s0 + cy * s1;
     }
-    dxs[(long)b * n + idx] = (float)acc;
+    dxs[o] = (float)acc;
   }
 }
 
@@ -902,15 +1024,19 @@ int fs_compress_softmax_fwd(const float* s, const float* w, const float* bias, f
   return FS_OK;
 }
 
-// scratch: B * (C + 1) floats (per-image partial sums of dw and db, added in image order)
+// include/fovealseg.h: floats of scratch fs_compress_softmax_bwd needs (one record of C + 1 partial sums per workgroup)
+long fs_compress_softmax_bwd_scratch_floats(int B, int C) { return (B > 0 && C > 0) ? (long)B * CS_SLICES * (C + 1) : 0; }
+
 int fs_compress_softmax_bwd(const float* g, const float* xs, const float* s, const float* w, float* ds, float* dw, float* db,
                             int B, int HW, int C, float* scratch, hipStream_t stream) {
-  FS_REQUIRE(g && xs && s && w && ds && dw && db && scratch && B > 0 && HW > 0 && C > 0 && C <= 32);
-  hipLaunchKernelGGL(compress_softmax_bwd_kernel, dim3(B), dim3(1024), 0, stream, g, xs, s, w, ds, scratch, HW, C);
+  FS_REQUIRE(g && xs && s && w && ds && dw && db && scratch && B > 0 && HW > 0 && C > 0 && C <= 32 && C % 4 == 0 && CS_THREADS % (C / 4) == 0);
+  FS_REQUIRE((((size_t)s | (size_t)ds | (size_t)w) & 15) == 0);
+  const int nwg = B * CS_SLICES;
+  hipLaunchKernelGGL(compress_softmax_bwd_kernel, dim3(nwg), dim3(CS_THREADS), 0, stream, g, xs, s, w, ds, scratch, HW, C);
   FS_LAUNCH_CHECK();
-  const int r = fs_slab_reduce(scratch, B, C, dw, 0, stream);
+  const int r = fs_slab_reduce(scratch, nwg, C, dw, 0, stream);
   if (r != FS_OK) return r;
-  return fs_slab_reduce(scratch + (long)B * C, B, 1, db, 0, stream);
+  return fs_slab_reduce(scratch + (long)nwg * C, nwg, 1, db, 0, stream);
 }
 
 int fs_area_pool_fwd(const float* y, float* out, int B, int H, int W, int hs, int ws, hipStream_t stream) {
@@ -920,39 +1046,72 @@ int fs_area_pool_fwd(const float* y, float* out, int B, int H, int W, int hs, in
   return FS_OK;
 }
 
+// include/fovealseg.h: floats behind `stats` (6 statistics + 2 pad + per-workgroup partial records of both passes)
+long fs_edge_loss_stats_floats(long n) {
+  if (n <= 0) return 0;
+  const int G = el_wgs(n);
+  return 8 + 4L * G + 2L * (4L * G + 2L * G);
+}
+
 int fs_edge_loss_fwd(const float* xs, const float* t, long n, float coef, float* loss, float* stats, hipStream_t stream) {
-  FS_REQUIRE(xs && t && loss && stats && n > 0);
-  hipLaunchKernelGGL(edge_loss_fwd_kernel, dim3(1), dim3(1024), 0, stream, xs, t, n, coef, loss, stats);
+  FS_REQUIRE(xs && t && loss && stats && n > 0 && (((size_t)stats) & 31) == 0);
+  const int G = el_wgs(n);
+  hipLaunchKernelGGL(edge_minmax_kernel, dim3(G), dim3(EL_THREADS), 0, stream, xs, t, n, stats);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(edge_sums_kernel, dim3(G), dim3(EL_THREADS), 0, stream, xs, t, n, stats);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(edge_finish_kernel, dim3(1), dim3(64), 0, stream, n, coef, G, loss, stats);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
 
-int fs_edge_loss_bwd(const float* xs, const float* t, long n, float coef, const float* gout, const float* stats, float* dxs,
+// stats: the buffer fs_edge_loss_fwd filled (its scratch part is written here: not const)
+int fs_edge_loss_bwd(const float* xs, const float* t, long n, float coef, const float* gout, float* stats, float* dxs,
                      hipStream_t stream) {
-  FS_REQUIRE(xs && t && gout && stats && dxs && n > 0);
-  hipLaunchKernelGGL(edge_loss_bwd_kernel, dim3(1), dim3(1024), 0, stream, xs, t, n, coef, gout, stats, dxs);
+  FS_REQUIRE(xs && t && gout && stats && dxs && n > 0 && (((size_t)stats) & 31) == 0);
+  const int G = el_wgs(n);
+  hipLaunchKernelGGL(edge_bwd_sums_kernel, dim3(G), dim3(EL_THREADS), 0, stream, xs, t, n, coef, gout, stats);
   FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(edge_bwd_apply_kernel, dim3(G), dim3(EL_THREADS), 0, stream, xs, t, n, coef, gout, stats, dxs);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+static int gg_set_lds(const void* fn, int bytes, unsigned long long& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return FS_ERR_ARG;
+  if (dev < 0 || dev >= 64 || !((done >> dev) & 1ull)) {        // the dynamic-LDS opt-in is a per-device function attribute
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    if (dev >= 0 && dev < 64) done |= 1ull << dev;
+  }
   return FS_OK;
 }
 
 int fs_gauss_grid_fwd(const float* xs, const double* g1d, float* grid, int B, int hs, int ws, int pad, hipStream_t stream) {
   FS_REQUIRE(xs && g1d && grid && B > 0 && hs > 1 && ws > 1 && hs * ws <= GMAX && pad >= 0 && 2 * pad + 1 <= 256);
-  hipLaunchKernelGGL(gauss_grid_fwd_kernel, dim3(B), dim3(1024), 3 * GMAX * sizeof(float), stream, xs, g1d, grid, hs, ws, pad);
+  static unsigned long long done = 0ull;
+  const int r = gg_set_lds((const void*)gauss_grid_fwd_kernel, 3 * GMAX * (int)sizeof(float), done);
+  if (r != FS_OK) return r;
+  hipLaunchKernelGGL(gauss_grid_fwd_kernel, dim3(B * GG_BANDS), dim3(1024), 3 * GMAX * sizeof(float), stream, xs, g1d, grid, hs, ws, pad);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
 
+// include/fovealseg.h: floats of scratch fs_gauss_grid_bwd needs ((dp, dax, day) per grid point, handed from its first launch to its second)
+long fs_gauss_grid_bwd_scratch_floats(int B, int hs, int ws) { return (B > 0 && hs > 0 && ws > 0) ? 3L * B * hs * ws : 0; }
+
 int fs_gauss_grid_bwd(const float* xs, const double* g1d, const float* dgrid, float* dxs, int B, int hs, int ws, int pad,
-                      hipStream_t stream) {
-  FS_REQUIRE(xs && g1d && dgrid && dxs && B > 0 && hs > 1 && ws > 1 && hs * ws <= GMAX && pad >= 0 && 2 * pad + 1 <= 256);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gauss_grid_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       5 * GMAX * (int)sizeof(float));
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gauss_grid_bwd_kernel, dim3(B), dim3(1024), 5 * GMAX * sizeof(float), stream, xs, g1d, dgrid, dxs, hs, ws, pad);
+                      float* scratch, hipStream_t stream) {
+  FS_REQUIRE(xs && g1d && dgrid && dxs && scratch && B > 0 && hs > 1 && ws > 1 && hs * ws <= GMAX && pad >= 0 && 2 * pad + 1 <= 256);
+  static unsigned long long done1 = 0ull, done2 = 0ull;
+  int r = gg_set_lds((const void*)gauss_grid_bwd1_kernel, 3 * GMAX * (int)sizeof(float), done1);
+  if (r != FS_OK) return r;
+  r = gg_set_lds((const void*)gauss_grid_bwd2_kernel, 5 * GMAX * (int)sizeof(float), done2);
+  if (r != FS_OK) return r;
+  hipLaunchKernelGGL(gauss_grid_bwd1_kernel, dim3(B * GG_BANDS), dim3(1024), 3 * GMAX * sizeof(float), stream, xs, g1d, dgrid, scratch, hs, ws, pad);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gauss_grid_bwd2_kernel, dim3(B * GG_BANDS), dim3(1024), 5 * GMAX * sizeof(float), stream, scratch, g1d, dxs, hs, ws, pad);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

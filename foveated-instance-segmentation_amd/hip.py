@@ -26,7 +26,7 @@ SIGNATURES = {
     "fs_edge_loss_fwd": "pplfpp",
     "fs_edge_loss_bwd": "pplfppp",
     "fs_gauss_grid_fwd": "pppiiii",
-    "fs_gauss_grid_bwd": "ppppiiii",
+    "fs_gauss_grid_bwd": "ppppiiii" + "p",
     "fs_grid_upsample_fwd": "ppiiiii",
     "fs_grid_upsample_bwd": "ppiiiii",
     "fs_grid_sample_fwd": "pppiiiiiii",
@@ -99,7 +99,8 @@ HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_worksp
              "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes", "fs_attention_bwd_split_ws_bytes", "fs_attention_mask_words", "fs_attention_bwd_split_parts_offset",
              "fs_stream_wait", "fs_set_deterministic", "fs_get_deterministic", "fs_conv2d_bwd_weight_ws_bytes", "fs_linear_bwd_weight_bias_ws_bytes",
              "fs_colsum_scratch_floats", "fs_bn_stats_scratch_doubles", "fs_mask_head_bwd_scratch_floats", "fs_layernorm_bwd_scratch_floats",
-             "fs_conv2d_pack_persistent", "fs_conv2d_ws_mode")
+             "fs_conv2d_pack_persistent", "fs_conv2d_ws_mode",
+             "fs_edge_loss_stats_floats", "fs_compress_softmax_bwd_scratch_floats", "fs_gauss_grid_bwd_scratch_floats")
 
 
 class HipLibraryError(RuntimeError):
@@ -140,6 +141,12 @@ def load():
     lib.fs_mask_head_bwd_scratch_floats.argtypes = [_L, _I]
     lib.fs_layernorm_bwd_scratch_floats.restype = _L
     lib.fs_layernorm_bwd_scratch_floats.argtypes = [_L, _I]
+    lib.fs_edge_loss_stats_floats.restype = _L
+    lib.fs_edge_loss_stats_floats.argtypes = [_L]
+    lib.fs_compress_softmax_bwd_scratch_floats.restype = _L
+    lib.fs_compress_softmax_bwd_scratch_floats.argtypes = [_I, _I]
+    lib.fs_gauss_grid_bwd_scratch_floats.restype = _L
+    lib.fs_gauss_grid_bwd_scratch_floats.argtypes = [_I, _I, _I]
     lib.fs_stream_wait.restype = _I
     lib.fs_stream_wait.argtypes = [_P, _P]
     lib.fs_set_deterministic.restype = _I

@@ -1207,7 +1207,7 @@ class CompressSoftmax(Function):
         ds = torch.empty_like(s)
         dw = torch.empty_like(w)
         db = torch.empty(1, device=s.device, dtype=torch.float32)
-        scratch = torch.empty(B * (C + 1), device=s.device, dtype=torch.float32)
+        scratch = torch.empty(hip.query("fs_compress_softmax_bwd_scratch_floats", B, C), device=s.device, dtype=torch.float32)
         hip.call("fs_compress_softmax_bwd", hip.ptr(g.contiguous()), hip.ptr(xs), hip.ptr(s), hip.ptr(w), hip.ptr(ds), hip.ptr(dw),
                  hip.ptr(db), B, H * W, C, hip.ptr(scratch))
         return ds, dw, db
@@ -1249,7 +1249,8 @@ class EdgeLoss(Function):
     @staticmethod
     def forward(ctx, xs, target, coef):
         loss = torch.empty(1, device=xs.device, dtype=torch.float32)
-        stats = torch.empty(6, device=xs.device, dtype=torch.float32)
+        # 6 statistics kept for the backward + the per-workgroup partial records of both passes
+        stats = torch.empty(hip.query("fs_edge_loss_stats_floats", xs.numel()), device=xs.device, dtype=torch.float32)
         hip.call("fs_edge_loss_fwd", hip.ptr(xs), hip.ptr(target), xs.numel(), float(coef), hip.ptr(loss), hip.ptr(stats))
         ctx.save_for_backward(xs, target, stats)
         ctx.coef = float(coef)
@@ -1281,7 +1282,9 @@ class GaussGrid(Function):
         xs, g1d = ctx.saved_tensors
         B, _, hs, ws = xs.shape
         dxs = torch.empty_like(xs)
-        _launch("fe_gauss_grid_bwd", 4.0 * B * hs * ws * 4, "fs_gauss_grid_bwd", hip.ptr(xs), hip.ptr(g1d), hip.ptr(dgrid.contiguous()), hip.ptr(dxs), B, hs, ws, ctx.pad)
+        scratch = torch.empty(hip.query("fs_gauss_grid_bwd_scratch_floats", B, hs, ws), device=xs.device, dtype=torch.float32)
+        _launch("fe_gauss_grid_bwd", 4.0 * B * hs * ws * 4, "fs_gauss_grid_bwd", hip.ptr(xs), hip.ptr(g1d), hip.ptr(dgrid.contiguous()), hip.ptr(dxs), B, hs, ws,
+                ctx.pad, hip.ptr(scratch))
         return dxs, None, None
 
 

@@ -44,20 +44,29 @@ int fs_compress_bwd(const float* g, const float* s, const float* w, float* ds, f
                     float* scratch, fs_stream_t stream);
 /* s (B,HW,C) -> xs (B,HW) = softmax_HW(w . relu(s) + bias).  models/models.py:369-372,715-723. */
 int fs_compress_softmax_fwd(const float* s, const float* w, const float* bias, float* xs, int B, int HW, int C, fs_stream_t stream);
+/* backward: C a multiple of 4; scratch = fs_compress_softmax_bwd_scratch_floats(B, C) floats (round 5: eight workgroups per image, one
+ * record of C + 1 partial sums each). */
+long fs_compress_softmax_bwd_scratch_floats(int B, int C);
 int fs_compress_softmax_bwd(const float* g, const float* xs, const float* s, const float* w, float* ds, float* dw, float* db,
                             int B, int HW, int C, float* scratch, fs_stream_t stream);
 /* y (B,1,H,W) -> (B,1,hs,ws) adaptive area average.  models/models.py:730. */
 int fs_area_pool_fwd(const float* y, float* out, int B, int H, int W, int hs, int ws, fs_stream_t stream);
-/* loss = coef * mean((minmax(xs) - minmax(t))^2) with whole-batch min/max; stats = 6 floats kept for bwd.
+/* loss = coef * mean((minmax(xs) - minmax(t))^2) with whole-batch min/max.  stats = fs_edge_loss_stats_floats(n) floats, 32-byte
+ * aligned, kept for bwd: [xs_min, xs_max, t_min, t_max, n_argmin, n_argmax] followed by the per-workgroup partial records of both
+ * passes (round 5: every pass over the batch runs on up to 256 workgroups; whole-batch statistics are partials + an ordered sum).
  * models/models.py:889-891,898 (coef = 0.05 * edge_loss_scale). */
+long fs_edge_loss_stats_floats(long n);
 int fs_edge_loss_fwd(const float* xs, const float* t, long n, float coef, float* loss, float* stats, fs_stream_t stream);
-int fs_edge_loss_bwd(const float* xs, const float* t, long n, float coef, const float* gout, const float* stats, float* dxs,
+int fs_edge_loss_bwd(const float* xs, const float* t, long n, float coef, const float* gout, float* stats, float* dxs,
                      fs_stream_t stream);
 /* xs (B,hs,ws) -> grid (B,hs,ws,2)=(x,y) in [-1,1]: replication pad + Gaussian-weighted centroid + clamp.
  * g1d = the 2*pad+1 separable Gaussian taps (double).  models/models.py:594-637,819-821. */
 int fs_gauss_grid_fwd(const float* xs, const double* g1d, float* grid, int B, int hs, int ws, int pad, fs_stream_t stream);
+/* backward: scratch = fs_gauss_grid_bwd_scratch_floats(B, hs, ws) floats (round 5: four workgroups per image, each a band of grid columns;
+ * the first of two launches hands (dp, dax, day) per grid point to the second). */
+long fs_gauss_grid_bwd_scratch_floats(int B, int hs, int ws);
 int fs_gauss_grid_bwd(const float* xs, const double* g1d, const float* dgrid, float* dxs, int B, int hs, int ws, int pad,
-                      fs_stream_t stream);
+                      float* scratch, fs_stream_t stream);
 /* nn.Upsample(size=(H,W), mode='bilinear') of the deformation grid, align_corners=False: grid (B,h,w,2) -> out (B,H,W,2); the
  * task network may run at a higher resolution than the saliency map (TRAIN.task_input_size != saliency_input_size).
  * The backward needs integer factors H/h, W/w.  models/models.py:621-631. */
@@ -122,11 +131,12 @@ long fs_conv2d_workspace_bytes(int H, int W, int Cin, int Ho, int Wo, int Cout, 
  * 4 = 1x1 / stride-1 GEMM kernel with pre-split weights (also the forward of stride >= filter layers with 64-aligned input channels,
  * as that GEMM over gathered rows), 5 = halo-tiled 3x3 stride-1 kernel with F(2,3) minimal filtering along
  * the row (even widths; 12 instead of 18 matrix steps per pixel pair), 6 = bwd-data of a 3x3 / stride-2 / pad-1 layer with the four
- * output parities in one launch, 7 = its forward with the four input parity planes in one LDS refill per chunk.  The
+ * output parities in one launch, 7 = its forward with the four input parity planes in one LDS refill per chunk, 8 = the 3x3 kernel with
+ * F(4,3) minimal filtering along the row (bf16x3, widths that are multiples of 4; 18 instead of 24 matrix steps per four pixels).  The
  * aligned kernels address the source with 32-bit byte offsets, so they are chosen only below 4 GB.  Host-side predicate. */
 int fs_conv2d_kernel_choice(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                             int transposed, long ws_bytes);
-/* Weight packs that outlive the call.  The kernels of families 2-7 above start with a small launch that writes the layer's weights,
+/* Weight packs that outlive the call.  The kernels of families 2-8 above start with a small launch that writes the layer's weights,
  * split into their 16-bit terms in consumption order, into ws; the weights only change at the optimiser step, so a caller may keep one
  * scratch per (layer, direction), fill it once per weight update -- on any stream, e.g. beside the first kernels of the next step
  * -- and run the convolutions on it (every nn.Conv2d on the path, e.g. models/hrnetv2_nodownsp.py:49-55).

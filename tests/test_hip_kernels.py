@@ -493,17 +493,24 @@ def test_split_precision_range_properties(mode, shape):
         xo = x.clone(); xo[0, 3, 5, 5] = 2.0 ** 30
         yo = nchw(ops.conv2d_fwd(nhwc(xo), wd, None, s, 1)).double()
         ro = F.conv2d(xo.double(), w.double(), None, s, 1)
-        mask = torch.ones_like(ro, dtype=torch.bool)
-        lo, hi = (5 - 1) // s, (5 + 1) // s
-        mask[0, :, max(lo, 0):hi + 1, max(lo, 0):hi + 1] = False
-        assert float((yo - ro)[mask].abs().max()) <= 2.0 ** 30 * 2.0 ** -36     # <= 2^-36 of the tile maximum (bound 2^-39 per term)
         lib = fovealseg.hip.load()
         wsb = fovealseg.hip.conv_workspace_bytes(H, W, Ci, Ho, Ho, Co, 3, 3, s, 1, 1, 0)
         choice = lib.fs_conv2d_kernel_choice(B, H, W, Ci, Ho, Ho, Co, 3, 3, s, 1, 1, 0, wsb)
+        mask = torch.ones_like(ro, dtype=torch.bool)
+        lo, hi = (5 - 1) // s, (5 + 1) // s
+        mask[0, :, max(lo, 0):hi + 1, max(lo, 0):hi + 1] = False
+        if choice == 8:
+            # F(4,3): the outlier enters the transform of its whole quad (output columns 4..7 for input column 5); in exact arithmetic it
+            # cancels out of column 7, in fp32 it leaves a transform-domain error there -- that column belongs to the reach
+            mask[0, :, max(lo, 0):hi + 1, 4:8] = False
+        assert float((yo - ro)[mask].abs().max()) <= 2.0 ** 30 * 2.0 ** -36     # <= 2^-36 of the tile maximum (bound 2^-39 per term)
         if choice == 5:
             # inside the reach the F(2,3) kernel forms the output from transform-domain products of size outlier * |U| (U = sums
             # of the filter row), so its error is relative to outlier * max|w|, not to the individual (possibly tiny) output
             assert float((yo - ro)[~mask].abs().max()) <= 2.0 ** 30 * float(w.abs().max()) * 2e-7
+        elif choice == 8:
+            # the F(4,3) kernel likewise, with transform coefficients up to 5 in, 8 out
+            assert float((yo - ro)[~mask].abs().max()) <= 2.0 ** 30 * float(w.abs().max()) * 4e-6
         else:
             # every direct kernel (halo, tap-class, plain) keeps the per-output bound (VERDICT r2 #5c: keyed on the kernel that ran)
             assert choice in (2, 3, 4, 1, 7), choice            # 7 = the stride-2 forward over parity planes: direct products as well
@@ -918,9 +925,10 @@ def test_seg_loss_ragged_sizes(B, K, H, W):
     assert relerr(pd.grad.cpu(), pr.grad) <= 1e-5
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 9, 11), (2, 1, 13, 7), (3, 1, 80, 80)])
+@pytest.mark.parametrize("shape", [(1, 1, 9, 11), (2, 1, 13, 7), (3, 1, 80, 80), (64, 1, 80, 80), (33, 1, 79, 81)])
 def test_edge_loss_ragged_sizes(shape):
-    # element counts with a scalar tail behind the 16-byte passes
+    # element counts with a scalar tail behind the 16-byte passes; round 5: one, five, 100 and 52 workgroups per pass (whole-batch min /
+    # max and sums as per-workgroup partials + an ordered sum), the last with a tail
     gen = torch.Generator().manual_seed(shape[2])
     xs = torch.rand(shape, generator=gen)
     t = torch.rand(shape, generator=gen)
@@ -936,9 +944,10 @@ def test_edge_loss_ragged_sizes(shape):
     assert relerr(xd.grad.cpu(), xr.grad) <= 1e-5
 
 
-@pytest.mark.parametrize("hs,ws,pad", [(48, 100, 45), (32, 160, 20), (80, 80, 45)])
+@pytest.mark.parametrize("hs,ws,pad", [(48, 100, 45), (32, 160, 20), (80, 80, 45), (50, 37, 30), (40, 3, 45)])
 def test_gauss_grid_bwd_shapes(hs, ws, pad):
-    # non-square grids: border-weight tables (sides <= 128) and the tap-by-tap border path (wider), against fp64 autograd
+    # non-square grids: border-weight tables (sides <= 128) and the tap-by-tap border path (wider), against fp64 autograd; round 5: four
+    # column bands per image -- widths that do not divide by four (37: bands of 10, 10, 10, 7) and fewer columns than bands (3)
     gen = torch.Generator().manual_seed(hs + ws)
     xs = torch.softmax(torch.randn(2, hs * ws, generator=gen) * 2, dim=1).view(2, 1, hs, ws)
     g1d = torch.from_numpy(O.gaussian_1d(2 * pad + 1, pad)).to(DEV)
@@ -2286,7 +2295,23 @@ WINO_CASES = [
     ("f16x2", 2, 6, 8, 128, 64),        # f16x2 takes this kernel from 128 input channels up
     ("f16x2", 3, 11, 12, 160, 96),
     ("f16x2", 1, 20, 20, 256, 128),
+    # F(4,3) along the row (csrc/conv_wino4.hip, round 5): bf16x3, widths that are multiples of 4 -- every tile plan the HRNet maps
+    # produce (80 / 40 / 20 wide: 2, 2 and 5 quads per tile row), ragged quad counts, K and N tails, tiles that straddle images
+    ("bf16x3", 2, 80, 80, 64, 64),
+    ("bf16x3", 3, 40, 40, 128, 128),
+    ("bf16x3", 5, 20, 20, 96, 160),
+    ("bf16x3", 2, 16, 24, 36, 100),     # 6 quads per row, K tail (36 = 32 + 4), N tail
+    ("bf16x3", 1, 12, 8, 32, 32),
+    ("bf16x3", 3, 7, 28, 64, 48),       # 7 quads per row (prime): ragged tiles in x
 ]
+
+
+def _wino_choice(mode, W, Cs, Cd):
+    """Kernel-choice code of a 3x3 stride-1 problem that takes the row-transform family: 8 = F(4,3) (bf16x3, W a multiple of 4 from 8 up,
+    except where the eight-wave F(2,3) kernel ties -- more than 64 output and at least 256 input channels on maps up to 20 wide), 5 = F(2,3)."""
+    if os.environ.get("FS_WINO4", "1") == "0" or mode != "bf16x3" or W % 4 or W < 8:
+        return 5
+    return 5 if (Cd > 64 and Cs >= 256 and W <= 20) else 8
 
 
 @pytest.mark.parametrize("case", WINO_CASES)
@@ -2297,10 +2322,10 @@ def test_winograd_row_kernel(case):
         lib = fovealseg.hip.load()
         ws = fovealseg.hip.conv_workspace_bytes(H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 0)
         if os.environ.get("FS_WINOGRAD", "1") != "0":
-            assert lib.fs_conv2d_kernel_choice(B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 0, ws) == 5
+            assert lib.fs_conv2d_kernel_choice(B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 0, ws) == _wino_choice(mode, W, Ci, Co)
             wsb = fovealseg.hip.conv_workspace_bytes(H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 1)
             # bwd-data: the source is dY with Cout channels (>= 32 for the halo family, >= 128 for this kernel in f16x2)
-            want = (5 if mode == "bf16x3" or Co >= 128 else 2) if Co >= 32 else 3
+            want = (_wino_choice(mode, W, Co, Ci) if mode == "bf16x3" or Co >= 128 else 2) if Co >= 32 else 3
             assert lib.fs_conv2d_kernel_choice(B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 1, 1, wsb) == want
         g = torch.Generator().manual_seed(B * 1000 + H * 100 + W + Ci + Co)
         x = torch.randn(B, Ci, H, W, generator=g)
@@ -2313,6 +2338,8 @@ def test_winograd_row_kernel(case):
         xd, wd, bd, dyd = nhwc(x), rsck_param(w), b.to(DEV), nhwc(cot)
         # forward + BatchNorm partial sums: the slabs add up to the column sums / sums of squares of what was written
         y, slab, nwg = ops.conv2d_fwd_stats(xd, wd, bd, 1, 1)
+        # F(4,3)'s output transform carries coefficients up to 8: measured 5e-7 .. 8e-7 forward and 1.0e-6 .. 2.2e-6 bwd-data (the cotangent
+        # is not rectified) where F(2,3) gives 3e-7 .. 6.5e-7 / 4.6e-7 .. 9.4e-7 (profiles/r05/wino4_ab.txt); same bound forward, 5e-6 bwd-data
         assert relerr(nchw(y), y64.detach()) <= 3e-6
         sums = slab.view(nwg, Co, 2).double().sum(0).cpu()
         yf = y.double().reshape(-1, Co).cpu()
@@ -2326,7 +2353,7 @@ def test_winograd_row_kernel(case):
         assert torch.equal(yd, torch.where(keep, y * (1.0 / (1.0 - p)), torch.zeros_like(y)))
         # bwd-data = the same kernel on the flipped, transposed weights
         dx = ops.conv2d_bwd_data(dyd, wd, xd.shape, 1, 1)
-        assert relerr(nchw(dx), x64.grad) <= 3e-6
+        assert relerr(nchw(dx), x64.grad) <= (5e-6 if _wino_choice(mode, W, Co, Ci) == 8 else 3e-6)
         # zeros in -> exact zeros out; a power-of-two scale goes through bit for bit where no tile mixes scales (bf16x3: everywhere)
         assert float(ops.conv2d_bwd_data(torch.zeros_like(dyd), wd, xd.shape, 1, 1).abs().max()) == 0.0
         if mode == "bf16x3":

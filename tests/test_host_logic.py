@@ -230,9 +230,13 @@ def test_conv_dispatch_predicate_above_4gb():
             # in the split modes, generic above (source or destination)
             small = lib.fs_conv2d_kernel_choice(64, 80, 80, 64, 80, 80, 64, 3, 3, 1, 1, 1, 0, ws)
             wino_on = os.environ.get("FS_WINOGRAD", "1") != "0"
-            assert small == ((5 if wino_on and mode == 1 else 2) if mode else 1), (mode, small)      # f16x2: from 128 channels up
+            # (8 = the F(4,3) kernel of round 5: bf16x3, widths that are multiples of 4; 5 = F(2,3))
+            assert small == ((8 if wino_on and mode == 1 else 2) if mode else 1), (mode, small)      # f16x2: from 128 channels up
             wide = lib.fs_conv2d_kernel_choice(64, 40, 40, 128, 40, 40, 128, 3, 3, 1, 1, 1, 0, ws)
-            assert wide == ((5 if wino_on else 2) if mode else 1), (mode, wide)
+            assert wide == (((8 if mode == 1 else 5) if wino_on else 2) if mode else 1), (mode, wide)
+            # two pairs per row, not a whole quad: F(2,3); more than 64 output and >= 256 input channels on a 20-wide map: the eight-wave F(2,3) kernel
+            assert lib.fs_conv2d_kernel_choice(64, 10, 10, 64, 10, 10, 64, 3, 3, 1, 1, 1, 0, ws) == ((5 if wino_on and mode == 1 else 2) if mode else 1)
+            assert lib.fs_conv2d_kernel_choice(64, 20, 20, 256, 20, 20, 256, 3, 3, 1, 1, 1, 0, ws) == ((5 if wino_on else 2) if mode else 1)
             odd = lib.fs_conv2d_kernel_choice(64, 81, 81, 64, 81, 81, 64, 3, 3, 1, 1, 1, 0, ws)
             assert odd == (2 if mode else 1), (mode, odd)
             assert lib.fs_conv2d_kernel_choice(2800, 80, 80, 64, 80, 80, 64, 3, 3, 1, 1, 1, 0, ws) == 0       # 4.6 GB source
