@@ -45,7 +45,7 @@ def _profiled_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this same command
     (profiles/rNN/hbm_traffic_serial*.json; FETCH_SIZE doubled per the gfx950 correction).  PMC counters
     cannot be read from inside the benchmark process, so this is the offline measurement, or None."""
-    for rel in ("profiles/r04/hbm_traffic_serial.json", "profiles/r03/hbm_traffic_serial.json", "profiles/r02/hbm_traffic_serial.json", "profiles/r01/hbm_traffic_serial.json"):
+    for rel in ("profiles/r05/hbm_traffic_serial.json", "profiles/r04/hbm_traffic_serial.json", "profiles/r03/hbm_traffic_serial.json", "profiles/r02/hbm_traffic_serial.json", "profiles/r01/hbm_traffic_serial.json"):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 table = json.load(f)
@@ -61,7 +61,7 @@ def _profiled_traffic(kernel):
 
 
 def _profiled_traffic_table():
-    for rel in ("profiles/r04/hbm_traffic_serial.json", "profiles/r03/hbm_traffic_serial.json"):
+    for rel in ("profiles/r05/hbm_traffic_serial.json", "profiles/r04/hbm_traffic_serial.json", "profiles/r03/hbm_traffic_serial.json"):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 return json.load(f), rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
@@ -75,8 +75,8 @@ def _profiled_mfma_busy(mode, kernel):
     (profiles/r02/pmc/sq_<mode>_<kernel>_fwd_shape0.txt: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)), or None."""
     import ast
     import re
-    rel = f"profiles/r04/pmc/sq_{mode}_{kernel}_fwd_shape0.txt"
-    for older in ("r03", "r02"):
+    rel = f"profiles/r05/pmc/sq_{mode}_{kernel}_fwd_shape0.txt"
+    for older in ("r04", "r03", "r02"):
         if not os.path.exists(os.path.join(ROOT, rel)):
             rel = f"profiles/{older}/pmc/sq_{mode}_{kernel}_fwd_shape0.txt"
     try:
@@ -90,6 +90,32 @@ def _profiled_mfma_busy(mode, kernel):
                 "sustained_clock_ghz": round(per_xcd / (vals["_dur"] * 1e3), 2), "shape": "64->64 3x3 @ 80x80, B=64", "source": rel}
     except Exception:
         return None
+
+
+def _profiled_kernel_avg_us(knames):
+    """Average duration of the named kernels in the committed `rocprofv3 --kernel-trace --stats` summary of this same command with the
+    branch streams serialised (profiles/r05/bench_serial_kernel_stats_bf16x3.csv): the KERNEL alone, where `avg_launch_us` of the line is
+    an in-process event bracket around the C-ABI call including its weight-pack pre-kernel."""
+    import csv
+    for rel in ("profiles/r05/bench_serial_kernel_stats_bf16x3.csv", "profiles/r04/bench_serial_kernel_stats_bf16x3_final_build.csv"):
+        try:
+            tot, calls = 0.0, 0
+            with open(os.path.join(ROOT, rel)) as f:
+                for row in csv.DictReader(f):
+                    if any(k + "<" in row["Name"] for k in knames):
+                        tot += float(row["TotalDurationNs"]); calls += int(row["Calls"])
+            if calls:
+                return {"kernel_avg_us": round(tot / calls / 1e3, 2), "source": rel}
+        except Exception:
+            continue
+    return None
+
+
+def takes_f43(W, Cs, Cd):
+    """csrc/conv_wino.hip: wino4_selected -- which 3x3 stride-1 problems of the bf16x3 mode run on the F(4,3) kernel (the rest: F(2,3))."""
+    if os.environ.get("FS_WINO4", "1") == "0" or W % 4 or W < 8:
+        return False
+    return not (Cd > 64 and Cs >= 256 and W <= 20)
 
 
 def _threads():
@@ -272,7 +298,7 @@ def main():
                 steps(args.steps)
                 barrier()
                 serial_elapsed = time.perf_counter() - tr0
-                res.update(roofline_entries(mode, timer.summary(), args.steps, serial_elapsed))
+                res.update(roofline_entries(mode, timer.summary(), args.steps, serial_elapsed, timer))
                 res.update(family_entries(mode, timer, args.steps))
             except Exception as exc:                       # the throughput line must survive a failure of the diagnostic pass
                 res["roofline"] = None
@@ -387,7 +413,8 @@ def _short_roofline(r):
     """The one roofline object of the JSON line: fixed keys, kernel name <= 80 characters."""
     if not r:
         return None
-    keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_us")
+    keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_measured_in_this_run", "launches_per_step", "avg_launch_us", "kernel_avg_us",
+            "executed_mfma_fraction")
     out = {"kernel": str(r.get("kernel", "")).split(" (")[0][:80]}
     out.update({k: r.get(k) for k in keys})
     return out
@@ -445,7 +472,7 @@ FRONTEND_KINDS = {
 }
 
 
-def roofline_entries(mode, summ, nsteps, serial_elapsed):
+def roofline_entries(mode, summ, nsteps, serial_elapsed, timer=None):
     tag, n_mfma, _bits, how = MODES[mode]
     peak = mode_peak(mode)
     out = {}
@@ -455,7 +482,7 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
         tr = _profiled_traffic(kname)
         return {"kernel": desc, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": tr["hbm_bytes_per_launch"] if tr else None, "traffic_unit": "HBM bytes per launch",
-                "traffic_source": tr["source"] if tr else None,
+                "traffic_source": tr["source"] if tr else None, "traffic_measured_in_this_run": False,
                 "launches_per_step": kk["launches"] // nsteps,
                 "avg_launch_us": round(1000.0 * kk["total_ms"] / kk["launches"], 2),
                 "gflop_per_launch": round(kk["flops"] / kk["launches"] / 1e9, 3),
@@ -486,22 +513,45 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
                 "share_of_serial_step": round(kk["total_ms"] / (1000.0 * serial_elapsed), 3)}
 
     if tag is not None and "conv3x3" in summ:
-        # every 3x3 stride-1 layer of this workload has an even width: in bf16x3 all of them take the F(2,3) row kernel, in f16x2 those
-        # with >= 128 source channels do (csrc/conv_wino.hip: fs_wino_eligible) and the rest the plain halo kernel
+        # every 3x3 stride-1 layer of this workload has an even width.  bf16x3: the layers whose width is a multiple of 4 take the F(4,3) row
+        # kernel of round 5 (csrc/conv_wino4.hip; takes_f43 above), the 10-wide maps and the wide 20-wide layers the F(2,3) kernels; f16x2: the
+        # layers with >= 128 source channels take F(2,3) (csrc/conv_wino.hip: fs_wino_eligible), the rest the plain halo kernel
         wino = os.environ.get("FS_WINOGRAD", "1") != "0"
-        kname = ["conv3x3_wino_kernel", "conv3x3_wino8_kernel"] if wino else "conv3x3_halo_kernel"
-        what = (f"conv3x3_wino_kernel<{tag}> (+ its eight-wave form conv3x3_wino8_kernel on wide layers; 3x3 stride-1 forward + bwd-data, halo-tiled "
-                "implicit GEMM with F(2,3) minimal filtering along the row: 12 of the direct form's 18 MFMA steps per pixel pair are executed"
-                + ("; layers below 128 source channels run conv3x3_halo_kernel, the direct form" if mode == "f16x2" else "") + f"; {how}; ")
+        f43 = wino and mode == "bf16x3" and os.environ.get("FS_WINO4", "1") != "0"
+        kname = (["conv3x3_wino4_kernel"] if f43 else []) + (["conv3x3_wino_kernel", "conv3x3_wino8_kernel"] if wino else ["conv3x3_halo_kernel"])
+        if f43:
+            what = (f"conv3x3_wino4_kernel<{tag}> (+ conv3x3_wino_kernel / conv3x3_wino8_kernel on the 10-wide maps and the wide 20-wide layers; 3x3 stride-1 "
+                    "forward + bwd-data, halo-tiled implicit GEMM with F(4,3) minimal filtering along the row: 18 matrix steps per four output pixels where the "
+                    f"direct form spends 36 and F(2,3) 24; {how}; ")
+        else:
+            what = (f"conv3x3_wino_kernel<{tag}> (+ its eight-wave form conv3x3_wino8_kernel on wide layers; 3x3 stride-1 forward + bwd-data, halo-tiled "
+                    "implicit GEMM with F(2,3) minimal filtering along the row: 12 of the direct form's 18 MFMA steps per pixel pair are executed"
+                    + ("; layers below 128 source channels run conv3x3_halo_kernel, the direct form" if mode == "f16x2" else "") + f"; {how}; ")
         if not wino:
             what = f"conv3x3_halo_kernel<{tag}> (3x3 stride-1 forward + bwd-data, halo-tiled implicit GEMM; {how}; "
         out["roofline"] = entry(
             summ["conv3x3"],
             what + "achieved = ALGORITHMIC FLOP/s of the direct convolution (2*B*H*W*Cout*9*Cin per launch) over the C-ABI call incl. its weight "
             "pack pre-kernel, peak = dense 16-bit MFMA peak / MFMAs per product)", kname)
-        out["roofline"]["executed_mfma_fraction"] = round(2.0 / 3.0, 4) if (wino and mode == "bf16x3") else None
+        # share of the direct form's products the matrix cores execute, FLOP-weighted over the launches of the pass: 1/2 on the F(4,3)
+        # kernel, 2/3 on the F(2,3) kernels (from the per-launch records: entry point + leading integer arguments)
+        frac_exec = None
+        if wino and mode == "bf16x3":
+            frac_exec = 2.0 / 3.0
+            if timer is not None and timer.tags.get("conv3x3"):
+                num = den = 0.0
+                for (s_, e_, fl), t_ in zip(timer.records["conv3x3"], timer.tags["conv3x3"]):
+                    bwd = t_[0].startswith("fs_conv2d_bwd_data")
+                    W_, Cs_, Cd_ = t_[3], (t_[7] if bwd else t_[4]), (t_[4] if bwd else t_[7])
+                    num += fl * (0.5 if (f43 and takes_f43(W_, Cs_, Cd_)) else 2.0 / 3.0); den += fl
+                frac_exec = num / den if den else frac_exec
+        out["roofline"]["executed_mfma_fraction"] = round(frac_exec, 4) if frac_exec is not None else None
+        ka = _profiled_kernel_avg_us(kname) if mode == "bf16x3" else None
+        out["roofline"]["kernel_avg_us"] = ka["kernel_avg_us"] if ka else None
+        out["roofline"]["kernel_avg_us_source"] = (ka["source"] + " (rocprofv3 --kernel-trace --stats: the kernels alone; avg_launch_us is the in-process bracket "
+                                                   "around the C-ABI call incl. the weight pack)") if ka else None
         out["roofline"]["note"] = ("frac prices the direct-convolution FLOPs against the dense peak; the matrix cores execute executed_mfma_fraction of them "
-                                   "(frac * executed_mfma_fraction = share of the peak the MFMA pipe actually delivers)") if (wino and mode == "bf16x3") else None
+                                   "(frac * executed_mfma_fraction = share of the peak the MFMA pipe actually delivers)") if frac_exec is not None else None
         if "wgrad3x3" in summ:
             out["roofline_wgrad"] = entry(summ["wgrad3x3"], f"conv_wgrad_class_kernel<{tag},3,3> (3x3 stride-1 bwd-weight, 9 taps per workgroup)",
                                           f"conv_wgrad_class_kernel<fs_split::{tag}, 3, 3")
@@ -516,7 +566,8 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed):
         if "conv_wgrad" in summ:
             out["roofline_wgrad"] = entry(summ["conv_wgrad"], "conv_wgrad_taps_kernel<3|9> + conv_wgrad_kernel (bwd-weight, fp32 MFMA)", "conv_wgrad_taps_kernel")
     if "roofline" in out:
-        dominant = "conv3x3_wino_kernel" if (mode == "bf16x3" and os.environ.get("FS_WINOGRAD", "1") != "0") else "conv3x3_halo_kernel"
+        dominant = (("conv3x3_wino4_kernel" if os.environ.get("FS_WINO4", "1") != "0" else "conv3x3_wino_kernel")
+                    if (mode == "bf16x3" and os.environ.get("FS_WINOGRAD", "1") != "0") else "conv3x3_halo_kernel")
         out["roofline"]["mfma_utilisation"] = _profiled_mfma_busy(mode, dominant)       # offline SQ counters of the same kernel (rocprofv3 --pmc)
         out["roofline"]["serial_ms_per_step"] = round(1000.0 * serial_elapsed / nsteps, 2)
         out["roofline"]["measured"] = "second pass of the same K steps with branch streams serialised, HIP events per launch on the launch stream"

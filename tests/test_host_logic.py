@@ -309,8 +309,12 @@ def test_bench_line_is_short_and_parseable(tmp_path, monkeypatch):
     assert back["value"] == 331.7 and back["conv_precision"] == "bf16x3" and back["config"]["workload"].startswith("configs[1]")
     assert "model" not in back["config"]
     r = back["roofline"]
-    assert set(r) == {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_us"}
-    assert len(r["kernel"]) <= 80 and r["kernel"].startswith("conv3x3_wino_kernel<PrecX3>") and r["bound"] == "mfma"
+    # round 5: the line says what each number is -- kernel_avg_us (rocprof, the kernels alone) beside avg_launch_us (in-process
+    # bracket around the C-ABI call incl. the weight pack), traffic marked as not measured in this run, the share of the products executed
+    assert set(r) == {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_measured_in_this_run", "launches_per_step",
+                      "avg_launch_us", "kernel_avg_us", "executed_mfma_fraction"}
+    assert r["traffic_measured_in_this_run"] is False
+    assert len(r["kernel"]) <= 80 and r["kernel"].startswith("conv3x3_wino4_kernel<PrecX3>") and r["bound"] == "mfma"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert set(back["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and back["cpu_baseline"]["kind"] == "port"
     assert set(back["modes"]) == set(results) and set(back["modes"]["f32"]) == {"value", "ms_per_step", "frac"}
