@@ -113,9 +113,7 @@ def _profiled_kernel_avg_us(knames):
 
 def takes_f43(W, Cs, Cd):
     """csrc/conv_wino.hip: wino4_selected -- which 3x3 stride-1 problems of the bf16x3 mode run on the F(4,3) kernel (the rest: F(2,3))."""
-    if os.environ.get("FS_WINO4", "1") == "0" or W % 4 or W < 8:
-        return False
-    return not (Cd > 64 and Cs >= 256 and W <= 20)
+    return not (os.environ.get("FS_WINO4", "1") == "0" or W % 4 or W < 8)
 
 
 def _threads():
@@ -518,9 +516,9 @@ def roofline_entries(mode, summ, nsteps, serial_elapsed, timer=None):
         # layers with >= 128 source channels take F(2,3) (csrc/conv_wino.hip: fs_wino_eligible), the rest the plain halo kernel
         wino = os.environ.get("FS_WINOGRAD", "1") != "0"
         f43 = wino and mode == "bf16x3" and os.environ.get("FS_WINO4", "1") != "0"
-        kname = (["conv3x3_wino4_kernel"] if f43 else []) + (["conv3x3_wino_kernel", "conv3x3_wino8_kernel"] if wino else ["conv3x3_halo_kernel"])
+        kname = (["conv3x3_wino4_kernel", "conv3x3_wino48_kernel"] if f43 else []) + (["conv3x3_wino_kernel", "conv3x3_wino8_kernel"] if wino else ["conv3x3_halo_kernel"])
         if f43:
-            what = (f"conv3x3_wino4_kernel<{tag}> (+ conv3x3_wino_kernel / conv3x3_wino8_kernel on the 10-wide maps and the wide 20-wide layers; 3x3 stride-1 "
+            what = (f"conv3x3_wino4_kernel<{tag}> (+ its eight-wave form conv3x3_wino48_kernel on wide layers, conv3x3_wino8_kernel on the 10-wide maps; 3x3 stride-1 "
                     "forward + bwd-data, halo-tiled implicit GEMM with F(4,3) minimal filtering along the row: 18 matrix steps per four output pixels where the "
                     f"direct form spends 36 and F(2,3) 24; {how}; ")
         else:

@@ -47,7 +47,7 @@ int fs_wino_conv3x3(int mode, const float* src, const float* w, const float* bia
 bool fs_wino_takes_f43(int mode, int B, int H, int W, int Cs, int Cd);      // conv_wino.hip: this problem goes to the F(4,3) kernel
 bool fs_wino4_eligible(int mode, int B, int H, int W, int Cs, int Cd);
 long fs_wino4_pack_bytes(int mode, int Cs, int Cd);
-int fs_wino4_stats_slabs(int B, int H, int W);
+int fs_wino4_stats_slabs(int B, int H, int W, int Cs, int Cd);
 int fs_wino4_conv3x3(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, int B, int H, int W, int Cs,
                      int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key, const FsBnSums* bn,
                      hipStream_t stream);

@@ -1024,9 +1024,8 @@ static bool wino4_selected(int mode, int B, int H, int W, int Cs, int Cd) {
   static const int pol = FS_ENV_INT("FS_WINO4", 1);
   if (pol == 0 || !fs_wino4_eligible(mode, B, H, W, Cs, Cd)) return false;
   // B = 64, us per call F(2,3) -> F(4,3): 64 -> 64 @ 80x80 167 -> 141 (fwd) / 165 -> 141 (bwd-data), 128 -> 128 @ 40x40 150 -> 132 / 151 -> 134,
-  // 192 -> 192 @ 80x80 1 090 -> 962, 960 -> 240 @ 80x80 5 810 -> 5 430 / 6 980 -> 6 530; against the eight-wave kernel on 256 -> 256 @ 20x20
-  // 142 -> 142 / 149 -> 145: a tie, which stays with the kernel of the lower error
-  if (pol == 1 && wino_use8(mode, Cs, Cd) && W <= 20) return false;
+  // 192 -> 192 @ 80x80 1 090 -> 962, 960 -> 240 @ 80x80 5 940 -> 5 285 / 7 150 -> 5 840 and 256 -> 256 @ 20x20 144 -> 130 / 145 -> 134 with the
+  // eight-wave form of the F(4,3) kernel (against the eight-wave F(2,3) kernel; its four-wave form only tied there: 142 / 142)
   return true;
 }
 
@@ -1043,7 +1042,7 @@ long fs_wino_pack_bytes(int mode, int Cs, int Cd) {
 }
 
 int fs_wino_stats_slabs(int mode, int B, int H, int W, int Cs, int Cd) {
-  if (wino4_selected(mode, B, H, W, Cs, Cd)) return fs_wino4_stats_slabs(B, H, W);
+  if (wino4_selected(mode, B, H, W, Cs, Cd)) return fs_wino4_stats_slabs(B, H, W, Cs, Cd);
   int Ph, PP, tx, nx;
   wino_plan(B, H, W, Ph, PP, tx, nx);
   return wino_use8(mode, Cs, Cd) ? 2 * nx : nx;        // the eight-wave kernel writes one row per (pixel tile, pixel parity)

@@ -473,6 +473,361 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(W4Args a) {
   }
 }
 
+// ---- eight-wave form (the structure of conv3x3_wino8_kernel, conv_wino.hip): one workgroup of 512 threads per CU owns 32 quads x 128
+// columns; waves = 2 component triples x 4 column groups.  Both waves of a SIMD (w and w + 4) stay in the MFMA phase and the split /
+// store of the NEXT chunk's halo image is a block of vector code inside the CURRENT chunk's MFMA phase, at step S_EARLY for waves 0-3
+// and S_LATE for waves 4-7, into the other of two LDS images (2 x 64 KB: an image is 57.6 KB, an exchange round of the epilogue 64 KB);
+// halo loads for chunk j + 2 go into the registers the split of chunk j + 1 just freed.  One barrier per chunk.  The split work per
+// MFMA is half the four-wave kernel's (one image feeds 128 columns).  For layers with > 64 destination and >= 256 source channels.
+template <class P>
+__global__ __launch_bounds__(512, 1) void conv3x3_wino48_kernel(W4Args a) {
+  static_assert(!P::SCALED, "bf16x3 only");
+  typedef typename P::x8 X8;
+  typedef typename P::x4 X4;
+  constexpr int NPL = P::NPL;
+  constexpr int IMG = XCH_BYTES;             // bytes reserved per halo image (57.6 KB used) = one exchange round
+  constexpr int NCOL = 128;                  // columns per workgroup
+  constexpr int S_EARLY = 3, S_LATE = 12;    // steps behind which waves 0-3 / 4-7 split the next chunk
+  constexpr int RD = 3;
+  static_assert(NPL * PLANE * 2 <= IMG && NSTEP % RD == 0, "image inside its buffer; ring phase kept across chunks");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* rowpix = reinterpret_cast<int*>(smem + 2 * IMG);                        // [2 tile parities][32]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int hw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = hw >> 2;                                                      // component triple; also the stagger group
+  const int wn = hw & 3;                                                       // 32-column group
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int ntile = a.nx * a.ny;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qd = ntile >> 3, rm = ntile & 7;
+  const int t_first = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd);
+  const int t_end = t_first + qd + (xcd < rm ? 1 : 0);
+  const int L = ((int)gridDim.x + 7 - xcd) >> 3;
+  if (t_first + loc >= t_end) return;                                          // workgroup-uniform
+  const int ntw = (t_end - t_first - loc + L - 1) / L;                         // tiles this workgroup walks: t_first + loc + k L
+  const int nch = a.nchunk;
+  const int nslots = (a.Ph + 2) * a.PQ, nquads = a.Ph * a.PQ;
+
+  auto image_row = [&](int vy, int& bb, int& yy) {
+    const bool in = vy >= 0 && vy < a.B * a.Hv;
+    bb = in ? div_small(vy, a.magic_hv) : 0;
+    yy = in ? vy - bb * a.Hv : a.H;
+  };
+  auto decode = [&](int w_, int& mt, int& n0, int& y0, int& x0) {
+    mt = div_small1(w_, a.magic_ny);
+    n0 = (w_ - mt * a.ny) * NCOL;
+    const int ty = div_small1(mt, a.magic_tx), tx = mt - ty * a.tiles_x;
+    y0 = ty * a.Ph; x0 = tx * 4 * a.PQ;
+  };
+  auto write_rowpix = [&](int par, int y0, int x0) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    if (t_ < NQ) {
+      const int p = row_perm(t_);
+      const int py = div_small(p, a.magic_pq), px = p - py * a.PQ;
+      int bb, yy;
+      image_row(y0 + py, bb, yy);
+      const bool live = p < nquads && yy < a.H && x0 + 4 * px < a.W;
+      rowpix[par * NQ + t_] = live ? ((bb * a.H + yy) * a.W + x0 + 4 * px) * a.Cd : -1;
+    }
+  };
+  // halo loader: one item per thread = (slot tid >> 3, channel quad tid & 7); slots 0..39 exist: waves 0-4 (wave-uniform)
+  const bool has_item = hw < 5;
+  int goff = 0, gmask = 0;
+  auto setup_loader = [&](int y0, int x0) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    const int slot = t_ >> 3;
+    const int hy = div_small(slot, a.magic_pq), pj = slot - hy * a.PQ;
+    const int ix = x0 + 4 * pj - 1;
+    int bb, iy;
+    image_row(y0 + hy - 1, bb, iy);
+    const bool rowok = slot < nslots && iy < a.H;
+    int m = 0;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) m |= (rowok && ix + e >= 0 && ix + e < a.W) ? (1 << e) : 0;
+    gmask = m;
+    goff = ((bb * a.H + (rowok ? iy : 0)) * a.W + ix) * a.Cs + 4 * (t_ & 7);
+  };
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(a.src, a.src_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.ws, a.ws_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
+  const int q = tid & 7;
+
+  f32x4 ra[6];
+  auto load_halo = [&](int chunk) {
+    if (!has_item) return;
+    const int c0 = chunk * 32;
+    const bool cok = c0 + 4 * q < a.Cs;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const bool ok = cok && ((gmask >> e) & 1);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? (int)((unsigned)(goff + e * a.Cs + c0) * 4u) : (int)OOB, 0, 0);
+      ra[e] = __builtin_bit_cast(f32x4, v);
+    }
+  };
+  auto store_halo = [&](int buf) {         // d0..d5 -> T0..T5 -> planes -> image `buf`
+    if (!has_item) return;
+    const int slot = tid >> 3;
+    if (slot >= nslots) return;
+    typename P::T* Aw = reinterpret_cast<typename P::T*>(smem + buf * IMG);
+    const f32x4 d0 = ra[0], d1 = ra[1], d2 = ra[2], d3 = ra[3], d4 = ra[4], d5 = ra[5];
+    const f32x4 e42 = d4 - 4.f * d2, o31 = d3 - 4.f * d1;
+    const f32x4 e2 = d4 - d2, o2 = 2.f * (d3 - d1);
+    const f32x4 T[NC] = {(4.f * d0 - 5.f * d2) + d4, e42 + o31, e42 - o31, e2 + o2, e2 - o2, (4.f * d1 - 5.f * d3) + d5};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      X4 p[NPL];
+      P::split4(T[c], p);
+      const int o = (c * WNS + slot) * XLD + 4 * q;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<X4*>(&Aw[pl * PLANE + o]) = p[pl];
+    }
+  };
+
+  int rowbase;
+  const int rowstep = a.PQ * XLD;
+  {
+    const int p = row_perm(l31);
+    const bool live = p < nquads;
+    const int py = live ? div_small(p, a.magic_pq) : 0, px = live ? p - py * a.PQ : 0;
+    rowbase = 3 * ct * CPLANE + (py * a.PQ + px) * XLD + 8 * lh;
+  }
+  const int plane_bytes = a.Npad * 32;
+  const int step_bytes = NPL * plane_bytes;
+  const int G = nch * NSTEP;               // B fragments this wave consumes per tile
+  auto b_voff = [&](int n0) { return HDR + ((n0 + 32 * wn + l31) * 16 + 8 * lh) * 2; };
+
+  X8 fa[2][NPL];
+  X8 fb[RD][NPL];
+  auto load_b = [&](int gg, int voff, X8 (&dst)[NPL]) {
+    const int kyc = (int)(((unsigned)gg * 10923u) >> 16);
+    const int g4 = kyc * 12 + 6 * ct + (gg - 6 * kyc);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff, g4 * step_bytes + pl * plane_bytes, 0);
+      dst[pl] = __builtin_bit_cast(X8, v);
+    }
+  };
+  auto read_a = [&](int buf, int step, X8 (&dst)[NPL]) {
+    const int ky = step / 6, ci = (step >> 1) % 3, s2 = step & 1;
+    const typename P::T* Ar = reinterpret_cast<const typename P::T*>(smem + buf * IMG);
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+      dst[pl] = *reinterpret_cast<const X8*>(&Ar[pl * PLANE + rowbase + ky * rowstep + ci * CPLANE + 16 * s2]);
+  };
+
+  // ---- cursors: the halo loader runs up to two chunks ahead of the MFMAs, across tile boundaries ----
+  int lk = 0, lc = 0;                      // (tile number, chunk) of the next halo load
+  auto loader_advance = [&]() {
+    if (++lc == nch) {
+      lc = 0; ++lk;
+      if (lk < ntw) {
+        int mt_, n0_, y0_, x0_;
+        decode(t_first + loc + lk * L, mt_, n0_, y0_, x0_);
+        setup_loader(y0_, x0_);
+      }
+    }
+  };
+  int mt, n0, y0, x0;
+  decode(t_first + loc, mt, n0, y0, x0);
+  setup_loader(y0, x0);
+  write_rowpix(0, y0, x0);
+  int bvoff = b_voff(n0);
+#pragma unroll
+  for (int r = 0; r < RD - 1; ++r) load_b(r, bvoff, fb[r]);
+  load_halo(0);
+  loader_advance();
+  store_halo(0);                           // chunk 0 of the first tile (exposed once per workgroup)
+  if (lk < ntw) { load_halo(lc); loader_advance(); }
+  __syncthreads();
+
+  int J = 0;                               // chunks multiplied so far: image buffer of the current chunk = J & 1
+  const int total_chunks = ntw * nch;
+  for (int k = 0; k < ntw; ++k) {
+    const bool has_next = k + 1 < ntw;
+    int mt_n = 0, n0_n = 0, y0_n = 0, x0_n = 0, bvoff_n = bvoff;
+    if (has_next) {
+      decode(t_first + loc + (k + 1) * L, mt_n, n0_n, y0_n, x0_n);
+      bvoff_n = b_voff(n0_n);
+    }
+    f32x16 acc[3], sacc[3];                // leading term / small terms (see the four-wave kernel)
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[ci][r] = 0.f; sacc[ci][r] = 0.f; }
+    int g = 0;
+    for (int chunk = 0; chunk < nch; ++chunk, ++J) {
+      const int buf = J & 1;
+      const bool split_next = J + 1 < total_chunks;          // ra holds the halo of chunk J + 1 (this tile's next chunk or the next tile's first)
+      read_a(buf, 0, fa[0]);
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        if (st + 1 < NSTEP) read_a(buf, st + 1, fa[(st + 1) & 1]);
+        {
+          const int gi = g + RD - 1;
+          const bool own = gi < G;
+          const int gn = gi - G < G ? gi - G : G - 1;
+          load_b(own ? gi : (has_next ? gn : G - 1), own ? bvoff : bvoff_n, fb[(st + RD - 1) % RD]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const X8(&A)[NPL] = fa[st & 1];
+        const X8(&Bf)[NPL] = fb[st % RD];
+        const int ci = (st >> 1) % 3;
+#pragma unroll
+        for (int t = 0; t + 1 < P::NTERM; ++t) sacc[ci] = P::mfma(A[P::ta(t)], Bf[P::tb(t)], sacc[ci]);
+        acc[ci] = P::mfma(A[P::ta(P::NTERM - 1)], Bf[P::tb(P::NTERM - 1)], acc[ci]);
+        __builtin_amdgcn_sched_barrier(0);
+        ++g;
+        // the NEXT chunk's split / store, at a different step for the two waves of a SIMD (w and w + 4, i.e. ct = 0 / 1)
+        if ((st == S_EARLY || st == S_LATE) && split_next && (st == S_EARLY) == (ct == 0)) {
+          store_halo(buf ^ 1);
+          if (lk < ntw) { load_halo(lc); loader_advance(); }    // chunk J + 2 into the registers just freed
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- epilogue: two exchange rounds through the image buffer the last chunk was read from.  Round r: every wave leaves its partial
+    // sums of outputs r and 2 + r; the wave of triple t then stores output 2 t + r of its column group. ----
+    unsigned char* const xbuf = smem + ((J - 1) & 1) * IMG;
+    const int par = k & 1;
+    const int n = n0 + 32 * wn + (lane & 7) * 4;
+    const bool nok = n < a.Cd;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr && nok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = a.bias[n + j];
+    }
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f}, csq = {0.f, 0.f, 0.f, 0.f};
+    const bool want_y = a.bn_y != nullptr, want_a = a.add_src != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.bn_y, want_y ? a.dst_bytes : 0u), rs_a = make_rsrc(a.add_src, want_a ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_ym = make_rsrc(a.bn_mask, a.bn_mask != nullptr ? a.dst_bytes >> 4 : 0u);
+    const __amdgpu_buffer_rsrc_t rs_am = make_rsrc(a.add_mask, a.add_mask != nullptr ? a.dst_bytes >> 4 : 0u);
+    const unsigned ym_all = a.bn_mask != nullptr ? 0u : 0xFu, am_all = a.add_mask != nullptr ? 0u : 0xFu;
+    f32x4 pf_y[4], pf_a[4];
+    unsigned pf_ym[4], pf_am[4];
+    auto pf_issue = [&](int slot, int i) {   // i = 4 r + k: output 2 ct + r, rows 8 k .. 8 k + 7
+      int l_ = lane;
+      asm volatile("" : "+v"(l_));
+      const int pix = rowpix[par * NQ + 8 * (i & 3) + (l_ >> 3)];
+      const bool live = pix >= 0 && nok;
+      const unsigned e = (unsigned)(pix + n + (2 * ct + (i >> 2)) * a.Cd);
+      const int o16 = live ? (int)(e * 4u) : (int)OOB, o1 = live ? (int)(e >> 2) : (int)OOB;
+      pf_y[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, o16, 0, 0));
+      pf_ym[slot] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_ym, o1, 0, 0) | ym_all;
+      pf_a[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, o16, 0, 0));
+      pf_am[slot] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_am, o1, 0, 0) | am_all;
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pf_issue(i, i);
+    f32x4 ep_sc = {1.f, 1.f, 1.f, 1.f}, ep_sh = {0.f, 0.f, 0.f, 0.f};
+    if (a.ep_scale != nullptr && nok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ep_sc[j] = a.ep_scale[n + j]; ep_sh[j] = a.ep_shift[n + j]; }
+    }
+    f32x4 bn_mu = {0.f, 0.f, 0.f, 0.f}, bn_is = {0.f, 0.f, 0.f, 0.f};
+    if (a.bn_y != nullptr && nok) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bn_mu[j] = a.bn_mean[n + j]; bn_is[j] = a.bn_invstd[n + j]; }
+    }
+#pragma unroll
+    for (int r_ = 0; r_ < 2; ++r_) {
+      {
+        int l_ = lane;
+        asm volatile("" : "+v"(l_));
+        float* xw = reinterpret_cast<float*>(xbuf) + hw * 2048 + (4 * (l_ >> 5)) * 32 + (l_ & 31);      // [wave][slot 0: output r | slot 1: output 2 + r][32 rows][32 columns]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2);
+          const float ma = acc[0][r] + sacc[0][r], mb = acc[1][r] + sacc[1][r], mc = acc[2][r] + sacc[2][r];
+          float lo, hi;                    // partial sums of outputs r_ and 2 + r_
+          if (ct == 0) {
+            const float s = mb + mc, d = mb - mc;
+            lo = r_ == 0 ? ma + s : d;
+            hi = r_ == 0 ? s : d;
+          } else {
+            const float s = ma + mb, d = ma - mb;
+            lo = r_ == 0 ? s : 2.f * d;
+            hi = r_ == 0 ? 4.f * s : 8.f * d + mc;
+          }
+          xw[row * 32] = lo;
+          xw[1024 + row * 32] = hi;
+        }
+      }
+      __syncthreads();
+      {
+        int l_ = lane;
+        asm volatile("" : "+v"(l_));
+        const int c4 = (l_ & 7) * 4, rsub = l_ >> 3;
+        // this wave stores output 2 ct + r_ of its column group: slot ct of itself and of the other triple's wave (hw ^ 4)
+        const float* s0 = reinterpret_cast<const float*>(xbuf) + hw * 2048 + ct * 1024;
+        const float* s1 = reinterpret_cast<const float*>(xbuf) + (hw ^ 4) * 2048 + ct * 1024;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int row = 8 * kk + rsub;
+          const int pix = rowpix[par * NQ + row];
+          const f32x4 m = *reinterpret_cast<const f32x4*>(s0 + row * 32 + c4) + *reinterpret_cast<const f32x4*>(s1 + row * 32 + c4);
+          const bool live = pix >= 0 && nok;
+          const unsigned e = (unsigned)(pix + n + (2 * ct + r_) * a.Cd);
+          f32x4 v;
+          const uint32_t keep = a.drop_thresh != 0u ? fs_dropout_keep4((uint32_t)e, a.drop_key, a.drop_thresh) : 15u;      // e is a multiple of 4
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x = m[j] + bv[j];
+            if (a.drop_thresh != 0u) x = ((keep >> j) & 1u) ? x * a.drop_scale : 0.f;
+            v[j] = live ? x : 0.f;
+          }
+          if (a.ep_scale != nullptr && live) {
+            v = v * ep_sc + ep_sh;
+            if (a.ep_res != nullptr) v += *reinterpret_cast<const f32x4*>(a.ep_res + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fs_act(v[j], a.ep_act);
+          }
+          if (want_a && live) {
+            f32x4 r = pf_a[kk];
+            const unsigned mk = pf_am[kk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = ((mk >> j) & 1u) ? r[j] : 0.f;
+            v += r;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
+          if (want_y) {
+            if (live) {
+              const f32x4 yy = pf_y[kk];
+              const unsigned mk = pf_ym[kk];
+              f32x4 gq = v;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) gq[j] = ((mk >> j) & 1u) ? gq[j] : 0.f;
+              csum += gq; csq += gq * ((yy - bn_mu) * bn_is);
+            }
+          } else {
+            csum += v; csq += v * v;
+          }
+          if (r_ == 0) pf_issue(kk, 4 + kk);
+        }
+      }
+      __syncthreads();
+    }
+    if (a.stats != nullptr) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { csum[j] += __shfl_xor(csum[j], o, 64); csq[j] += __shfl_xor(csq[j], o, 64); }
+      if (lane < 8 && nok) {               // slab row = (pixel tile, component triple = output pair): [2 nx][Cd][2]
+        float* dst = a.stats + ((long)(2 * mt + ct) * a.Cd + n) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dst[2 * j] = csum[j]; dst[2 * j + 1] = csq[j]; }
+      }
+    }
+    if (!has_next) break;
+    mt = mt_n; n0 = n0_n; bvoff = bvoff_n;
+    write_rowpix((k + 1) & 1, y0_n, x0_n);
+  }
+}
+
 // Policy (kernel A/B builds read FS_WINO4; the shipped build carries the constant): 0 off, 1 on where eligible
 const int g_wino4 = FS_ENV_INT("FS_WINO4", 1);
 
@@ -492,6 +847,18 @@ void wino4_plan(int B, int H, int W, int& Ph, int& PQ, int& tiles_x, int& nx) {
   }
   tiles_x = cdiv(wq, PQ);
   nx = cdiv(rows, Ph) * tiles_x;
+}
+
+// Which layers take the eight-wave form (profiles/r05/wino48_ab.txt; B = 64, us per call four-wave -> eight-wave): long channel loops whose
+// destination channels fill 128-column tiles -- 256 -> 256 @ 20x20 141 -> 130 (fwd) / 142 -> 134 (bwd-data), 960 -> 240 @ 80x80 5 560 -> 5 285,
+// its bwd-data (240 -> 960: 960 pads to 1 024) 6 560 -> 5 840; a tie at 128 source channels (128 -> 128 @ 40x40 136 / 136), and a loss
+// where 128-column tiles pad the destination by a third (192 -> 192 @ 80x80 980 -> 1 136).
+// FS_WINO48 in kernel A/B builds: 0 never, 1 that rule, 2 every layer above 64 destination channels
+bool wino4_use8(int Cs, int Cd) {
+  static const int pol = FS_ENV_INT("FS_WINO48", 1);
+  if (pol == 0 || Cd <= 64) return false;
+  const int pad64 = (Cd + 63) / 64 * 64, pad128 = (Cd + 127) / 128 * 128;
+  return pol == 2 || (Cs >= 192 && pad128 * 10 <= pad64 * 11);
 }
 
 int wino4_grid_slots() {
@@ -515,19 +882,20 @@ bool fs_wino4_eligible(int mode, int B, int H, int W, int Cs, int Cd) {
   // at 40 images of 160 x 160 x 1024 channels has 129 k of them and stays on the F(2,3) kernels, whose tiles are two to four times larger)
   int Ph, PQ, tx, nx;
   wino4_plan(B, H, W, Ph, PQ, tx, nx);
-  return (long)nx * ((Cd + 63) / 64) < 65536;
+  const int ncol = wino4_use8(Cs, Cd) ? 128 : 64;
+  return (long)nx * ((Cd + ncol - 1) / ncol) < 65536;
 }
 
 long fs_wino4_pack_bytes(int mode, int Cs, int Cd) {
   (void)mode;
-  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 63) / 64) * 64;
+  const long nchunk = (Cs + 31) / 32, Npad = ((Cd + 127) / 128) * 128;        // room for either column tiling
   return HDR + nchunk * 36 * 3 * Npad * 16 * 2;
 }
 
-int fs_wino4_stats_slabs(int B, int H, int W) {
+int fs_wino4_stats_slabs(int B, int H, int W, int Cs, int Cd) {
   int Ph, PQ, tx, nx;
   wino4_plan(B, H, W, Ph, PQ, tx, nx);
-  return nx;
+  return wino4_use8(Cs, Cd) ? 2 * nx : nx;        // the eight-wave kernel writes one row per (pixel tile, output pair)
 }
 
 int fs_wino4_conv3x3(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, int B, int H, int W, int Cs,
@@ -540,10 +908,12 @@ int fs_wino4_conv3x3(int mode, const float* src, const float* w, const float* bi
   a.ep_scale = bn ? bn->ep_scale : nullptr; a.ep_shift = bn ? bn->ep_shift : nullptr; a.ep_res = bn ? bn->ep_res : nullptr; a.ep_act = bn ? bn->ep_act : 0;
   a.src = src; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = dst; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cs = Cs; a.Cd = Cd;
-  a.Npad = ((Cd + 63) / 64) * 64;
+  const bool eight = wino4_use8(Cs, Cd);
+  const int ncol = eight ? 128 : 64;              // columns per workgroup
+  a.Npad = ((Cd + ncol - 1) / ncol) * ncol;
   a.nchunk = (Cs + 31) / 32;
   wino4_plan(B, H, W, a.Ph, a.PQ, a.tiles_x, a.nx);
-  a.ny = a.Npad / 64;
+  a.ny = a.Npad / ncol;
   a.Hv = H + 1;
   a.magic_hv = div_magic(a.Hv);
   a.magic_pq = div_magic(a.PQ);
@@ -568,18 +938,27 @@ int fs_wino4_conv3x3(int mode, const float* src, const float* w, const float* bi
   // 960 -> 240 with the 60 registers it costs, profiles/r05/wino4_ab.txt)
   constexpr int RD = 3;
   constexpr int lds = wino4_lds_bytes<P>();
+  constexpr int lds8 = 2 * XCH_BYTES + 2 * NQ * 4;
   {
     static unsigned long long done = 0ull;            // the dynamic-LDS opt-in is a per-device function attribute
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return FS_ERR_ARG;
     if (dev < 0 || dev >= 64 || !((done >> dev) & 1ull)) {
-      const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel<P, RD>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel<P, RD>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (attr != hipSuccess) return (int)attr;
+      attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino48_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8);
       if (attr != hipSuccess) return (int)attr;
       if (dev >= 0 && dev < 64) done |= 1ull << dev;
     }
   }
   const long ntile = (long)a.nx * a.ny;
   const int slots = wino4_grid_slots();
+  if (eight) {
+    const unsigned grid8 = (unsigned)(ntile < slots / 2 ? ntile : slots / 2);
+    hipLaunchKernelGGL((conv3x3_wino48_kernel<P>), dim3(grid8), dim3(512), lds8, stream, a);
+    FS_LAUNCH_CHECK();
+    return FS_OK;
+  }
   const unsigned grid = (unsigned)(ntile < slots ? ntile : slots);
   hipLaunchKernelGGL((conv3x3_wino4_kernel<P, RD>), dim3(grid), dim3(256), lds, stream, a);
   FS_LAUNCH_CHECK();

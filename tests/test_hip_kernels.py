@@ -2303,15 +2303,21 @@ WINO_CASES = [
     ("bf16x3", 2, 16, 24, 36, 100),     # 6 quads per row, K tail (36 = 32 + 4), N tail
     ("bf16x3", 1, 12, 8, 32, 32),
     ("bf16x3", 3, 7, 28, 64, 48),       # 7 quads per row (prime): ragged tiles in x
+    # ... and its eight-wave form (128-column workgroups, the next chunk's split inside the MFMA phase): > 64 destination channels that
+    # fill 128-column tiles, >= 192 source channels
+    ("bf16x3", 5, 20, 20, 256, 256),
+    ("bf16x3", 2, 40, 40, 288, 200),    # K tail (288 = 9 x 32), N tail (200 of 256)
+    ("bf16x3", 1, 12, 8, 320, 72),      # one tile, 72 of 128 columns
+    ("bf16x3", 2, 16, 24, 192, 240),    # forward eight-wave (192 -> 240), bwd-data four-wave (240 -> 192: 192 pads to 256 in 128-column tiles)
 ]
 
 
 def _wino_choice(mode, W, Cs, Cd):
-    """Kernel-choice code of a 3x3 stride-1 problem that takes the row-transform family: 8 = F(4,3) (bf16x3, W a multiple of 4 from 8 up,
-    except where the eight-wave F(2,3) kernel ties -- more than 64 output and at least 256 input channels on maps up to 20 wide), 5 = F(2,3)."""
+    """Kernel-choice code of a 3x3 stride-1 problem that takes the row-transform family: 8 = F(4,3) (bf16x3, W a multiple of 4 from 8 up;
+    its four- or eight-wave form), 5 = F(2,3)."""
     if os.environ.get("FS_WINO4", "1") == "0" or mode != "bf16x3" or W % 4 or W < 8:
         return 5
-    return 5 if (Cd > 64 and Cs >= 256 and W <= 20) else 8
+    return 8
 
 
 @pytest.mark.parametrize("case", WINO_CASES)

@@ -234,9 +234,9 @@ def test_conv_dispatch_predicate_above_4gb():
             assert small == ((8 if wino_on and mode == 1 else 2) if mode else 1), (mode, small)      # f16x2: from 128 channels up
             wide = lib.fs_conv2d_kernel_choice(64, 40, 40, 128, 40, 40, 128, 3, 3, 1, 1, 1, 0, ws)
             assert wide == (((8 if mode == 1 else 5) if wino_on else 2) if mode else 1), (mode, wide)
-            # two pairs per row, not a whole quad: F(2,3); more than 64 output and >= 256 input channels on a 20-wide map: the eight-wave F(2,3) kernel
+            # five pairs per row, not whole quads: F(2,3); a wide 20-wide layer: F(4,3) as well (its eight-wave form)
             assert lib.fs_conv2d_kernel_choice(64, 10, 10, 64, 10, 10, 64, 3, 3, 1, 1, 1, 0, ws) == ((5 if wino_on and mode == 1 else 2) if mode else 1)
-            assert lib.fs_conv2d_kernel_choice(64, 20, 20, 256, 20, 20, 256, 3, 3, 1, 1, 1, 0, ws) == ((5 if wino_on else 2) if mode else 1)
+            assert lib.fs_conv2d_kernel_choice(64, 20, 20, 256, 20, 20, 256, 3, 3, 1, 1, 1, 0, ws) == (((8 if mode == 1 else 5) if wino_on else 2) if mode else 1)
             odd = lib.fs_conv2d_kernel_choice(64, 81, 81, 64, 81, 81, 64, 3, 3, 1, 1, 1, 0, ws)
             assert odd == (2 if mode else 1), (mode, odd)
             assert lib.fs_conv2d_kernel_choice(2800, 80, 80, 64, 80, 80, 64, 3, 3, 1, 1, 1, 0, ws) == 0       # 4.6 GB source

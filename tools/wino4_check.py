@@ -14,6 +14,7 @@ from fovealseg import ops, hip
 CASES = [  # B, H, W, Cin, Cout
     (2, 80, 80, 64, 64), (3, 40, 40, 128, 128), (5, 20, 20, 256, 256), (2, 80, 80, 192, 24), (2, 16, 24, 36, 100), (1, 12, 8, 32, 16),
     (2, 80, 80, 96, 240),
+    (5, 20, 20, 256, 256), (2, 40, 40, 288, 200), (1, 12, 8, 320, 72), (3, 16, 24, 256, 128),      # eight-wave form: > 64 destination, >= 256 source channels
 ]
 
 
