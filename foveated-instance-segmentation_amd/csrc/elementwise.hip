@@ -392,6 +392,48 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
   }
 }
 
+// g = dout * (out > 0) AND the BatchNorm-backward column sums of up to three conv + BatchNorm layers whose output gradient g IS (round 5: the
+// same-resolution terms of an HRNet fuse row -- the last, activation-free ConvBn of every down-path -- all receive this one tensor): the
+// gradient is in registers here, so each layer's own reduction pass over (g, y) becomes one extra read of its y.  Row / column walk and
+// slab layout of bn_bwd_partial_kernel; sum g is the same for every term and is stored with each.
+struct BnTerms { const float* y[3]; const float* mean[3]; const float* invstd[3]; float* slab[3]; int n; };
+__global__ __launch_bounds__(256)
+void relu_bwd_bnsum_kernel(const float* __restrict__ dout, const float* __restrict__ out, float* __restrict__ g, long M, int C,
+                           int rows_per_block, BnTerms t) {
+  extern __shared__ float red[];
+  RowWalk w(C);
+  const int c = 4 * w.col;
+  f32x4 s = {0, 0, 0, 0}, sx[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  if (w.active()) {
+    f32x4 mu[3], is[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { mu[k][j] = k < t.n ? t.mean[k][c + j] : 0.f; is[k][j] = k < t.n ? t.invstd[k][c + j] : 0.f; }
+    const long rb = (long)blockIdx.x * rows_per_block;
+    long re = rb + rows_per_block; if (re > M) re = M;
+    for (long r = rb + w.r0; r < re; r += w.rpi) {
+      const long o = r * C + c;
+      f32x4 d = *reinterpret_cast<const f32x4*>(dout + o);
+      const f32x4 z = *reinterpret_cast<const f32x4*>(out + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = z[j] > 0.f ? d[j] : 0.f;
+      *reinterpret_cast<f32x4*>(g + o) = d;
+      s += d;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k < t.n) sx[k] += d * ((*reinterpret_cast<const f32x4*>(t.y[k] + o) - mu[k]) * is[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (k < t.n) {                          // (workgroup-uniform)
+      if (k > 0) __syncthreads();           // the previous term's readers of `red` are done
+      bn_slab_store(w, s, sx[k], C, C, t.slab[k], red);
+    }
+  }
+}
+
 // ---- bilinear up-sample into a channel slice of a wider NHWC buffer (final 960-ch concat) ------
 __global__ __launch_bounds__(256) void upsample_slice_fwd_kernel(const float* __restrict__ src, int B, int th, int tw, int C,
                                                                  float* __restrict__ dst, int Ho, int Wo, int Cdst, int coff) {
@@ -445,6 +487,53 @@ __global__ __launch_bounds__(256) void upsample_slice_bwd_kernel(const float* __
     }
     *reinterpret_cast<f32x4*>(dsrc + q * C + c) = acc;
   }
+}
+
+// the same gather with the row / column walk of the BatchNorm kernels, AND the BatchNorm-backward column sums of the layer whose output
+// gradient dsrc is (round 5: the 1x1 ConvBn of an HRNet fuse up-path, which is activation-free): sum d, sum d * xhat into slab[block][C][2]
+__global__ __launch_bounds__(256)
+void upsample_slice_bwd_bnsum_kernel(const float* __restrict__ g, int Ho, int Wo, int Cg, int coff, float* __restrict__ dsrc, int th, int tw,
+                                     int C, long M, int rows_per_block, const float* __restrict__ y, const float* __restrict__ mean,
+                                     const float* __restrict__ invstd, float* __restrict__ slab) {
+  extern __shared__ float red[];
+  RowWalk w(C);
+  const int c = 4 * w.col;
+  const int fy = Ho / th, fx = Wo / tw;
+  f32x4 s = {0, 0, 0, 0}, sx = {0, 0, 0, 0};
+  if (w.active()) {
+    f32x4 mu, is;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; is[j] = invstd[c + j]; }
+    const long rb = (long)blockIdx.x * rows_per_block;
+    long re = rb + rows_per_block; if (re > M) re = M;
+    for (long q = rb + w.r0; q < re; q += w.rpi) {
+      const int qx = (int)(q % tw);
+      const int qy = (int)((q / tw) % th);
+      const int b = (int)(q / ((long)tw * th));
+      f32x4 acc = {0, 0, 0, 0};
+      int y_lo = fy * qy - fy / 2, y_hi = fy * qy + (3 * fy) / 2 - 1;
+      int x_lo = fx * qx - fx / 2, x_hi = fx * qx + (3 * fx) / 2 - 1;
+      if (y_lo < 0) y_lo = 0;
+      if (x_lo < 0) x_lo = 0;
+      if (y_hi > Ho - 1 || qy == th - 1) y_hi = Ho - 1;
+      if (x_hi > Wo - 1 || qx == tw - 1) x_hi = Wo - 1;
+      for (int oy = y_lo; oy <= y_hi; ++oy) {
+        const Lerp Ly = lerp_coord(oy, th, Ho);
+        const float wy = (Ly.i0 == qy ? Ly.l0 : 0.f) + (Ly.i1 == qy ? Ly.l1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = x_lo; ox <= x_hi; ++ox) {
+          const Lerp Lx = lerp_coord(ox, tw, Wo);
+          const float wx = (Lx.i0 == qx ? Lx.l0 : 0.f) + (Lx.i1 == qx ? Lx.l1 : 0.f);
+          if (wx == 0.f) continue;
+          acc += (wy * wx) * *reinterpret_cast<const f32x4*>(g + (((long)b * Ho + oy) * Wo + ox) * Cg + coff + c);
+        }
+      }
+      const long o = q * C + c;
+      *reinterpret_cast<f32x4*>(dsrc + o) = acc;
+      s += acc; sx += acc * ((*reinterpret_cast<const f32x4*>(y + o) - mu) * is);
+    }
+  }
+  bn_slab_store(w, s, sx, C, C, slab, red);
 }
 
 // ---- column sums (bias gradients): per-row-block partials into part[block][C], summed in block order by fs_slab_reduce ----------
@@ -866,6 +955,23 @@ int fs_relu_bwd(const float* dout, const float* out, float* g, long n, hipStream
   return FS_OK;
 }
 
+// include/fovealseg.h: fs_relu_bwd_bnsum -- g = dout * (out > 0) over (M, C) plus, for nterm <= 3 layers, slab_k[fs_bn_bwd_slabs(M, C)][C][2]
+int fs_relu_bwd_bnsum(const float* dout, const float* out, float* g, long M, int C, int nterm, const float* const* y, const float* const* mean,
+                      const float* const* invstd, float* const* slab, hipStream_t stream) {
+  FS_REQUIRE(dout && out && g && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && nterm >= 1 && nterm <= 3 && y && mean && invstd && slab);
+  BnTerms t;
+  t.n = nterm;
+  for (int k = 0; k < 3; ++k) {
+    const bool on = k < nterm;
+    FS_REQUIRE(!on || (y[k] && mean[k] && invstd[k] && slab[k]));
+    t.y[k] = on ? y[k] : nullptr; t.mean[k] = on ? mean[k] : nullptr; t.invstd[k] = on ? invstd[k] : nullptr; t.slab[k] = on ? slab[k] : nullptr;
+  }
+  const int rpb = rows_per_block_for(M, C);
+  hipLaunchKernelGGL(relu_bwd_bnsum_kernel, dim3(fs_bn_bwd_slabs(M, C)), dim3(256), slab_lds_bytes(C), stream, dout, out, g, M, C, rpb, t);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
 int fs_upsample_slice_fwd(const float* src, int B, int th, int tw, int C, float* dst, int Ho, int Wo, int Cdst, int coff,
                           hipStream_t stream) {
   FS_REQUIRE(src && dst && C % 4 == 0 && Cdst % 4 == 0 && coff % 4 == 0 && coff + C <= Cdst && Ho % th == 0 && Wo % tw == 0);
@@ -883,6 +989,19 @@ int fs_upsample_slice_bwd(const float* g, int B, int Ho, int Wo, int Cg, int cof
   const long total = (long)B * th * tw * (C / 4);
   int blocks = cdiv(total, 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(upsample_slice_bwd_kernel, dim3(blocks), dim3(256), 0, stream, g, B, Ho, Wo, Cg, coff, dsrc, th, tw, C);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// include/fovealseg.h: fs_upsample_slice_bwd_bnsum -- fs_upsample_slice_bwd (true up-sampling factors only) plus slab[fs_bn_bwd_slabs(B*th*tw, C)][C][2]
+int fs_upsample_slice_bwd_bnsum(const float* g, int B, int Ho, int Wo, int Cg, int coff, float* dsrc, int th, int tw, int C, const float* y,
+                                const float* mean, const float* invstd, float* slab, hipStream_t stream) {
+  FS_REQUIRE(g && dsrc && y && mean && invstd && slab && C % 4 == 0 && C <= 1024 && Cg % 4 == 0 && coff % 4 == 0 && coff + C <= Cg);
+  FS_REQUIRE(B > 0 && th > 0 && tw > 0 && Ho % th == 0 && Wo % tw == 0 && (Ho / th) % 2 == 0 && (Wo / tw) % 2 == 0);
+  const long M = (long)B * th * tw;
+  const int rpb = rows_per_block_for(M, C);
+  hipLaunchKernelGGL(upsample_slice_bwd_bnsum_kernel, dim3(fs_bn_bwd_slabs(M, C)), dim3(256), slab_lds_bytes(C), stream, g, Ho, Wo, Cg, coff, dsrc,
+                     th, tw, C, M, rpb, y, mean, invstd, slab);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -59,6 +59,8 @@ SIGNATURES = {
     "fs_add_n": "pppppl",
     "fs_upsample_slice_fwd": "piiiipiiii",
     "fs_upsample_slice_bwd": "piiiiipiii",
+    "fs_upsample_slice_bwd_bnsum": "piiiiipiii" + "pppp",
+    "fs_relu_bwd_bnsum": "ppplii" + "pppp",
     "fs_colsum": "plipip",
     "fs_maxpool_fwd": "pppiiiiiiiii",
     "fs_maxpool_bwd": "pppiiiiiiiii",

@@ -411,7 +411,7 @@ def conv2d_bwd_data(dy, w, x_shape, stride, pad, dil=1, w_amax=None, src_bn=None
                     stride, pad, dil, hip.ptr(ws), ws_bytes, hip.ptr(w_amax), hip.ptr(y), hip.ptr(amask), hip.ptr(mean), hip.ptr(invstd),
                     hip.ptr(slab), hip.ptr(a_src), hip.ptr(a_mask))
             if slab is not None:
-                BN_SLABS[dx.data_ptr()] = (slab, rows, dx)
+                BN_SLABS[(dx.data_ptr(), y.data_ptr())] = (slab, rows, dx)
             return dx
     _launch_conv(packed, kind, flops, "fs_conv2d_bwd_data", hip.ptr(dy), hip.ptr(rsck(w)), hip.ptr(dx),
             B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, hip.ptr(ws), ws_bytes, hip.ptr(w_amax))
@@ -632,9 +632,10 @@ def _queue_wgrad_join():
         pass
 
 
-# BatchNorm-backward column sums that the PRODUCER of a gradient tensor already formed (FanOut.backward below):
-# dz.data_ptr() -> (slab, nslab, dz).  The entry keeps dz alive, so its address cannot be reused while the entry exists;
-# ConvBnAct.backward pops it.  Cleared at the start of every module forward.
+# BatchNorm-backward column sums that the PRODUCER of a gradient tensor already formed (FanOut.backward below, the bwd-data epilogue of the
+# consumer conv, HrFuse.backward): (dz.data_ptr(), y.data_ptr()) -> (slab, nslab, dz), y = the conv output of the layer the sums are for
+# (one fuse gradient is the output gradient of up to three layers).  The entry keeps dz alive, so its address cannot be reused while the
+# entry exists; ConvBnAct.backward pops it.  Cleared at the start of every module forward.
 BN_SLABS = {}
 
 
@@ -674,7 +675,7 @@ class FanOut(Function):
                 hip.call("fs_add_n_bnsum", hip.ptr(acc), hip.ptr(take[0]), hip.ptr(take[1]) if len(take) > 1 else None,
                          hip.ptr(take[2]) if len(take) > 2 else None, hip.ptr(out), hip.ptr(amask), hip.ptr(y), hip.ptr(mean),
                          hip.ptr(invstd), M, C, act if amask is not None else ACT_NONE, hip.ptr(slab))
-                BN_SLABS[out.data_ptr()] = (slab, nslab, out)
+                BN_SLABS[(out.data_ptr(), y.data_ptr())] = (slab, nslab, out)
             else:
                 hip.call("fs_add_n", hip.ptr(acc), hip.ptr(take[0]), hip.ptr(take[1]) if len(take) > 1 else None,
                          hip.ptr(take[2]) if len(take) > 2 else None, hip.ptr(out), acc.numel())
@@ -859,7 +860,7 @@ class ConvBnAct(Function):
         dgamma = tg if direct_affine else torch.empty(C, device=y.device, dtype=torch.float32)
         dbeta = tb if direct_affine else torch.empty(C, device=y.device, dtype=torch.float32)
         # BatchNorm backward = column sums (unless the kernel that produced dz already formed them) -> finalize -> apply
-        pre = BN_SLABS.pop(dz.data_ptr(), None)
+        pre = BN_SLABS.pop((dz.data_ptr(), y.data_ptr()), None)
         if pre is not None and pre[2].shape == dz.shape:
             slab, nslab = pre[0], pre[1]
             slab.record_stream(torch.cuda.current_stream())
@@ -973,6 +974,11 @@ class HrFuse(Function):
         hip.call("fs_hr_fuse_fwd", ptrs, th, tw, n, hip.ptr(out), B, Ho, Wo, C, 1)
         ctx.save_for_backward(out)
         ctx.shapes = [tuple(t.shape) for t in terms]
+        # terms that are the output of an activation-free conv + BatchNorm layer (the last ConvBn of every fuse path): their output gradient
+        # IS this node's gradient (up-sampled back for the lower-resolution ones), so backward forms their BatchNorm-backward sums as it
+        # produces that gradient (round 5; before, each of them ran its own reduction pass over it: 62 of the 91 left in an HRNet step)
+        ctx.bns = [(bn if (bn is not None and bn[4] == ACT_NONE and bn[1] is None and tuple(bn[0].shape) == tuple(t.shape) and t.shape[-1] <= 1024) else None)
+                   for t, bn in ((t, getattr(t, "_fs_bn", None)) for t in terms)] if FUSE_BN_BWD_SUMS else [None] * n
         return out
 
     @staticmethod
@@ -980,8 +986,19 @@ class HrFuse(Function):
         (out,) = ctx.saved_tensors
         dout = dout.contiguous()
         g = torch.empty_like(out)
-        hip.call("fs_relu_bwd", hip.ptr(dout), hip.ptr(out), hip.ptr(g), out.numel())
         B, Ho, Wo, C = out.shape
+        same = [i for i, shp in enumerate(ctx.shapes) if ctx.needs_input_grad[2 + i] and shp[1] == Ho and shp[2] == Wo and ctx.bns[i] is not None][:3]
+        if same:
+            M = B * Ho * Wo
+            nslab = hip.bn_bwd_slabs(M, C)
+            slabs = [torch.empty(nslab * C * 2, device=out.device, dtype=torch.float32) for _ in same]
+            arr = lambda xs: (ctypes.c_void_p * len(xs))(*[hip.ptr(x) for x in xs])      # noqa: E731
+            hip.call("fs_relu_bwd_bnsum", hip.ptr(dout), hip.ptr(out), hip.ptr(g), M, C, len(same), arr([ctx.bns[i][0] for i in same]),
+                     arr([ctx.bns[i][2] for i in same]), arr([ctx.bns[i][3] for i in same]), arr(slabs))
+            for i, slab in zip(same, slabs):
+                BN_SLABS[(g.data_ptr(), ctx.bns[i][0].data_ptr())] = (slab, nslab, g)
+        else:
+            hip.call("fs_relu_bwd", hip.ptr(dout), hip.ptr(out), hip.ptr(g), out.numel())
         grads = []
         for i, shp in enumerate(ctx.shapes):
             if not ctx.needs_input_grad[2 + i]:
@@ -990,7 +1007,16 @@ class HrFuse(Function):
                 grads.append(g)
             else:
                 d = torch.empty(shp, device=out.device, dtype=torch.float32)
-                hip.call("fs_upsample_slice_bwd", hip.ptr(g), B, Ho, Wo, C, 0, hip.ptr(d), shp[1], shp[2], C)
+                bn = ctx.bns[i]
+                if bn is not None and (Ho // shp[1]) % 2 == 0 and (Wo // shp[2]) % 2 == 0:
+                    y, _, mean, invstd, _ = bn
+                    nslab = hip.bn_bwd_slabs(B * shp[1] * shp[2], C)
+                    slab = torch.empty(nslab * C * 2, device=out.device, dtype=torch.float32)
+                    hip.call("fs_upsample_slice_bwd_bnsum", hip.ptr(g), B, Ho, Wo, C, 0, hip.ptr(d), shp[1], shp[2], C, hip.ptr(y), hip.ptr(mean),
+                             hip.ptr(invstd), hip.ptr(slab))
+                    BN_SLABS[(d.data_ptr(), y.data_ptr())] = (slab, nslab, d)
+                else:
+                    hip.call("fs_upsample_slice_bwd", hip.ptr(g), B, Ho, Wo, C, 0, hip.ptr(d), shp[1], shp[2], C)
                 grads.append(d)
         return (None, None, *grads)
 

@@ -269,6 +269,17 @@ int fs_upsample_slice_fwd(const float* src, int B, int th, int tw, int C, float*
                           fs_stream_t stream);
 int fs_upsample_slice_bwd(const float* g, int B, int Ho, int Wo, int Cg, int coff, float* dsrc, int th, int tw, int C,
                           fs_stream_t stream);
+/* Round 5: the two producers of an HRNet fuse row's gradients also form the BatchNorm-backward column sums of the layers that receive them
+ * (models/hrnetv2_nodownsp.py:179-252: the last ConvBn of every fuse path has no activation, so its output gradient IS the fuse gradient):
+ *   fs_relu_bwd_bnsum: g = dout * (out > 0) over (M rows, C channels, C <= 1024) and, for nterm <= 3 layers k with conv output y[k] and batch
+ *     statistics mean[k] / invstd[k], slab[k][fs_bn_bwd_slabs(M, C)][C][2] = per-row-block (sum g, sum g * xhat_k) -- the input of fs_bn_bwd_finalize.
+ *     y / mean / invstd / slab are HOST arrays of nterm device pointers.
+ *   fs_upsample_slice_bwd_bnsum: fs_upsample_slice_bwd (even up-sampling factors) plus slab[fs_bn_bwd_slabs(B*th*tw, C)][C][2] of the layer
+ *     whose output gradient dsrc is. */
+int fs_relu_bwd_bnsum(const float* dout, const float* out, float* g, long M, int C, int nterm, const float* const* y, const float* const* mean,
+                      const float* const* invstd, float* const* slab, fs_stream_t stream);
+int fs_upsample_slice_bwd_bnsum(const float* g, int B, int Ho, int Wo, int Cg, int coff, float* dsrc, int th, int tw, int C, const float* y,
+                                const float* mean, const float* invstd, float* slab, fs_stream_t stream);
 /* column sums of M rows of C floats (bias gradients); accumulate != 0: ADDED to out (a gradient-arena target), else overwritten.
  * scratch = fs_colsum_scratch_floats(M, C) floats (per-row-block partial sums, added in block order). */
 long fs_colsum_scratch_floats(long M, int C);

@@ -2433,6 +2433,67 @@ def test_bn_backward_sums_from_the_gradient_producer(C, hw, act_last):
         assert float((a - b).abs().max()) <= 2e-5 * scale          # same sums, different summation order (and bwd-weight atomics)
 
 
+@pytest.mark.parametrize("chans,hw", [((32, 64), 16), ((32, 64, 128), 16), ((16, 32, 64, 128), 24)])
+def test_fuse_row_gradients_carry_the_batchnorm_sums_of_their_layers(chans, hw):
+    """Round 5: the last ConvBn of every HRNet fuse path has no activation, so the fuse node's backward produces its output
+    gradient directly -- the ReLU-masked fuse gradient for the down-paths (ONE tensor shared by up to three layers), its up-sampling adjoint
+    for the 1x1 up-paths -- and now forms those layers' BatchNorm-backward column sums in the same launches (fs_relu_bwd_bnsum,
+    fs_upsample_slice_bwd_bnsum).  Same gradients as with every layer on its own reduction pass; none of those passes left for the fuse layers."""
+    from fovealseg import modules as Mods
+    torch.manual_seed(sum(chans) + hw)
+    saved = Mods.PARALLEL_BRANCHES
+    Mods.PARALLEL_BRANCHES = False
+    mod = Mods.HighResolutionModule(list(chans)).to(DEV)
+    Mods._assign_paths(mod, "t")
+    mod.train()
+    with torch.no_grad():
+        for m in mod.modules():
+            if isinstance(m, Mods.HipBatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0.0, 0.3)
+    n = len(chans)
+    xs0 = [torch.randn(2, hw >> i, hw >> i, c, device=DEV) for i, c in enumerate(chans)]
+    cots = [torch.randn(2, hw >> i, hw >> i, c, device=DEV) for i, c in enumerate(chans)]
+    ops.DropoutState.seed, ops.DropoutState.step = 5, 2
+
+    def run(fused):
+        ops.FUSE_BN_BWD_SUMS = fused
+        ops.reset_step_state()
+        mod.zero_grad()
+        xs = [x.clone().requires_grad_(True) for x in xs0]
+        outs = mod(xs)
+        loss = sum((o * c).sum() for o, c in zip(outs, cots))
+        calls = []
+        orig = fovealseg.hip.call
+
+        def spy(name, *a):
+            calls.append(name)
+            return orig(name, *a)
+        fovealseg.hip.call = spy
+        try:
+            loss.backward()
+        finally:
+            fovealseg.hip.call = orig
+        return [x.grad.clone() for x in xs] + [p.grad.clone() for p in mod.parameters()], calls
+    try:
+        g_fused, calls_fused = run(True)
+        g_plain, calls_plain = run(False)
+    finally:
+        ops.FUSE_BN_BWD_SUMS = True
+        Mods.PARALLEL_BRANCHES = saved
+    downs = n * (n - 1) // 2                       # fuse terms j < i: one activation-free last ConvBn each
+    ups = n * (n - 1) // 2                         # fuse terms j > i: one 1x1 ConvBn each
+    assert calls_fused.count("fs_upsample_slice_bwd_bnsum") == ups and calls_fused.count("fs_upsample_slice_bwd") == 0
+    assert calls_fused.count("fs_relu_bwd_bnsum") == n - 1 and calls_fused.count("fs_relu_bwd") == 1       # row 0 has no down-path
+    assert calls_plain.count("fs_relu_bwd") == n and calls_plain.count("fs_upsample_slice_bwd") == ups
+    # the fuse layers' own reduction passes are gone (the plain run has one per BatchNorm layer of the module)
+    assert calls_plain.count("fs_bn_bwd_partial") - calls_fused.count("fs_bn_bwd_partial") >= downs + ups
+    assert not ops.BN_SLABS and not ops.PENDING_RES
+    for a, b in zip(g_fused, g_plain):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-5 * scale
+
+
 def test_residual_consumer_independent_of_the_conv_consumer_keeps_its_gradient():
     """a two-way fan-out whose conv alias feeds an F(2,3)-eligible 3x3 conv and whose other alias is the `res` of a layer that
     does NOT depend on that conv is unordered in the backward.  The residual layer must then materialise its gradient (never stash it for an
