@@ -586,9 +586,11 @@ def _wgrad_stream_obj(raw):
 
 
 def _wgrad_retire(raw, keep):
-    """The kept tensors of side stream `raw` may be dropped once everything enqueued there so far has run: remember them under an event."""
+    """The kept tensors of side stream `raw` may be dropped once everything enqueued there so far has run: remember them under an event.
+    (Under stream capture nothing runs and an event cannot be queried; the caller drops the list at the join instead -- every node
+    captured behind the join is ordered behind the side launches, and the graph's private pool keeps the addresses for its replays.)"""
     st = _wgrad_stream_obj(raw)
-    if st is None or not keep:
+    if st is None or not keep or torch.cuda.is_current_stream_capturing():
         return
     ev = torch.cuda.Event()
     ev.record(st)
@@ -596,7 +598,7 @@ def _wgrad_retire(raw, keep):
 
 
 def _wgrad_reap():
-    if _WGRAD_RETIRED:
+    if _WGRAD_RETIRED and not torch.cuda.is_current_stream_capturing():
         _WGRAD_RETIRED[:] = [(ev, keep) for ev, keep in _WGRAD_RETIRED if not ev.query()]
 
 
@@ -887,13 +889,18 @@ class ConvBnAct(Function):
         src_bn = ctx.src_bn if ctx.fan is None else (ctx.fan[1] if pend is not None else None)
         if not WGRAD_FIRST:
             dx = conv2d_bwd_data(dy, w, x.shape, m["stride"], m["pad"], m["dil"], w_amax=ctx.w_amax, src_bn=src_bn, addend=pend) if ctx.needs_input_grad[0] else None
-        if tgt is not None and 2.0 * M * C * w.shape[1] * w.shape[2] * w.shape[3] < WGRAD_SIDE_FLOPS and TIMER is None:
+        # (not under stream capture: forking the side stream into a capture once per layer and joining it once at the end ends in a host
+        #  segmentation fault inside hipStreamEndCapture on ROCm 7.2 -- tools/probes/graph_probe.py, profiles/r05/graph_probe.txt)
+        if (tgt is not None and 2.0 * M * C * w.shape[1] * w.shape[2] * w.shape[3] < WGRAD_SIDE_FLOPS and TIMER is None
+                and not torch.cuda.is_current_stream_capturing()):
             side = _wgrad_side_stream(dy.device)
             _queue_wgrad_join()                       # backward() returns with its stream ordered behind the side stream
             hip.stream_wait(side, hip._stream())      # dy (and x) were produced on the current stream
             keep = _WGRAD_SIDE_BUSY.setdefault(side, [])
-            if len(keep) >= _WGRAD_ROTATE:            # a long backward (configs[4]: every layer is small) does not hold on to all of its
-                _wgrad_retire(side, keep)             # activations and gradients: lists retire under an event and go when it has completed
+            if len(keep) >= _WGRAD_ROTATE and not torch.cuda.is_current_stream_capturing():
+                # a long backward (configs[4]: every layer is small) does not hold on to all of its activations and gradients: lists
+                # retire under an event and go when it has completed
+                _wgrad_retire(side, keep)
                 keep = _WGRAD_SIDE_BUSY[side] = []
                 _wgrad_reap()
             keep.append((x, dy))

@@ -20,7 +20,7 @@ echo "[profiles] traffic done"
 cd $R
 export FS_CONV_PRECISION=bf16x3
 mkdir -p $O/pmc
-for spec in "fwd 0 conv3x3_wino4_kernel" "fwd 1 conv3x3_wino4_kernel" "fwd 2 conv3x3_wino8_kernel" "fwd 3 conv3x3_wino8_kernel" "wgrad 0 conv_wgrad_class_kernel" "fwd 7 conv_s2fwd_kernel" "bwd_data 7 conv_s2bwd_kernel" \
+for spec in "fwd 0 conv3x3_wino4_kernel" "fwd 1 conv3x3_wino4_kernel" "fwd 2 conv3x3_wino48_kernel" "fwd 3 conv3x3_wino8_kernel" "wgrad 0 conv_wgrad_class_kernel" "fwd 7 conv_s2fwd_kernel" "bwd_data 7 conv_s2bwd_kernel" \
             "fwd 13 conv_s2fwd_kernel" "bwd_data 13 conv_s2bwd_kernel" "wgrad 12 conv_wgrad_planes_kernel" "wgrad 9 linear_wgrad_kernel"; do
   set -- $spec
   bash tools/pmc_conv.sh $1 $2 $3 > $O/pmc/sq_bf16x3_$3_$1_shape$2.txt 2>&1
