@@ -1363,15 +1363,18 @@ int fs_conv2d_pack(const float* w, int B, int H, int W, int Cin, int Ho, int Wo,
 // this shape when called with ws_bytes of scratch (depends on which kernel it selects).
 int fs_conv2d_stats_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                           long ws_bytes) {
-  const long need = fs_conv2d_workspace_bytes(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0);
-  if (need > 0 && ws_bytes >= need) {
-    const bool halo = H == Ho && W == Wo && fs_halo_eligible(H, W, Cin, Cout, R, S, stride, pad, dil);
-    if (halo && fs_wino_eligible(g_conv_precision, B, Ho, Wo, Cin, Cout)) return fs_wino_stats_slabs(g_conv_precision, B, Ho, Wo, Cin, Cout);
-    if (halo) return fs_halo_stats_slabs(B, Ho, Wo);
-    if (g_s2fwd && fs_s2fwd_eligible(H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil)) return fs_s2fwd_slabs(B, Ho, Wo);
-    if (tapset_shape_ok(Cin, Cout, R, S, stride, dil)) return fs_tapset_slabs(B, Ho, Wo, (R + stride - 1) / stride, (S + stride - 1) / stride);
+  // the SAME predicates, in the same order, as the dispatch of fs_conv2d_fwd_stats (launch_affine): a count derived from eligibility alone
+  // would describe another kernel's slab layout whenever a dispatch condition (precision mode, 4 GB bounds, scratch size) fails
+  ConvArgs c{nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0, 1.f, 0u, 0u};
+  c.ws_ = ws_bytes > 0 ? (void*)&c : nullptr;
+  c.ws_bytes_ = ws_bytes;
+  if (aligned_ok(c)) {
+    if (use_s2fwd(c)) return fs_s2fwd_slabs(B, Ho, Wo);
+    if (use_tapset(c) && !use_halo(c)) return fs_tapset_slabs(B, Ho, Wo, (R + stride - 1) / stride, (S + stride - 1) / stride);
+    if (use_wino(c)) return fs_wino_stats_slabs(g_conv_precision, B, Ho, Wo, Cin, Cout);
+    if (use_halo(c)) return fs_halo_stats_slabs(B, Ho, Wo);
   }
-  return cdiv((long)B * Ho * Wo, 128);
+  return cdiv((long)B * Ho * Wo, 128);      // the 1x1 GEMM kernels, the plain aligned kernel and the generic one: one slab per 128 rows
 }
 
 // include/fovealseg.h: fs_conv2d_fwd

@@ -4,6 +4,7 @@ There is NO fallback: if the library is missing or a launch is rejected the call
 used only for device memory (tensor.data_ptr()) and the current HIP stream.
 """
 import ctypes
+import threading
 import os
 
 import torch
@@ -332,7 +333,21 @@ def _stream():
 _fn_cache = {}
 
 
-STREAM_OVERRIDE = None      # a raw stream handle: launches go there instead of torch's current stream (ops: side-stream weight gradients)
+# A raw stream handle: the calling THREAD's launches go there instead of torch's current stream (ops: side-stream weight gradients, the
+# weight-pack prefetch).  Per thread (round 5): a ctypes call releases the GIL, so a second launching thread -- a prefetch thread, a
+# serving worker -- must never see another thread's override.
+_tls = threading.local()
+
+
+def stream_override():
+    return getattr(_tls, "stream", None)
+
+
+def set_stream_override(handle):
+    """Route this thread's launches to `handle` (None: back to torch's current stream); returns the previous value."""
+    old = getattr(_tls, "stream", None)
+    _tls.stream = handle
+    return old
 
 
 def stream_wait(waiter, signaller):
@@ -354,12 +369,13 @@ def call_packed(name, *args):
 
 
 def call(name, *args):
-    """Launch `name` on torch's current HIP stream (or STREAM_OVERRIDE); raises on any non-zero status."""
+    """Launch `name` on torch's current HIP stream (or this thread's stream override); raises on any non-zero status."""
     fn = _fn_cache.get(name)
     if fn is None:
         lib = _lib if _lib is not None else load()
         fn = _fn_cache[name] = getattr(lib, name)
-    err = fn(*args, STREAM_OVERRIDE if STREAM_OVERRIDE is not None else _stream())
+    so = getattr(_tls, "stream", None)
+    err = fn(*args, so if so is not None else _stream())
     if err != 0:
         what = "argument rejected at the C-ABI boundary" if err == 1001 else f"hipError {err}"
         raise HipLibraryError(f"{name}: {what}")

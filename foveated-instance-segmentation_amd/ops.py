@@ -248,13 +248,14 @@ def _pack_for(w, device, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, tra
         e.cell, e.epoch, e.version, e.group, e.stream, e.ready = cell, -1, -1, None, None, set()
         _PACK_ORDER.append(weakref.ref(e))
     e.used = True
-    cur = hip.STREAM_OVERRIDE if hip.STREAM_OVERRIDE is not None else hip._stream()
+    so = hip.stream_override()
+    cur = so if so is not None else hip._stream()
     if (e.cell is cell and e.epoch == cell[0] and e.version == w._version):
         if cur not in e.ready:          # first use on this stream since the pack was enqueued: order the stream behind it
             g = e.group
             if g is not None:
                 if cur not in g.waited:
-                    # the wait goes on `cur`, the stream the launch uses (which is STREAM_OVERRIDE when that is set), not on torch's
+                    # the wait goes on `cur`, the stream the launch uses (which is the thread's stream override when that is set), not on torch's
                     # current stream
                     (torch.cuda.current_stream() if cur == hip._stream() else torch.cuda.ExternalStream(cur)).wait_event(g.event)
                     g.waited.add(cur)
@@ -321,7 +322,7 @@ def repack_weights():
         side = _PACK_SIDE[dev.index] = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream())          # the optimiser step (and the arena's max|w| refresh) come first
     raw = side.cuda_stream
-    hip.STREAM_OVERRIDE = raw
+    hip.set_stream_override(raw)
     try:
         group = _PackGroup()
         for i, (e, w, cell) in enumerate(todo):
@@ -332,7 +333,7 @@ def repack_weights():
                 group.event.record(side)
                 group = _PackGroup()
     finally:
-        hip.STREAM_OVERRIDE = None
+        hip.set_stream_override(None)
 
 
 def _launch_conv(packed, kind, flops, name, *args):
@@ -904,11 +905,11 @@ class ConvBnAct(Function):
                 keep = _WGRAD_SIDE_BUSY[side] = []
                 _wgrad_reap()
             keep.append((x, dy))
-            hip.STREAM_OVERRIDE = side
+            hip.set_stream_override(side)
             try:
                 conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"], accumulate=True, keep=keep)
             finally:
-                hip.STREAM_OVERRIDE = None
+                hip.set_stream_override(None)
             dw = None
         else:
             dw = conv2d_bwd_weight(x, dy, w.shape, m["stride"], m["pad"], out=tgt, dil=m["dil"], accumulate=tgt is not None)
