@@ -113,6 +113,7 @@ def _batch_to_space(y, d):
 
 
 PARALLEL_BRANCHES = True
+PARALLEL_FUSE = os.environ.get("FS_PARALLEL_FUSE", "1") != "0"      # fuse rows on the branch streams too (A/B switch, read once)
 _SIDE = {}
 
 
@@ -294,14 +295,39 @@ class HighResolutionModule(nn.Module):
             outs[i].record_stream(main)
         return outs
 
+    def _fuse_row(self, i, fan, xs):
+        n = len(self.chans)
+        terms = [fan[j][i] if j == i else self.fuse_layers[i][j](fan[j][i]) for j in range(n)]
+        return ops.HrFuse.apply(xs[i].shape[1], xs[i].shape[2], *terms)
+
     def forward(self, xs):
         n = len(self.chans)
         xs = self._run_branches(xs)
         fan = [ops.fan_out(xs[j], n) for j in range(n)]        # every branch output is read by all n fuse rows
+        if PARALLEL_BRANCHES and PARALLEL_FUSE and xs[0].is_cuda and ops.ACT_TRACE is None:
+            # Round 5: the n fuse rows are independent of each other as well (row i: its up-path 1x1 convs, its stride-2 down chains, one
+            # HrFuse), and most of their launches are small (20x20 / 10x10 maps, BatchNorm finalize kernels): row i runs on the side
+            # stream branch i ran on -- the stream the NEXT module's branch i will take its input on -- and the backward follows.
+            main = torch.cuda.current_stream()
+            side = _side_streams(xs[0].device, n - 1)
+            fork = torch.cuda.Event()
+            fork.record(main)                                   # behind the fan-out aliases (views: no launch) and _run_branches' joins
+            outs = [None] * n
+            for i in range(1, n):
+                s = side[i - 1]
+                s.wait_event(fork)
+                for j in range(n):
+                    fan[j][i].record_stream(s)
+                with torch.cuda.stream(s):
+                    outs[i] = self._fuse_row(i, fan, xs)
+            outs[0] = self._fuse_row(0, fan, xs)
+            for i in range(1, n):
+                main.wait_stream(side[i - 1])
+                outs[i].record_stream(main)
+            return outs
         outs = []
         for i in range(n):
-            terms = [fan[j][i] if j == i else self.fuse_layers[i][j](fan[j][i]) for j in range(n)]
-            outs.append(ops.HrFuse.apply(xs[i].shape[1], xs[i].shape[2], *terms))
+            outs.append(self._fuse_row(i, fan, xs))
             if ops.ACT_TRACE is not None:
                 ops.ACT_TRACE.append(((self, i), ACT_RELU, outs[-1]))
         return outs
