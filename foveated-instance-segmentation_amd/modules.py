@@ -114,6 +114,7 @@ def _batch_to_space(y, d):
 
 PARALLEL_BRANCHES = True
 PARALLEL_FUSE = os.environ.get("FS_PARALLEL_FUSE", "1") != "0"      # fuse rows on the branch streams too (A/B switch, read once)
+STREAM_DEPS = os.environ.get("FS_STREAM_DEPS", "1") != "0"          # modules of a stage chained stream by stream, one join per stage (A/B switch)
 _SIDE = {}
 
 
@@ -332,6 +333,64 @@ class HighResolutionModule(nn.Module):
                 ops.ACT_TRACE.append(((self, i), ACT_RELU, outs[-1]))
         return outs
 
+    def forward_deps(self, xs, ready, defer):
+        """forward() with the stream dependencies spelled out instead of two joins on the main stream per module (round 5).  Stream of index
+        i: the main stream for i = 0, side stream i - 1 otherwise; branch i, row i and the NEXT module's branch i all run on stream i.
+        `ready[i]` (or None): xs[i] is complete on stream i only (the previous module of the stage deferred its join) -- branch i, on the
+        same stream, needs no wait then.  Between branches and rows the dependency is all-to-all (every row reads every branch): stream i
+        waits for the end-of-branch events of the other streams.  defer: return (outs, per-stream readiness) without joining the main stream."""
+        n = len(self.chans)
+        main = torch.cuda.current_stream()
+        side = _side_streams(xs[0].device, n - 1)
+        streams = [main] + list(side)
+        fork = None
+        bouts, bdone = [None] * n, [None] * n
+        for i in range(n - 1, -1, -1):               # side streams first, the main stream's branch last (as _run_branches issues them)
+            s = streams[i]
+            if i > 0 and (ready is None or ready[i] is None):
+                if fork is None:
+                    fork = torch.cuda.Event()
+                    fork.record(main)
+                s.wait_event(fork)
+                xs[i].record_stream(s)
+            with torch.cuda.stream(s):
+                bouts[i] = self.branches[i](xs[i])
+                bdone[i] = torch.cuda.Event()
+                bdone[i].record(s)
+        fan = [ops.fan_out(bouts[j], n) for j in range(n)]
+        outs, rdone = [None] * n, [None] * n
+        for i in range(n - 1, -1, -1):
+            s = streams[i]
+            for j in range(n):
+                if j != i:
+                    s.wait_event(bdone[j])
+                    fan[j][i].record_stream(s)
+            with torch.cuda.stream(s):
+                outs[i] = self._fuse_row(i, fan, bouts)
+                if defer and i > 0:
+                    rdone[i] = torch.cuda.Event()
+                    rdone[i].record(s)
+        if defer:
+            return outs, rdone
+        for i in range(1, n):
+            main.wait_stream(side[i - 1])
+            outs[i].record_stream(main)
+        return outs, None
+
+
+class _Stage(_Chain):
+    """The modules of one HRNet stage (reference child names '0', '1', ...).  With the branch streams on, consecutive modules are chained
+    stream by stream: row i of module k and branch i of module k + 1 run on the same side stream, so nothing but the last module of the
+    stage joins the main stream (HighResolutionModule.forward_deps)."""
+
+    def forward(self, xs):
+        if not (PARALLEL_BRANCHES and PARALLEL_FUSE and STREAM_DEPS and xs[0].is_cuda and ops.ACT_TRACE is None) or len(self) < 2:
+            return super().forward(xs)
+        ready = None
+        for k, m in enumerate(self):
+            xs, ready = m.forward_deps(xs, ready, defer=k + 1 < len(self))
+        return xs
+
 
 class HRNetV2(nn.Module):
     WIDTHS = (64, 128, 256, 512)
@@ -348,9 +407,9 @@ class HRNetV2(nn.Module):
         self.transition1 = nn.ModuleList([_ConvBn(256, W[0], 3, 1, True), _Chain(_ConvBn(256, W[1], 3, 2, True))])
         self.stage2 = _Chain(*[HighResolutionModule(W[:2]) for _ in range(1)])
         self.transition2 = nn.ModuleList([None, None, _Chain(_ConvBn(W[1], W[2], 3, 2, True))])
-        self.stage3 = _Chain(*[HighResolutionModule(W[:3]) for _ in range(4)])
+        self.stage3 = _Stage(*[HighResolutionModule(W[:3]) for _ in range(4)])
         self.transition3 = nn.ModuleList([None, None, None, _Chain(_ConvBn(W[2], W[3], 3, 2, True))])
-        self.stage4 = _Chain(*[HighResolutionModule(W[:4]) for _ in range(3)])
+        self.stage4 = _Stage(*[HighResolutionModule(W[:4]) for _ in range(3)])
         _assign_paths(self)
 
     def forward_nhwc(self, x):

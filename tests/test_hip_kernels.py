@@ -2494,6 +2494,43 @@ def test_fuse_row_gradients_carry_the_batchnorm_sums_of_their_layers(chans, hw):
         assert float((a - b).abs().max()) <= 2e-5 * scale
 
 
+def test_branch_and_row_streams_do_not_change_the_encoder():
+    """Round 5: the fuse rows of a HighResolutionModule run on the branch streams, and the modules of a stage are chained stream by stream
+    (one join per stage instead of two per module).  Stream placement must not change a bit: the whole HRNetV2 encoder forward and, in
+    deterministic mode, every parameter gradient are identical with the streams off, with the rows on the branch streams and with the
+    stage-level chaining on top -- run twice each, so that a missing dependency (a race) would have two chances to show."""
+    from fovealseg import modules as Mods
+    H = fovealseg.hip
+    torch.manual_seed(21)
+    enc = fovealseg.ModelBuilder.build_encoder("hrnetv2_nodownsp", 960, "").to(DEV)
+    enc.train()
+    x0 = torch.randn(2, 64, 64, 3, device=DEV)
+    saved = (Mods.PARALLEL_BRANCHES, Mods.PARALLEL_FUSE, Mods.STREAM_DEPS)
+    H.set_deterministic(True)
+
+    def run(branches, fuse, deps):
+        Mods.PARALLEL_BRANCHES, Mods.PARALLEL_FUSE, Mods.STREAM_DEPS = branches, fuse, deps
+        ops.reset_step_state()
+        ops.DropoutState.seed, ops.DropoutState.step = 4, 9
+        enc.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        feat = enc.forward_nhwc(x)
+        (feat * feat).sum().backward()
+        torch.cuda.synchronize()
+        return feat.detach().clone(), x.grad.clone(), [p.grad.clone() for p in enc.parameters()]
+    try:
+        ref = run(False, False, False)
+        for cfg in ((True, False, False), (True, True, False), (True, True, True), (True, True, True)):
+            got = run(*cfg)
+            assert torch.equal(got[0], ref[0]), cfg
+            assert torch.equal(got[1], ref[1]), cfg
+            for a, b in zip(got[2], ref[2]):
+                assert torch.equal(a, b), cfg
+    finally:
+        Mods.PARALLEL_BRANCHES, Mods.PARALLEL_FUSE, Mods.STREAM_DEPS = saved
+        H.set_deterministic(False)
+
+
 def test_residual_consumer_independent_of_the_conv_consumer_keeps_its_gradient():
     """a two-way fan-out whose conv alias feeds an F(2,3)-eligible 3x3 conv and whose other alias is the `res` of a layer that
     does NOT depend on that conv is unordered in the backward.  The residual layer must then materialise its gradient (never stash it for an
