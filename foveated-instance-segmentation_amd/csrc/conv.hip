@@ -1100,6 +1100,17 @@ int launch_tapset_forward(const ConvArgs& c) {
   return run_tapset(p, c.stream_);
 }
 
+// bwd-data extras (BatchNorm-backward sums / addend) outside the 3x3 stride-1 family: the kernel launch_affine reaches for this problem is
+// the 1x1 GEMM or the one-launch stride-2 kernel (round 5).  Same predicates, same order as the dispatch below.
+bool bnsum_beyond_wino(const ConvArgs& c) {
+  if (!c.transposed || use_s2fwd(c)) return false;
+  if (c.stride == 1 && use_tapset(c) && !use_halo(c)) return false;
+  if (use_wino(c) || use_halo(c)) return false;
+  if (use_pointwise(c)) return true;
+  if (use_pw_gather(c) || c.stride == 1) return false;
+  return use_s2bwd(c);
+}
+
 int launch_affine(const ConvArgs& c, long M) {
   AffArgs a{c.src, c.w, c.bias, c.dst, c.B, c.Hs, c.Ws, c.Cs, c.Hd, c.Wd, c.Cd, c.R, c.S, c.stride, c.pad, c.dil, c.transposed,
             c.drop_scale, c.drop_thresh, c.drop_key,
@@ -1122,7 +1133,7 @@ int launch_affine(const ConvArgs& c, long M) {
   if (use_wino(c))
     return fs_wino_conv3x3(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cs, c.Cd,
                            c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key, c.bn_, c.stream_);
-  if (c.bn_ != nullptr) return FS_ERR_ARG;        // the caller asked for fused sums on a shape fs_conv2d_bwd_data_bnsum_slabs reported 0 for
+  if (c.bn_ != nullptr && !bnsum_beyond_wino(c)) return FS_ERR_ARG;        // the caller asked for fused sums on a shape fs_conv2d_bwd_data_bnsum_slabs reported 0 for
   if (use_halo(c))
     return fs_halo_conv3x3(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cs, c.Cd,
                            c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key,
@@ -1130,14 +1141,14 @@ int launch_affine(const ConvArgs& c, long M) {
   if (use_pointwise(c))
     return fs_pointwise_conv(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, (long)c.B * c.Hd * c.Wd, c.Cs, c.Cd,
                              c.transposed ? c.Cd : c.Cs, c.transposed ? c.Cs : c.Cd, c.transposed, c.drop_scale, c.drop_thresh, c.drop_key,
-                             c.stream_);
+                             c.bn_, c.stream_);
   if (use_pw_gather(c))
     return fs_pointwise_gather_conv(g_conv_precision, c.src, c.w, c.bias, c.dst, c.stats_, c.ws_, c.w_amax_, c.B, c.Hs, c.Ws, c.Cs, c.Hd, c.Wd, c.Cd,
                                     c.R, c.S, c.stride, c.pad, c.drop_scale, c.drop_thresh, c.drop_key, c.stream_);
   if ((!c.transposed || c.stride == 1) && fs_ws_mode_tls != 0) return FS_ERR_ARG;      // the plain kernel has no weight pack
   if (!c.transposed || c.stride == 1) return launch_affine_one(a);
   if (use_s2bwd(c))
-    return fs_s2bwd_conv(g_conv_precision, c.src, c.w, c.dst, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cd, c.Hs, c.Ws, c.Cs, c.stream_);
+    return fs_s2bwd_conv(g_conv_precision, c.src, c.w, c.dst, c.ws_, c.w_amax_, c.B, c.Hd, c.Wd, c.Cd, c.Hs, c.Ws, c.Cs, c.bn_, c.stats_, c.stream_);
   // stride>1 bwd-data: one dense sub-problem per output parity class (oy0, ox0).  dX pixel y receives
   // tap r iff (y + pad - r) % stride == 0, i.e. r = r0 + stride*t with r0 = (oy0 + pad) % stride, and then
   // reads dY row (y + pad - r)/stride = py + (oy0 + pad - r0)/stride - t.
@@ -1485,7 +1496,9 @@ int fs_conv2d_bwd_data_bnsum_slabs(int B, int H, int W, int Cin, int Ho, int Wo,
   ConvArgs a{nullptr, nullptr, nullptr, nullptr, B, Ho, Wo, Cout, H, W, Cin, R, S, stride, pad, dil, 1, 1.f, 0u, 0u};
   static unsigned char dummy;
   a.ws_ = ws_bytes > 0 ? &dummy : nullptr; a.ws_bytes_ = ws_bytes;
-  if (!aligned_ok(a) || (use_tapset(a) && !use_halo(a)) || !use_wino(a)) return 0;
+  if (!aligned_ok(a)) return 0;
+  if (bnsum_beyond_wino(a)) return use_pointwise(a) ? fs_pointwise_stats_slabs((long)B * H * W) : fs_s2bwd_stats_slabs(B, Ho, Wo);
+  if ((use_tapset(a) && !use_halo(a)) || !use_wino(a)) return 0;
   return fs_wino_stats_slabs(g_conv_precision, B, H, W, Cout, Cin);      // bwd-data: source channels = Cout, destination = Cin
 }
 

@@ -66,9 +66,11 @@ bool fs_pointwise_scatter_eligible(int Cin, int Cout, int R, int S, int stride, 
 int fs_pointwise_scatter_conv(int mode, const float* dy, const float* w, float* dx, void* ws, const unsigned* w_amax, int B, int H, int W,
                               int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, hipStream_t stream);
 // M = B*H*W rows; transposed = 1: bwd-data (src = dY with Cs = Cout channels, dst = dX with Cd = Cin).  stats: [ceil(M/128)][Cd][2] or null.
+// bn (bwd-data only, may be null): stats then receives the BatchNorm-backward sums of the layer that produced x, and / or a second gradient joins dst
 int fs_pointwise_conv(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
                       long M, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,
-                      hipStream_t stream);
+                      const FsBnSums* bn, hipStream_t stream);
+int fs_pointwise_stats_slabs(long M);
 
 // ---- deterministic split-K (include/fovealseg.h fs_set_deterministic) ----------------------------------------------------------
 // Every bwd-weight kernel ends by adding its workgroup's partial dW tile to the tiles of the other pixel splits.  By default that is an
@@ -106,8 +108,10 @@ int fs_wgrad_split(int mode, const float* x, const float* dy, float* dw, int B, 
 // ---- conv_s2bwd.hip: bwd-data of a 3x3 / stride 2 / pad 1 convolution, the four output parities in one launch ----
 bool fs_s2bwd_eligible(int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil);
 long fs_s2bwd_pack_bytes(int mode, int Cin, int Cout);
+// bn (may be null): slab[fs_s2bwd_stats_slabs][Cin][2] receives the BatchNorm-backward sums of the layer that produced x, and / or a second gradient joins dX
+int fs_s2bwd_stats_slabs(int B, int Ho, int Wo);
 int fs_s2bwd_conv(int mode, const float* dy, const float* w, float* dx, void* ws, const unsigned* w_amax, int B, int H, int W, int Cin, int Ho,
-                  int Wo, int Cout, hipStream_t stream);
+                  int Wo, int Cout, const FsBnSums* bn, float* slab, hipStream_t stream);
 
 // ---- conv_s2fwd.hip: forward of a 3x3 / stride 2 / pad 1 convolution, the four input parity planes in one LDS refill per chunk ----
 bool fs_s2fwd_eligible(int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil);

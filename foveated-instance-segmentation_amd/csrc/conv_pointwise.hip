@@ -39,6 +39,10 @@ struct PwArgs {
   // (Ho, Wo above; rows past the real grid read zeros) is written to dX pixel (oy * sc_st + sc_dy, ox * sc_st + sc_dx) when that is inside
   // sc_H x sc_W: every pixel of the tap's residue class is written exactly once, the classes no tap reaches are zero-filled by the caller.
   int sc_on, sc_st, sc_dy, sc_dx, sc_H, sc_W;
+  // bwd-data extras (round 5; plain rows only): BatchNorm-backward column sums of the layer whose output gradient dst is -- stats then holds
+  // (sum dz, sum dz * zhat) with dz = dst masked by that layer's activation bits -- and a second gradient added to dst in the same epilogue
+  const float* bn_y; const unsigned char* bn_mask; const float* bn_mean; const float* bn_invstd;
+  const float* add_src; const unsigned char* add_mask;
 };
 
 // Wp[g = 2 * chunk + s][plane][n][j] = plane-th term of Wt[k = 32 * chunk + 16 * s + j][n] (scaled by 2^(14-Ew) in f16x2), behind a
@@ -75,9 +79,10 @@ __global__ __launch_bounds__(256) void conv1x1_pack_kernel(const float* __restri
 // DB (bf16x3, kernel A/B builds only -- measured slower, see run_pointwise): the two LDS chunk images are a double buffer -- while the
 // MFMAs of 32-channel chunk c run on one image, chunk c + 1 (loaded one round earlier) is split and stored into the other, half of it
 // behind each k16 step; ONE barrier per chunk instead of load -> barrier -> split + store -> barrier -> MFMAs per pair of chunks.
-template <class P, int NW, bool DB>
+template <class P, int NW, bool DB, bool BN = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(PwArgs a) {
   static_assert(!DB || !P::SCALED, "the double-buffered loop has no running-exponent step");
+  static_assert(!(DB && BN), "the bwd-data extras live in the shipped loop only");
   typedef typename P::x8 X8;
   typedef typename P::x4 X4;
   constexpr int NPL = P::NPL;
@@ -373,6 +378,66 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(PwArgs a) {
     __syncthreads();
   }
   float csum[NW], csq[NW];
+  if constexpr (BN) {
+    // The extras' operands sit at the addresses of the stores (lane = column, register = row): one group of 8 rows (half of tile mi of sub-tile
+    // j) is requested while the group before it is stored, so a round trip is covered by 8 stores instead of standing in front of each.
+    // An absent operand gets a zero-size descriptor: its loads return 0 without touching memory (the window stays branch-free).
+    const bool want_y = a.bn_y != nullptr, want_a = a.add_src != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.bn_y, want_y ? a.dst_bytes : 0u), rs_a = make_rsrc(a.add_src, want_a ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_ym = make_rsrc(a.bn_mask, a.bn_mask != nullptr ? a.dst_bytes >> 4 : 0u);
+    const __amdgpu_buffer_rsrc_t rs_am = make_rsrc(a.add_mask, a.add_mask != nullptr ? a.dst_bytes >> 4 : 0u);
+    const unsigned ym_all = a.bn_mask != nullptr ? 0u : 0xFu, am_all = a.add_mask != nullptr ? 0u : 0xFu;
+    float yv[2][8], av[2][8];
+    unsigned ymv[2][8], amv[2][8];
+    auto element = [&](int g, int k, unsigned& e) -> bool {            // group g = (sub-tile j, tile mi, row half): 8 accumulator rows
+      const int j = g >> 2, mi = (g >> 1) & 1, r = 8 * (g & 1) + k;
+      const int n = n0 + 64 * j + 32 * wn + l31;
+      const int trow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const long row = m0 + 64 * wm + 32 * mi + row_perm(trow);
+      e = (unsigned)(row * a.Cd + n);
+      return row < a.M && n < a.Cd;
+    };
+    auto issue = [&](int g, int slot) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        unsigned e;
+        const bool live = element(g, k, e);
+        const int o4 = live ? (int)(e * 4u) : (int)OOB, o1 = live ? (int)(e >> 2) : (int)OOB;
+        yv[slot][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_y, o4, 0, 0));
+        ymv[slot][k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_ym, o1, 0, 0) | ym_all;
+        av[slot][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, o4, 0, 0));
+        amv[slot][k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_am, o1, 0, 0) | am_all;
+      }
+    };
+    issue(0, 0);
+#pragma unroll
+    for (int g = 0; g < 4 * NW; ++g) {
+      const int j = g >> 2, mi = (g >> 1) & 1, slot = g & 1;
+      if (g + 1 < 4 * NW) issue(g + 1, slot ^ 1);
+      const int n = n0 + 64 * j + 32 * wn + l31;
+      const bool nok = n < a.Cd;
+      if ((g & 3) == 0) { csum[j] = 0.f; csq[j] = 0.f; }
+      const float bv = (a.bias != nullptr && nok) ? a.bias[n] : 0.f;
+      const float mu = (want_y && nok) ? a.bn_mean[n] : 0.f, is = (want_y && nok) ? a.bn_invstd[n] : 0.f;
+      const unsigned bit = (unsigned)(n & 3);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = 8 * (g & 1) + k;
+        unsigned e;
+        const bool live = element(g, k, e);
+        float v = P::SCALED ? fmaf(acc[mi][j][r] * f2, f1, bv) : acc[mi][j][r] + bv;
+        if (want_a) v += ((amv[slot][k] >> bit) & 1u) ? av[slot][k] : 0.f;
+        v = live ? v : 0.f;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
+        if (want_y) {
+          const float dz = ((ymv[slot][k] >> bit) & 1u) ? v : 0.f;
+          csum[j] += dz; csq[j] += dz * ((yv[slot][k] - mu) * is);
+        } else {
+          csum[j] += v; csq[j] += v * v;
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
     csum[j] = 0.f; csq[j] = 0.f;
@@ -396,6 +461,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(PwArgs a) {
         csum[j] += v; csq[j] += v * v;
       }
     }
+  }
   }
   if (a.stats != nullptr) {
     float* red = reinterpret_cast<float*>(&Ah[0]);     // [wm][64*NW cols][2]; the operand images are dead since the barrier above
@@ -444,6 +510,12 @@ static int run_pointwise(PwArgs& a, const float* w, void* ws, const unsigned* w_
     }
   }
 #endif
+  if (a.bn_y != nullptr || a.add_src != nullptr) {
+    if (nw == 2) hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 2, false, true>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 1, false, true>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+    FS_LAUNCH_CHECK();
+    return FS_OK;
+  }
   if (nw == 2) hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 2, false>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((conv1x1_gemm_kernel<P, 1, false>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
@@ -462,11 +534,17 @@ long fs_pointwise_pack_bytes(int mode, int Cs, int Cd) {
   return HDR + nchunk * 2 * npl * Npad * 16 * 2;
 }
 
+// rows of the [rows][Cd][2] slab the epilogue's column sums go to: one per 128-row tile
+int fs_pointwise_stats_slabs(long M) { return (int)cdiv(M, ROWS); }
+
 int fs_pointwise_conv(int mode, const float* src, const float* w, const float* bias, float* dst, float* stats, void* ws, const unsigned* w_amax,
                       long M, int Cs, int Cd, int Cin, int Cout, int transposed, float drop_scale, uint32_t drop_thresh, uint32_t drop_key,
-                      hipStream_t stream) {
+                      const FsBnSums* bn, hipStream_t stream) {
   PwArgs a;
   a.src = src; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = dst; a.stats = stats;
+  if (bn != nullptr && (!transposed || (bn->y != nullptr && stats == nullptr))) return FS_ERR_ARG;
+  a.bn_y = bn ? bn->y : nullptr; a.bn_mask = bn ? bn->mask : nullptr; a.bn_mean = bn ? bn->mean : nullptr; a.bn_invstd = bn ? bn->invstd : nullptr;
+  a.add_src = bn ? bn->add_src : nullptr; a.add_mask = bn ? bn->add_mask : nullptr;
   a.M = M; a.Cs = Cs; a.Cd = Cd;
   const int nwp = pw_nw(Cd);
   a.Npad = ((Cd + 64 * nwp - 1) / (64 * nwp)) * 64 * nwp;
@@ -511,6 +589,7 @@ int fs_pointwise_gather_conv(int mode, const float* x, const float* w, const flo
   PwArgs a;
   const int K = R * S * Cin;
   a.src = x; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = y; a.stats = stats;
+  a.bn_y = nullptr; a.bn_mask = nullptr; a.bn_mean = nullptr; a.bn_invstd = nullptr; a.add_src = nullptr; a.add_mask = nullptr;
   a.M = (long)B * Ho * Wo; a.Cs = K; a.Cd = Cout;
   const int nwp = pw_nw(Cout);
   a.Npad = ((Cout + 64 * nwp - 1) / (64 * nwp)) * 64 * nwp;
@@ -549,6 +628,7 @@ int fs_pointwise_scatter_conv(int mode, const float* dy, const float* w, float* 
       if (He <= 0 || We <= 0) continue;
       PwArgs a;
       a.src = dy; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = nullptr; a.dst = dx; a.stats = nullptr;
+      a.bn_y = nullptr; a.bn_mask = nullptr; a.bn_mean = nullptr; a.bn_invstd = nullptr; a.add_src = nullptr; a.add_mask = nullptr;
       a.M = (long)B * He * We; a.Cs = Cout; a.Cd = Cin;
       const int nwp = pw_nw(Cin);
       a.Npad = ((Cin + 64 * nwp - 1) / (64 * nwp)) * 64 * nwp;

@@ -38,6 +38,10 @@ struct S2Args {
   int Ph, Pw, tiles_y, tiles_x, nx, ny;
   unsigned src_bytes, wp_bytes, dst_bytes;
   unsigned magic_pw, magic_wh;
+  // extras (round 5): BatchNorm-backward column sums of the layer whose output gradient dX is (stats[tile][Cd][2] = sum dz, sum dz * zhat,
+  // dz = dX masked by that layer's activation bits) and a second gradient added to dX in the same epilogue
+  const float* bn_y; const unsigned char* bn_mask; const float* bn_mean; const float* bn_invstd;
+  const float* add_src; const unsigned char* add_mask; float* stats;
 };
 
 // Wp[g = 2 * (chunk * 9 + t) + s2][plane][n][j] = plane-th term of W[r_t][s_t][n][k = 32 chunk + 16 s2 + j]   (w is [R][S][Cin][Cout]:
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_s2bwd_pack_kernel(const float* __res
   }
 }
 
-template <class P>
+template <class P, bool BN = false>
 __global__ __launch_bounds__(256, 2) void conv_s2bwd_kernel(S2Args a) {
   typedef typename P::x8 X8;
   typedef typename P::x4 X4;
@@ -262,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2bwd_kernel(S2Args a) {
       f2 = one ? 1.f : pow2f(Ew - 14);
     }
     const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
+    if constexpr (!BN) {
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const i32x4 pix = *reinterpret_cast<const i32x4*>(&rowpix[32 * wm + 8 * rg + 4 * lh]);
@@ -277,6 +282,79 @@ __global__ __launch_bounds__(256, 2) void conv_s2bwd_kernel(S2Args a) {
           const float v = P::SCALED ? acc[c][r] * f2 * f1 : acc[c][r];
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
         }
+      }
+    }
+    }
+  }
+  if constexpr (BN) {
+    // lane = column, (tile row, parity) = register: the extras' operands sit at the addresses of the stores.  One group of two tile rows x
+    // four parities is requested while the group before it is stored; an absent operand gets a zero-size descriptor (loads return 0).
+    const bool nok = n < a.Cd;
+    float f1 = 1.f, f2 = 1.f;
+    if (P::SCALED) {
+      const int Ew = exponent_of_bits(*a.ew);
+      const int es = E + Ew - 28;
+      const bool one = es >= -126 && es <= 127;
+      f1 = one ? pow2f(es) : pow2f(E - 14);
+      f2 = one ? 1.f : pow2f(Ew - 14);
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(a.dst, a.dst_bytes);
+    const bool want_y = a.bn_y != nullptr, want_a = a.add_src != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.bn_y, want_y ? a.dst_bytes : 0u), rs_a = make_rsrc(a.add_src, want_a ? a.dst_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t rs_ym = make_rsrc(a.bn_mask, a.bn_mask != nullptr ? a.dst_bytes >> 4 : 0u);
+    const __amdgpu_buffer_rsrc_t rs_am = make_rsrc(a.add_mask, a.add_mask != nullptr ? a.dst_bytes >> 4 : 0u);
+    const unsigned ym_all = a.bn_mask != nullptr ? 0u : 0xFu, am_all = a.add_mask != nullptr ? 0u : 0xFu;
+    const float mu = (want_y && nok) ? a.bn_mean[n] : 0.f, is = (want_y && nok) ? a.bn_invstd[n] : 0.f;
+    const unsigned bit = (unsigned)(n & 3);
+    float yv[2][8], av[2][8];
+    unsigned ymv[2][8], amv[2][8];
+    auto element = [&](int g, int k, unsigned& e) -> bool {          // group g = (row group rg, row pair): k = 4 (ri & 1) + parity c
+      const int rg = g >> 1, ri = 2 * (g & 1) + (k >> 2), c = k & 3, a_ = c >> 1, b_ = c & 1;
+      const int row = 32 * wm + 8 * rg + 4 * lh + ri;
+      const int pix = rowpix[row], flg = rowflag[row];
+      e = (unsigned)(pix + a_ * a.Wd + b_) * (unsigned)a.Cd + (unsigned)n;
+      return nok && pix >= 0 && (a_ == 0 || (flg & 1)) && (b_ == 0 || (flg & 2));
+    };
+    auto issue = [&](int g, int slot) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        unsigned e;
+        const bool live = element(g, k, e);
+        const int o4 = live ? (int)(e * 4u) : (int)OOB, o1 = live ? (int)(e >> 2) : (int)OOB;
+        yv[slot][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_y, o4, 0, 0));
+        ymv[slot][k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_ym, o1, 0, 0) | ym_all;
+        av[slot][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, o4, 0, 0));
+        amv[slot][k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_am, o1, 0, 0) | am_all;
+      }
+    };
+    float csum = 0.f, csq = 0.f;
+    issue(0, 0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int slot = g & 1;
+      if (g + 1 < 8) issue(g + 1, slot ^ 1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = 4 * (g >> 1) + 2 * (g & 1) + (k >> 2), c = k & 3;
+        unsigned e;
+        const bool live = element(g, k, e);
+        float v = P::SCALED ? acc[c][r] * f2 * f1 : acc[c][r];
+        if (want_a) v += ((amv[slot][k] >> bit) & 1u) ? av[slot][k] : 0.f;
+        v = live ? v : 0.f;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
+        const float dz = ((ymv[slot][k] >> bit) & 1u) ? v : 0.f;
+        csum += dz; csq += dz * ((yv[slot][k] - mu) * is);
+      }
+    }
+    if (a.stats != nullptr) {
+      // the wave's 32 tile rows: lanes l and l ^ 32 hold the two row halves of a column; the two pixel halves (wm) meet in LDS
+      csum += __shfl_xor(csum, 32, 64); csq += __shfl_xor(csq, 32, 64);
+      float* red = reinterpret_cast<float*>(&Ah[0]);       // [wm][64 columns][2]; the halo image is dead since the barrier behind the loop
+      if (lh == 0) { red[(wm * 64 + 32 * wn + l31) * 2] = csum; red[(wm * 64 + 32 * wn + l31) * 2 + 1] = csq; }
+      __syncthreads();
+      if (tid < 128) {
+        const int col = tid >> 1, which = tid & 1;
+        if (n0 + col < a.Cd) a.stats[((long)mt * a.Cd + n0 + col) * 2 + which] = red[col * 2 + which] + red[(64 + col) * 2 + which];
       }
     }
   }
@@ -307,7 +385,8 @@ int run_s2bwd(S2Args& a, const float* w, void* ws, const unsigned* w_amax, int C
     FS_LAUNCH_CHECK();
   }
   if (fs_ws_mode_tls == FS_WS_PACK_ONLY) return FS_OK;
-  hipLaunchKernelGGL((conv_s2bwd_kernel<P>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+  if (a.bn_y != nullptr || a.add_src != nullptr) hipLaunchKernelGGL((conv_s2bwd_kernel<P, true>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv_s2bwd_kernel<P, false>), dim3((unsigned)(a.nx * a.ny)), dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }
@@ -325,9 +404,19 @@ long fs_s2bwd_pack_bytes(int mode, int Cin, int Cout) {
 }
 
 // dX (B,H,W,Cin) of a 3x3 / stride 2 / pad 1 convolution from dY (B,Ho,Wo,Cout); every element of dX is written
+// rows of the [rows][Cin][2] slab the extras' column sums go to: one per patch of the q grid
+int fs_s2bwd_stats_slabs(int B, int Ho, int Wo) {
+  int Ph, Pw;
+  s2bwd_patch(Ho, Wo, &Ph, &Pw);
+  return B * cdiv(Ho, Ph) * cdiv(Wo, Pw);
+}
+
 int fs_s2bwd_conv(int mode, const float* dy, const float* w, float* dx, void* ws, const unsigned* w_amax, int B, int H, int W, int Cin, int Ho,
-                  int Wo, int Cout, hipStream_t stream) {
+                  int Wo, int Cout, const FsBnSums* bn, float* slab, hipStream_t stream) {
   S2Args a;
+  if (bn != nullptr && bn->y != nullptr && slab == nullptr) return FS_ERR_ARG;
+  a.bn_y = bn ? bn->y : nullptr; a.bn_mask = bn ? bn->mask : nullptr; a.bn_mean = bn ? bn->mean : nullptr; a.bn_invstd = bn ? bn->invstd : nullptr;
+  a.add_src = bn ? bn->add_src : nullptr; a.add_mask = bn ? bn->add_mask : nullptr; a.stats = (bn != nullptr && bn->y != nullptr) ? slab : nullptr;
   a.src = dy; a.ws = reinterpret_cast<const unsigned char*>(ws); a.dst = dx;
   a.B = B; a.Hs = Ho; a.Ws = Wo; a.Cs = Cout; a.Hd = H; a.Wd = W; a.Cd = Cin;
   a.Npad = ((Cin + 63) / 64) * 64;

@@ -192,7 +192,9 @@ int fs_conv2d_bwd_data(const float* dy, const float* w, float* dx, int B, int H,
  * activation bits (1 byte per 4 channels, NULL = unmasked) -- so autograd's add at the block input disappears as well (bn_y may be NULL
  * when only the addend is wanted).
  * fs_conv2d_bwd_data_bnsum_slabs (host only) gives the slab's row count, or 0 when the kernel this shape runs on cannot form the sums
- * (then call fs_conv2d_bwd_data + fs_bn_bwd_partial). */
+ * (then call fs_conv2d_bwd_data + fs_bn_bwd_partial).  Kernels that can: the 3x3 stride-1 row-transform family (round 3), and since
+ * round 5 the 1x1 GEMM kernel (hrnetv2_nodownsp.py:96-103: conv2 -> bn2 -> relu -> conv3 of a Bottleneck) and the one-launch 3x3 /
+ * stride-2 kernel (hrnetv2_nodownsp.py:160-176: the first convolution of a two-step fuse down-path). */
 int fs_conv2d_bwd_data_bnsum_slabs(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
                                    long ws_bytes);
 int fs_conv2d_bwd_data_bnsum(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R,

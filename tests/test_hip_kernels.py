@@ -2433,6 +2433,130 @@ def test_bn_backward_sums_from_the_gradient_producer(C, hw, act_last):
         assert float((a - b).abs().max()) <= 2e-5 * scale          # same sums, different summation order (and bwd-weight atomics)
 
 
+BNSUM_EPILOGUE_CASES = [
+    # kind, B, H, W, Cin, Cout, mask, addend
+    ("1x1", 2, 20, 20, 64, 256, True, False),        # HRNet layer1 conv3's bwd-data -> bn2 (64-column workgroups)
+    ("1x1", 3, 9, 7, 128, 64, True, True),           # 128-column workgroups, ragged last row tile, residual addend
+    ("1x1", 1, 5, 5, 36, 32, False, False),          # ragged columns, BatchNorm without activation bits
+    ("s2", 2, 20, 20, 64, 64, True, False),          # fuse down-path 0 -> 2, second convolution
+    ("s2", 3, 13, 9, 128, 256, True, True),          # odd sizes: the last dX row / column has no parity-1 partner
+    ("s2", 1, 6, 6, 36, 16, False, False),
+]
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("case", BNSUM_EPILOGUE_CASES)
+def test_bwd_data_epilogue_sums_on_the_pointwise_and_stride2_kernels(case, mode):
+    """Round 5: the 1x1 GEMM kernel and the one-launch 3x3 / stride-2 bwd-data kernel form the BatchNorm-backward column
+    sums of the layer that produced x in their epilogue (and take a second gradient there), like the 3x3 stride-1 kernels since round 3.
+    Against the same entry point without the extras: dX (+ the masked addend) bit for bit, the slab rows add up to sum dz and
+    sum dz * zhat with dz = dX masked by the activation bits."""
+    kind, B, H, W, Cin, Cout, with_mask, with_add = case
+    fovealseg.hip.set_conv_precision(mode)
+    try:
+        g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin)
+        R, stride, pad = (1, 1, 0) if kind == "1x1" else (3, 2, 1)
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+        w = rsck_param(torch.randn(Cout, Cin, R, R, generator=g) / (R * Cin ** 0.5))
+        dy = torch.randn(B, Ho, Wo, Cout, generator=g).to(DEV)
+        y = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+        mean = torch.randn(Cin, generator=g).to(DEV) * 0.1
+        invstd = (torch.rand(Cin, generator=g) + 0.5).to(DEV)
+        bits = (torch.rand(B, H, W, Cin, generator=g) < 0.6).to(DEV)
+        weights = (1 << torch.arange(4, device=DEV, dtype=torch.int32))
+        amask = (bits.view(-1, 4).to(torch.int32) * weights).sum(1).to(torch.uint8) if with_mask else None
+        add = torch.randn(B, H, W, Cin, generator=g).to(DEV) if with_add else None
+        abits = (torch.rand(B, H, W, Cin, generator=g) < 0.5).to(DEV)
+        add_mask = (abits.view(-1, 4).to(torch.int32) * weights).sum(1).to(torch.uint8) if with_add else None
+        ws = fovealseg.hip.conv_workspace_bytes(H, W, Cin, Ho, Wo, Cout, R, R, stride, pad, 1, 1)
+        rows = fovealseg.hip.bwd_data_bnsum_slabs(B, H, W, Cin, Ho, Wo, Cout, R, R, stride, pad, 1, ws)
+        assert rows > 0
+        plain = ops.conv2d_bwd_data(dy, w, (B, H, W, Cin), stride, pad)
+        ops.BN_SLABS.clear()
+        calls = []
+        orig = fovealseg.hip.call
+
+        def spy(name, *a):
+            calls.append(name)
+            return orig(name, *a)
+        fovealseg.hip.call = spy
+        try:
+            dx = ops.conv2d_bwd_data(dy, w, (B, H, W, Cin), stride, pad, src_bn=(y, amask, mean, invstd, 1 if with_mask else 0),
+                                     addend=(add, add_mask) if with_add else None)
+        finally:
+            fovealseg.hip.call = orig
+        assert calls.count("fs_conv2d_bwd_data_bnsum") == 1 and calls.count("fs_conv2d_bwd_data") == 0
+        want = plain + (add * abits if with_add else 0.0)
+        assert torch.equal(dx, want) if not with_add else float((dx - want).abs().max()) <= 1e-6 * float(want.abs().max())
+        slab, nrows, owner = ops.BN_SLABS.pop((dx.data_ptr(), y.data_ptr()))
+        assert nrows == rows and owner is dx and not ops.BN_SLABS
+        sums = slab.view(rows, Cin, 2).double().sum(0)
+        dz = (dx * bits if with_mask else dx).double().reshape(-1, Cin)
+        zhat = ((y - mean) * invstd).double().reshape(-1, Cin)
+        s1, s2 = dz.sum(0), (dz * zhat).sum(0)
+        assert float((sums[:, 0] - s1).abs().max()) <= 2e-5 * float(dz.abs().sum(0).max())
+        assert float((sums[:, 1] - s2).abs().max()) <= 2e-5 * float((dz * zhat).abs().sum(0).max())
+    finally:
+        fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
+        ops.BN_SLABS.clear()
+
+
+@pytest.mark.parametrize("kind,hw", [("bottleneck", 12), ("down_path", 16), ("down_path", 13)])
+def test_bottleneck_and_down_path_sums_come_from_the_bwd_data_kernels(kind, hw):
+    """Round 5: the layers whose output gradient leaves a 1x1 or a 3x3 / stride-2 bwd-data kernel (HRNet layer1's conv2 -> conv3, the first
+    convolution of a two-step fuse down-path) no longer run their own BatchNorm reduction pass.  Same gradients either way."""
+    from fovealseg import modules as Mods
+    torch.manual_seed(hw)
+    if kind == "bottleneck":
+        net = Mods.Bottleneck(64, 32, True).to(DEV)
+        x0 = torch.randn(2, hw, hw, 64, device=DEV)
+        fused_partials, plain_partials = 2, 4          # bn3 and the shortcut's BatchNorm get their gradient from the loss / bn3's apply pass
+    else:
+        net = Mods._Chain(Mods._ConvBn(32, 32, 3, 2, True), Mods._ConvBn(32, 64, 3, 2, False)).to(DEV)
+        x0 = torch.randn(2, hw, hw, 32, device=DEV)
+        fused_partials, plain_partials = 1, 2
+    net.train()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, Mods.HipBatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0.0, 0.3)
+    cot = None
+
+    def run(fused):
+        nonlocal cot
+        ops.FUSE_BN_BWD_SUMS = fused
+        ops.reset_step_state()
+        net.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        out = net(x)
+        if cot is None:
+            cot = torch.randn_like(out)
+        calls = []
+        orig = fovealseg.hip.call
+
+        def spy(name, *a):
+            calls.append(name)
+            return orig(name, *a)
+        fovealseg.hip.call = spy
+        try:
+            (out * cot).sum().backward()
+        finally:
+            fovealseg.hip.call = orig
+        return [x.grad.clone()] + [p.grad.clone() for p in net.parameters()], calls
+    try:
+        g_fused, calls_fused = run(True)
+        g_plain, calls_plain = run(False)
+    finally:
+        ops.FUSE_BN_BWD_SUMS = True
+    assert calls_plain.count("fs_bn_bwd_partial") == plain_partials and calls_plain.count("fs_conv2d_bwd_data_bnsum") == 0
+    assert calls_fused.count("fs_bn_bwd_partial") == fused_partials
+    assert calls_fused.count("fs_conv2d_bwd_data_bnsum") == plain_partials - fused_partials
+    assert not ops.BN_SLABS and not ops.PENDING_RES
+    for a, b in zip(g_fused, g_plain):
+        assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-30)
+
+
 @pytest.mark.parametrize("chans,hw", [((32, 64), 16), ((32, 64, 128), 16), ((16, 32, 64, 128), 24)])
 def test_fuse_row_gradients_carry_the_batchnorm_sums_of_their_layers(chans, hw):
     """Round 5: the last ConvBn of every HRNet fuse path has no activation, so the fuse node's backward produces its output

@@ -29,10 +29,14 @@ def main():
 
             def wrapped(ctx, *g, _orig=orig, _n=name):
                 out = _orig(ctx, *g)
+                meta = getattr(ctx, "meta", None)
                 for t in (out if isinstance(out, tuple) else (out,)):
                     if isinstance(t, torch.Tensor) and not hasattr(t, "_fs_src"):
                         try:
                             t._fs_src = _n
+                            if isinstance(meta, dict) and _n == "ConvBnAct":
+                                wsh = tuple(ctx.saved_tensors[1].shape)
+                                t._fs_src_meta = "w%s stride %d fan %s" % (wsh, meta.get("stride", 0), ctx.fan is not None)
                         except Exception:
                             pass
                 return out
@@ -41,6 +45,7 @@ def main():
     bytes_ = collections.Counter()
     real = H.call
     cur = {}
+    layers = []
 
     def spy(name, *args):
         if name == "fs_bn_bwd_partial":
@@ -48,6 +53,7 @@ def main():
             small = [a for a in ints if a < (1 << 31)]
             seen[cur.get("src", "?")] += 1
             bytes_[cur.get("src", "?")] += small[-3] * small[-2] * 4 if len(small) >= 3 else 0
+            layers.append((cur.get("src", "?"), small[-3] if len(small) >= 3 else 0, small[-2] if len(small) >= 3 else 0, cur.get("consumer", "?")))
         return real(name, *args)
 
     H.call = spy
@@ -56,12 +62,15 @@ def main():
 
     def cba_wrapped(ctx, dz, *rest):
         cur["src"] = getattr(dz, "_fs_src", "autograd-sum/unknown")
+        cur["consumer"] = getattr(dz, "_fs_src_meta", "?")
         return cba(ctx, dz, *rest)
     ops.ConvBnAct.backward = staticmethod(cba_wrapped)
     T.train_step(module, opts, data, cfg, epoch=1, cur_iter=1)
     torch.cuda.synchronize()
     for k, n in seen.most_common():
         print(f"{n:4d} layers  {bytes_[k] / 2 ** 20:9.1f} MB of dz  produced by {k}")
+    for src, M, C, cons in layers:
+        print(f"    {src:16s} M = {M:8d} C = {C:4d}  {M * C * 4 / 2 ** 20:7.1f} MB   producer conv: {cons}")
 
 
 if __name__ == "__main__":
