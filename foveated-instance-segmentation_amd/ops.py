@@ -1483,6 +1483,7 @@ class Unfold(Function):
 
 
 UNFOLD_BIG_FILTERS = os.environ.get("FS_UNFOLD_CONV", "1") != "0"
+PATCHIFY_DIRECT = os.environ.get("FS_PATCHIFY_DIRECT", "1") != "0"
 
 
 def conv_bias_any(x, w, bias, stride, pad):
@@ -1494,6 +1495,11 @@ def conv_bias_any(x, w, bias, stride, pad):
     # do not overlap, the unfold is a pure permutation, and the alternative is one single-tap launch per filter tap and pass (configs[3]:
     # 312 conv_igemm_split launches per step, 13.7 ms; round 4)
     patchify = r > 1 and stride == r and pad == 0
+    # ... unless the library's own stride >= filter route takes them (<= 9 taps, Cin a multiple of 64, Cout of 64: the 2x2 reduction of the
+    # Mix-Transformer's 40-block stage): the 1x1 GEMM kernel gathers the patch rows itself, its bwd-data scatters them, bwd-weight reads
+    # them in place -- no unfold / fold passes and no patch matrix kept for the backward
+    if patchify and PATCHIFY_DIRECT and r * s <= 9 and cin % 64 == 0 and cout % 64 == 0:
+        patchify = False
     if (not UNFOLD_BIG_FILTERS or r != s or (r * s <= 32 and not patchify) or hip.get_conv_precision() != "bf16x3" or cout % 4 or cout < 16):
         return ConvBias.apply(x, w, bias, stride, pad)
     B, H, W, _ = x.shape
