@@ -1483,7 +1483,7 @@ class Unfold(Function):
 
 
 UNFOLD_BIG_FILTERS = os.environ.get("FS_UNFOLD_CONV", "1") != "0"
-PATCHIFY_DIRECT = os.environ.get("FS_PATCHIFY_DIRECT", "1") != "0"
+PATCHIFY_DIRECT = os.environ.get("FS_PATCHIFY_DIRECT", "0") == "1"
 
 
 def conv_bias_any(x, w, bias, stride, pad):
@@ -1495,9 +1495,10 @@ def conv_bias_any(x, w, bias, stride, pad):
     # do not overlap, the unfold is a pure permutation, and the alternative is one single-tap launch per filter tap and pass (configs[3]:
     # 312 conv_igemm_split launches per step, 13.7 ms; round 4)
     patchify = r > 1 and stride == r and pad == 0
-    # ... unless the library's own stride >= filter route takes them (<= 9 taps, Cin a multiple of 64, Cout of 64: the 2x2 reduction of the
-    # Mix-Transformer's 40-block stage): the 1x1 GEMM kernel gathers the patch rows itself, its bwd-data scatters them, bwd-weight reads
-    # them in place -- no unfold / fold passes and no patch matrix kept for the backward
+    # (FS_PATCHIFY_DIRECT=1: leave the <= 9-tap ones -- the 2x2 reduction of the Mix-Transformer's 40-block stage -- to the library's own
+    # stride >= filter route instead: gathered-row GEMM forward, one scattered-row GEMM per tap for bwd-data, bwd-weight on gathered rows;
+    # no unfold / fold passes, no patch matrix kept.  Measured on configs[3], B = 16, alternating on one box: 198.9 / 198.4 ms per step
+    # unfolded, 200.4 / 200.4 direct (-0.9 %, 1.2 GB less memory): four quarter-size GEMM launches cost more than one GEMM + a 73 us fold.  Off.)
     if patchify and PATCHIFY_DIRECT and r * s <= 9 and cin % 64 == 0 and cout % 64 == 0:
         patchify = False
     if (not UNFOLD_BIG_FILTERS or r != s or (r * s <= 32 and not patchify) or hip.get_conv_precision() != "bf16x3" or cout % 4 or cout < 16):
