@@ -468,7 +468,7 @@ class _Linear(nn.Module):
 
     def forward(self, x):           # x (B, cin) -> (B, cout)
         B, cin = x.shape
-        w4 = self.weight.view(self.weight.shape[0], cin, 1, 1)
+        w4 = ops.param_view(self.weight, lambda t: t.view(t.shape[0], t.shape[1], 1, 1))
         return ops.ConvBias.apply(x.view(B, 1, 1, cin), w4, self.bias, 1, 0).view(B, -1)
 
 

@@ -445,7 +445,28 @@ def under_torch_ddp(module) -> bool:
     return active is not None and getattr(active, "module", None) is module
 
 
+PARAM_VIEW_DIRECT = os.environ.get("FS_PARAM_VIEW_DIRECT", "1") != "0"
+
+
+def param_view(leaf, fn):
+    """fn(leaf): a VIEW of a parameter over the same storage (nn.Linear's (out, in) weight as the (out, in, 1, 1) filter of a 1x1 conv, a
+    k x k stride-k filter as the (k*k*Cin, Cout) matrix of its patch rows) that remembers how it was made, so that a kernel writing the
+    view's gradient can write it through the same view of the parameter's arena slice (_direct_grad_target) -- without that the gradient
+    is a temporary that travels back through ViewBackward to an AccumulateGrad add: 370 small launches per configs[3] step."""
+    v = fn(leaf)
+    if PARAM_VIEW_DIRECT:
+        v._fs_grad_via = (leaf, fn)
+    return v
+
+
 def _direct_grad_target(p):
+    via = getattr(p, "_fs_grad_via", None)
+    if via is not None:
+        g = _direct_grad_target(via[0])
+        if g is None:
+            return None
+        t = via[1](g)
+        return t if (t.data_ptr() == g.data_ptr() and t.shape == p.shape and t.stride() == p.stride()) else None
     home = getattr(p, "_fs_grad_home", None)
     if not DIRECT_GRAD or DDP_ACTIVE or home is None or not p.is_leaf:
         return None
@@ -933,6 +954,7 @@ class ConvBias(Function):
         ctx.save_for_backward(x, w)
         ctx.sp = (stride, pad, bias is not None, float(drop_p), int(drop_key))
         ctx.bias_ref = bias
+        ctx.w_via = getattr(w, "_fs_grad_via", None)      # param_view's record, kept here: the saved tensor may come back as a new object
         return conv2d_fwd(x, w, bias, stride, pad, float(drop_p), int(drop_key))
 
     @staticmethod
@@ -945,6 +967,8 @@ class ConvBias(Function):
             hip.call("fs_dropout", hip.ptr(dy), hip.ptr(masked), dy.numel(), drop_p, drop_key)
             dy = masked
         dx = conv2d_bwd_data(dy, w, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
+        if ctx.w_via is not None and getattr(w, "_fs_grad_via", None) is None:
+            w._fs_grad_via = ctx.w_via
         tgt = _direct_grad_target(w)
         cout, cin, r, s = w.shape
         rows = dy.numel() // cout
@@ -1507,7 +1531,8 @@ def conv_bias_any(x, w, bias, stride, pad):
     Ho, Wo = _out_hw(H, W, r, s, stride, pad)
     kk = r * s * cin
     kp = max(16, (kk + 3) // 4 * 4)
-    w2 = w.permute(2, 3, 1, 0).reshape(1, 1, kk, cout).permute(3, 2, 0, 1)      # logical (Cout, kk, 1, 1) over the same RSCK storage
+    as_matrix = lambda t: t.permute(2, 3, 1, 0).reshape(1, 1, kk, cout).permute(3, 2, 0, 1)      # logical (Cout, kk, 1, 1) over the same RSCK storage
+    w2 = param_view(w, as_matrix) if kp == kk else as_matrix(w)
     if kp != kk:
         w2 = PadWeightChannels.apply(w2, kp)
     y = ConvBias.apply(Unfold.apply(x, r, stride, pad, kp), w2, bias, 1, 0)

@@ -45,7 +45,7 @@ class HipLinear(nn.Module):
         """drop_p > 0 (training): the nn.Dropout(drop_p) that follows this layer, keyed by its module path, fused into the epilogue."""
         cin = x.shape[-1]
         lead = x.shape[:-1]
-        w4 = self.weight.view(self.weight.shape[0], cin, 1, 1)
+        w4 = ops.param_view(self.weight, lambda t: t.view(t.shape[0], t.shape[1], 1, 1))
         key = ops.DropoutState.key(ops.layer_id_from_name(drop_path)) if drop_p > 0 else 0
         y = ops.ConvBias.apply(x.reshape(1, -1, 1, cin), w4, self.bias, 1, 0, float(drop_p), key)
         return y.view(*lead, -1)

@@ -2075,6 +2075,50 @@ def test_segformer_through_module_surface():
     assert module.encoder.segformer.encoder.block[2][20].mlp.dense1.weight.grad is not None
 
 
+def test_linear_weight_gradients_land_in_the_arena_through_their_views():
+    """Round 5: a linear layer hands the conv engine a VIEW of its parameter (the (out, in) matrix as a 1x1 filter; a k x k stride-k filter as
+    the matrix of its patch rows), so the arena-direct path did not see a leaf and every such gradient travelled ViewBackward ->
+    AccumulateGrad -> add_ (370 launches per configs[3] step).  ops.param_view records how the view was made; the kernels then add into the
+    same view of the arena slice.  Same gradients on both routes, and no AccumulateGrad add left for the weights of the linears."""
+    from fovealseg import train
+    cfg = fovealseg.lvis50_cfg()
+    cfg.MODEL.arch_encoder, cfg.MODEL.fc_dim = "segformer", 1024
+    module, nets = train.build_module(cfg, device=DEV)
+    module.train()
+    opts = train.create_optimizers(nets, cfg)
+    batch = train.synthetic_batch(2, 128, 128, seed=9, device=DEV)
+
+    def run(direct):
+        saved = ops.DIRECT_GRAD
+        ops.DIRECT_GRAD = direct
+        feed = {"img_data": batch[0], "seg_label": batch[2], "focus_point": batch[1], "cls_label": batch[3]}      # (forward replaces seg_label)
+        try:
+            for o in opts:
+                o.zero_grad()
+            ops.DropoutState.seed, ops.DropoutState.step = 5, 0
+            ops.reset_step_state()
+            from torch.profiler import profile, ProfilerActivity
+            with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
+                loss, _, _ = module(feed)
+                loss.mean().backward()
+                torch.cuda.synchronize()
+
+            def is_matrix(sh):          # a linear's (out, in) weight or a k x k stride-k reduction filter (C, C, k, k); activations are (B, ..., C) with B = 2
+                sh = tuple(sh)
+                return (len(sh) == 2 and min(sh) >= 64) or (len(sh) == 4 and sh[0] == sh[1] >= 64 and sh[2] == sh[3] and sh[2] in (2, 4, 8))
+            adds = sum(1 for e in prof.events() if e.name == "aten::add_" and e.input_shapes and is_matrix(e.input_shapes[0]))
+            return [o.flat.grad.clone() for o in opts], adds
+        finally:
+            ops.DIRECT_GRAD = saved
+    g_direct, adds_direct = run(True)
+    g_auto, adds_auto = run(False)
+    for a, b in zip(g_direct, g_auto):
+        assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-30)        # bwd-weight's float atomics
+    blk = module.encoder.segformer.encoder.block
+    n_lin = sum(6 for st in blk for b_ in st) + sum(1 for st in blk for b_ in st if b_.attention.self.sr_ratio > 1)
+    assert adds_auto >= n_lin and adds_direct == 0, (adds_auto, adds_direct, n_lin)
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE configs[3] / configs[4]: task network at 160x160 on an 80x80 saliency grid (grid up-sampling,
 # models/models.py:621-631); DeepLab behind a 2048x2048 -> 80x80 warp at the per-GPU batch of the 8-GPU config.
