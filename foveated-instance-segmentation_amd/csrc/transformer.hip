@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
                                                             float* __restrict__ part_g, float* __restrict__ part_b, long M, int C,
-                                                            int rows_per_block) {
+                                                            int rows_per_block, const float* __restrict__ addend) {
   extern __shared__ float sm[];          // [4 waves][2][C] partials of dgamma / dbeta
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long r0 = (long)blockIdx.x * rows_per_block;
@@ -82,7 +82,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = 4 * lane + 256 * j;
-      if (c < C) *reinterpret_cast<f32x4*>(dx + row * C + c) = rs * (gg[j] - m1 - xh[j] * m2);
+      if (c < C) {
+        f32x4 d = rs * (gg[j] - m1 - xh[j] * m2);
+        if (addend != nullptr) d += *reinterpret_cast<const f32x4*>(addend + row * C + c);      // the other gradient of x (the residual branch's)
+        *reinterpret_cast<f32x4*>(dx + row * C + c) = d;
+      }
     }
   }
   // sm = [4 waves][2 C]: every wave stores its partial sums, the block adds them in wave order and writes its record to
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd16_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, float* __restrict__ dx,
                                                               float* __restrict__ part_g, float* __restrict__ part_b, long M, int C,
-                                                              int rows_per_block) {
+                                                              int rows_per_block, const float* __restrict__ addend) {
   extern __shared__ float sm[];          // [4 waves][2][C] partials of dgamma / dbeta
   const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const long r0 = (long)blockIdx.x * rows_per_block;
@@ -188,7 +192,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd16_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = 4 * l16 + 64 * j;
-      if (rok && c < C) *reinterpret_cast<f32x4*>(dx + row * C + c) = rs * (gg[j] - m1 - xh[j] * m2);
+      if (rok && c < C) {
+        f32x4 d = rs * (gg[j] - m1 - xh[j] * m2);
+        if (addend != nullptr) d += *reinterpret_cast<const f32x4*>(addend + row * C + c);
+        *reinterpret_cast<f32x4*>(dx + row * C + c) = d;
+      }
     }
   }
   // the four groups of a wave hold partials of the same channels: add them across the wave first (lanes l, l ^ 16, l ^ 32, l ^ 48)
@@ -848,8 +856,9 @@ long fs_layernorm_bwd_scratch_floats(long M, int C) {
 }
 
 // scratch: fs_layernorm_bwd_scratch_floats(M, C) floats -- per-workgroup records of the dgamma / dbeta sums, added in workgroup order
-int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
-                     float* dgamma, float* dbeta, long M, int C, int accumulate, float* scratch, hipStream_t stream) {
+// addend (nullable, may alias nothing of the outputs): a second gradient of x, added to dx in the same pass (include/fovealseg.h: fs_layernorm_bwd_add)
+int fs_layernorm_bwd_add(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, const float* addend, float* dx,
+                         float* dgamma, float* dbeta, long M, int C, int accumulate, float* scratch, hipStream_t stream) {
   FS_REQUIRE(g && x && gamma && mean && rstd && dx && dgamma && dbeta && scratch && M > 0 && C > 0 && C % 4 == 0 && C <= 2048);
   int rpb, nblk;
   ln_bwd_plan(M, C, &rpb, &nblk);
@@ -859,17 +868,22 @@ int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const f
   const size_t lds = 8 * (size_t)C * sizeof(float);
   if (need <= 5) {                  // (wider rows fill a wave per row; 8 float4s per lane of five arrays would spill)
     const dim3 grid((unsigned)nblk);
-#define FS_LN_BWD16(NJ_) hipLaunchKernelGGL(layernorm_bwd16_kernel<NJ_>, grid, dim3(256), lds, stream, g, x, gamma, mean, rstd, dx, part_g, part_b, M, C, rpb)
+#define FS_LN_BWD16(NJ_) hipLaunchKernelGGL(layernorm_bwd16_kernel<NJ_>, grid, dim3(256), lds, stream, g, x, gamma, mean, rstd, dx, part_g, part_b, M, C, rpb, addend)
     if (need <= 1) FS_LN_BWD16(1);
     else if (need <= 2) FS_LN_BWD16(2);
     else FS_LN_BWD16(5);
 #undef FS_LN_BWD16
   } else {
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), lds, stream, g, x, gamma, mean, rstd,
-                       dx, part_g, part_b, M, C, rpb);
+                       dx, part_g, part_b, M, C, rpb, addend);
   }
   FS_LAUNCH_CHECK();
   return fs_slab_reduce_pair(part_g, part_b, nblk, C, dgamma, dbeta, accumulate, stream);
+}
+
+int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                     float* dgamma, float* dbeta, long M, int C, int accumulate, float* scratch, hipStream_t stream) {
+  return fs_layernorm_bwd_add(g, x, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, M, C, accumulate, scratch, stream);
 }
 
 int fs_gelu_fwd(const float* x, float* y, long n, hipStream_t stream) {

@@ -77,6 +77,7 @@ SIGNATURES = {
     "fs_adam_step": "pppplfffffif",
     "fs_layernorm_fwd": "pppppplif",
     "fs_layernorm_bwd": "pppppppplii" + "p",
+    "fs_layernorm_bwd_add": "ppppppppplii" + "p",
     "fs_gelu_fwd": "ppl",
     "fs_gelu_bwd": "pppl",
     "fs_unfold": "pp" + "iiiiiiiiii",

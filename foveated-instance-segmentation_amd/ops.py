@@ -1470,6 +1470,45 @@ class LayerNorm(Function):
         return dx, dgamma, dbeta, None
 
 
+class LayerNormFan(Function):
+    """(LayerNorm(x), x): the pre-norm fan-out of a transformer block -- x feeds the normalisation AND the residual add -- as one autograd
+    node, so that both gradients of x arrive together and the LayerNorm backward pass adds the residual's while it writes dx
+    (fs_layernorm_bwd_add) instead of the autograd engine running an add pass over the activation (104 per configs[3] step)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        hip.call("fs_layernorm_fwd", hip.ptr(x), hip.ptr(gamma), hip.ptr(beta), hip.ptr(y), hip.ptr(mean), hip.ptr(rstd), M, C, float(eps))
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.beta_ref = beta
+        ctx.set_materialize_grads(False)          # an unused output's gradient arrives as None, not as a tensor of zeros
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g, g_skip):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        if g is None:
+            return g_skip, None, None, None
+        C = x.shape[-1]
+        dx = torch.empty_like(x)
+        tg, tb = _direct_grad_target(gamma), _direct_grad_target(ctx.beta_ref)
+        direct = tg is not None and tb is not None
+        dgamma = tg if direct else torch.empty_like(gamma)
+        dbeta = tb if direct else torch.empty_like(gamma)
+        M = x.numel() // C
+        scratch = torch.empty(hip.query("fs_layernorm_bwd_scratch_floats", M, C), device=x.device, dtype=torch.float32)
+        hip.call("fs_layernorm_bwd_add", hip.ptr(g.contiguous()), hip.ptr(x), hip.ptr(gamma), hip.ptr(mean), hip.ptr(rstd),
+                 hip.ptr(g_skip.contiguous()) if g_skip is not None else None, hip.ptr(dx), hip.ptr(dgamma), hip.ptr(dbeta), M, C,
+                 1 if direct else 0, hip.ptr(scratch))
+        if direct:
+            dgamma = dbeta = None
+        return dx, dgamma, dbeta, None
+
+
 class Gelu(Function):
     @staticmethod
     def forward(ctx, x):

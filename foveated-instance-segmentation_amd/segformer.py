@@ -10,6 +10,8 @@ stage-1 size (1024 channels).  This module restates that network with the 4.46.2
 Parity: against oracle/segformer_oracle.py, which is pinned to transformers 5.15.0's `SegformerModel`
 (the version installed here) by tests/golden/g13_segformer.npz -- "parity unpinned" w.r.t. 4.46.2 itself.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -49,6 +51,9 @@ class HipLinear(nn.Module):
         key = ops.DropoutState.key(ops.layer_id_from_name(drop_path)) if drop_p > 0 else 0
         y = ops.ConvBias.apply(x.reshape(1, -1, 1, cin), w4, self.bias, 1, 0, float(drop_p), key)
         return y.view(*lead, -1)
+
+
+LN_FAN = os.environ.get("FS_LN_FAN", "1") != "0"      # A/B switch: 0 = separate LayerNorm node, the engine adds the residual's gradient
 
 
 def _ln(mod, x):
@@ -159,6 +164,11 @@ class SegformerLayer(nn.Module):
         return ops.ResidualDropPath.apply(x, y, p, key)
 
     def forward(self, x):
+        if LN_FAN:           # x feeds the LayerNorm and the residual add: one node for both, the gradients meet inside the LayerNorm backward
+            y, x = ops.LayerNormFan.apply(x, self.layer_norm_1.weight, self.layer_norm_1.bias, LN_EPS)
+            x = self._dp(x, self.attention(y), ".drop_path1")
+            y, x = ops.LayerNormFan.apply(x, self.layer_norm_2.weight, self.layer_norm_2.bias, LN_EPS)
+            return self._dp(x, self.mlp(y), ".drop_path2")
         x = self._dp(x, self.attention(_ln(self.layer_norm_1, x)), ".drop_path1")
         return self._dp(x, self.mlp(_ln(self.layer_norm_2, x)), ".drop_path2")
 

@@ -327,6 +327,11 @@ int fs_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
 long fs_layernorm_bwd_scratch_floats(long M, int C);
 int fs_layernorm_bwd(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
                      float* dgamma, float* dbeta, long M, int C, int accumulate, float* scratch, fs_stream_t stream);
+/* The same pass with a second gradient of x added to dx (round 5): x of a pre-norm block feeds the LayerNorm and the residual add
+ * (transformers' modeling_segformer.py SegformerLayer.forward, used by /root/reference/models/segformer.py:88-100), so the residual's gradient
+ * arrives beside the LayerNorm's; adding it here replaces the autograd engine's add pass (104 per configs[3] step).  addend NULL = fs_layernorm_bwd. */
+int fs_layernorm_bwd_add(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, const float* addend,
+                         float* dx, float* dgamma, float* dbeta, long M, int C, int accumulate, float* scratch, fs_stream_t stream);
 /* exact (erf) GELU. */
 int fs_gelu_fwd(const float* x, float* y, long n, fs_stream_t stream);
 int fs_gelu_bwd(const float* g, const float* x, float* dx, long n, fs_stream_t stream);

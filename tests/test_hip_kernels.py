@@ -1732,6 +1732,21 @@ def test_layernorm_gelu_dwconv_droppath():
         assert relerr(out.detach().cpu(), ref.detach()) <= 1e-5
         assert relerr(xd.grad.cpu(), xr.grad) <= 1e-4
         assert relerr(wd.grad.cpu(), wr.grad) <= 1e-4 and relerr(bd.grad.cpu(), br.grad) <= 1e-4
+        # the pre-norm fan-out as one node (round 5): y = LN(x) and x itself; the residual's gradient is added inside the LayerNorm backward
+        # pass.  Same outputs bit for bit; dx = the separate node's dx + the skip gradient, the one rounding of that add apart
+        cot2 = torch.randn(ref.shape, generator=g).to(DEV)
+        xf, wf, bf = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        yf, xskip = ops.LayerNormFan.apply(xf, wf, bf, 1e-6)
+        assert torch.equal(yf, out) and torch.equal(xskip, xf)
+        torch.autograd.backward([yf, xskip], [cot.to(DEV), cot2])
+        assert torch.equal(xf.grad, xd.grad + cot2)
+        assert torch.equal(wf.grad, wd.grad) and torch.equal(bf.grad, bd.grad)
+        xg = x.to(DEV).requires_grad_(True)          # only the skip output used / only the LayerNorm output used
+        ops.LayerNormFan.apply(xg, wf, bf, 1e-6)[1].backward(cot2)
+        assert torch.equal(xg.grad, cot2)
+        xh = x.to(DEV).requires_grad_(True)
+        ops.LayerNormFan.apply(xh, wf, bf, 1e-6)[0].backward(cot.to(DEV))
+        assert torch.equal(xh.grad, xd.grad)
     x = torch.randn(2, 9, 7, 256, generator=g) * 2
     xr = x.clone().requires_grad_(True)
     ref = F.gelu(xr)
