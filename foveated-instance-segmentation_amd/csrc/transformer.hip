@@ -321,8 +321,9 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(const float* __restrict__ 
 // dw[c][t] = sum_pix x[pix + t][c] * dy[pix][c].  Same walk (10 loads per 4 pixels instead of 40); a thread loops over the items
 // item0, item0 + nitem_lanes, ... and writes its 9 x 4 partial sums to slab[item lane][9][C] (coalesced, no atomics, no memset);
 // dwconv3_wgrad_reduce_kernel adds the slab rows into dw.
+// nt = 10: the bias gradient (column sums of dy, which this kernel reads exactly once anyway) rides along as a tenth slab plane.
 __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                           float* __restrict__ slab, int B, int H, int W, int C, int nlanes) {
+                                                           float* __restrict__ slab, int B, int H, int W, int C, int nlanes, int nt) {
   const int cw = C >> 2;
   const int rg = (H + DW_RY - 1) / DW_RY, sg = (W + DW_SEG - 1) / DW_SEG;
   const long items = (long)B * rg * sg;
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const float* __restr
   const long lane0 = gt / cw;
   if (lane0 >= nlanes) return;
   const int c = 4 * cq;
-  f32x4 acc[9];
+  f32x4 acc[9], accb = f32x4{0, 0, 0, 0};
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = f32x4{0, 0, 0, 0};
   for (long item = lane0; item < items; item += nlanes) {
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const float* __restr
       for (int r = 0; r < DW_RY; ++r) {
         const bool ok = y0 + r < H;
         const f32x4 g = ok ? *reinterpret_cast<const f32x4*>(gb + ((long)(y0 + r) * W + ix) * C) : f32x4{0, 0, 0, 0};
+        accb += g;
 #pragma unroll
         for (int ty = 0; ty < 3; ++ty) {
           acc[3 * ty] += g * v0[r + ty];
@@ -368,28 +370,29 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const float* __restr
       for (int r = 0; r < DW_RY + 2; ++r) { v0[r] = v1[r]; v1[r] = v2[r]; }
     }
   }
-  float* dst = slab + (long)lane0 * 9 * C + c;
+  float* dst = slab + (long)lane0 * nt * C + c;
 #pragma unroll
   for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(dst + (long)t * C) = acc[t];
+  if (nt == 10) *reinterpret_cast<f32x4*>(dst + 9L * C) = accb;
 }
 
 // dw[c][t] (+)= sum over slab rows of slab[row][t][c]: block = 32 consecutive (t, c) elements x 8 row groups
 __global__ __launch_bounds__(256) void dwconv3_wgrad_reduce_kernel(const float* __restrict__ slab, int nlanes, int C, float* __restrict__ dw,
-                                                                  int accumulate) {
+                                                                  int accumulate, int nt, float* __restrict__ db, int accumulate_b) {
   __shared__ float red[8][32];
   const int e = threadIdx.x & 31, rgp = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + e;                          // i = t * C + c: 128-byte segments per slab row
   float s = 0.f;
-  if (i < 9 * C)
-    for (int r = rgp; r < nlanes; r += 8) s += slab[(long)r * 9 * C + i];
+  if (i < nt * C)
+    for (int r = rgp; r < nlanes; r += 8) s += slab[(long)r * nt * C + i];
   red[rgp][e] = s;
   __syncthreads();
-  if (rgp == 0 && i < 9 * C) {
+  if (rgp == 0 && i < nt * C) {
 #pragma unroll
     for (int k = 1; k < 8; ++k) s += red[k][e];
     const int t = i / C, c = i - t * C;
-    float* d = dw + c * 9 + t;
-    *d = (accumulate ? *d : 0.f) + s;
+    float* d = t < 9 ? dw + c * 9 + t : db + c;
+    *d = ((t < 9 ? accumulate : accumulate_b) ? *d : 0.f) + s;
   }
 }
 
@@ -947,9 +950,22 @@ int fs_dwconv3_bwd_weight(const float* x, const float* dy, float* dw, float* ws,
   FS_REQUIRE(x && dy && dw && ws && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
   const int lanes = fs_dwconv3_wgrad_lanes(B, H, W, C);
   const long threads = (long)lanes * (C / 4);
-  hipLaunchKernelGGL(dwconv3_wgrad_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, dy, ws, B, H, W, C, lanes);
+  hipLaunchKernelGGL(dwconv3_wgrad_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, dy, ws, B, H, W, C, lanes, 9);
   FS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dwconv3_wgrad_reduce_kernel, dim3(cdiv(9L * C, 32)), dim3(256), 0, stream, ws, lanes, C, dw, accumulate);
+  hipLaunchKernelGGL(dwconv3_wgrad_reduce_kernel, dim3(cdiv(9L * C, 32)), dim3(256), 0, stream, ws, lanes, C, dw, accumulate, 9, nullptr, 0);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// include/fovealseg.h: fs_dwconv3_bwd_weight_bias -- the same two launches also form db[C] = column sums of dy (ws = lanes * 10 * C floats)
+int fs_dwconv3_bwd_weight_bias(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int H, int W, int C, int accumulate_w,
+                               int accumulate_b, hipStream_t stream) {
+  FS_REQUIRE(x && dy && dw && db && ws && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+  const int lanes = fs_dwconv3_wgrad_lanes(B, H, W, C);
+  const long threads = (long)lanes * (C / 4);
+  hipLaunchKernelGGL(dwconv3_wgrad_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, dy, ws, B, H, W, C, lanes, 10);
+  FS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dwconv3_wgrad_reduce_kernel, dim3(cdiv(10L * C, 32)), dim3(256), 0, stream, ws, lanes, C, dw, accumulate_w, 10, db, accumulate_b);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -86,6 +86,7 @@ SIGNATURES = {
     "fs_gelu_dropout_bwd": "ppplfu",
     "fs_dwconv3_fwd": "ppppiiiii",
     "fs_dwconv3_bwd_weight": "ppppiiiii",
+    "fs_dwconv3_bwd_weight_bias": "pppppiiiiii",
     "fs_residual_droppath": "pppllfu",
     "fs_attention_fwd": "pppppiiiiffu",
     "fs_attention_fwd_split": "ppppppp" + "l" + "iiii" + "ffu",

@@ -1598,6 +1598,9 @@ class GeluDropout(Function):
         return dx, None, None
 
 
+DWCONV_BIAS_FUSED = os.environ.get("FS_DWCONV_BIAS_FUSED", "1") != "0"      # A/B switch: 0 = separate column-sum pass
+
+
 class DwConv3(Function):
     """Depthwise Conv2d(C,C,3,1,1,groups=C) + bias on NHWC; w logical (C,1,3,3)."""
 
@@ -1621,12 +1624,23 @@ class DwConv3(Function):
         tgt = _direct_grad_target(w)
         tgt = tgt if (tgt is not None and tgt.is_contiguous()) else None
         dw = tgt if tgt is not None else torch.empty_like(w)
-        ws = torch.empty(hip.query("fs_dwconv3_wgrad_lanes", B, H, W, C) * 9 * C, device=x.device, dtype=torch.float32)
+        lanes = hip.query("fs_dwconv3_wgrad_lanes", B, H, W, C)
+        if ctx.has_bias and not DWCONV_BIAS_FUSED:
+            ws = torch.empty(lanes * 9 * C, device=x.device, dtype=torch.float32)
+            hip.call("fs_dwconv3_bwd_weight", hip.ptr(x), hip.ptr(g), hip.ptr(dw), hip.ptr(ws), B, H, W, C, 1 if tgt is not None else 0)
+            return dx, (None if tgt is not None else dw), colsum(g, C, into=_direct_grad_target(ctx.bias_ref))
+        if ctx.has_bias:          # the bias gradient rides in the weight-gradient launches, which read dy once anyway
+            btgt = _direct_grad_target(ctx.bias_ref)
+            db = btgt if btgt is not None else torch.empty(C, device=x.device, dtype=torch.float32)
+            ws = torch.empty(lanes * 10 * C, device=x.device, dtype=torch.float32)
+            hip.call("fs_dwconv3_bwd_weight_bias", hip.ptr(x), hip.ptr(g), hip.ptr(dw), hip.ptr(db), hip.ptr(ws), B, H, W, C,
+                     1 if tgt is not None else 0, 1 if btgt is not None else 0)
+            return dx, (None if tgt is not None else dw), (None if btgt is not None else db)
+        ws = torch.empty(lanes * 9 * C, device=x.device, dtype=torch.float32)
         hip.call("fs_dwconv3_bwd_weight", hip.ptr(x), hip.ptr(g), hip.ptr(dw), hip.ptr(ws), B, H, W, C, 1 if tgt is not None else 0)
         if tgt is not None:
             dw = None
-        db = colsum(g, C, into=_direct_grad_target(ctx.bias_ref)) if ctx.has_bias else None
-        return dx, dw, db
+        return dx, dw, None
 
 
 class ResidualDropPath(Function):

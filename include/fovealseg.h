@@ -347,6 +347,10 @@ int fs_dwconv3_fwd(const float* x, const float* w, const float* bias, float* y, 
 int fs_dwconv3_wgrad_lanes(int B, int H, int W, int C);      /* host only */
 int fs_dwconv3_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int B, int H, int W, int C, int accumulate,
                           fs_stream_t stream);
+/* ... with the bias gradient db[C] = column sums of dy formed by the same two launches (the kernel reads every dy element exactly once
+ * already; a separate column-sum pass re-read 131 MB per Mix-FFN block of configs[3]): ws = lanes * 10 * C floats. */
+int fs_dwconv3_bwd_weight_bias(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int H, int W, int C,
+                               int accumulate_w, int accumulate_b, fs_stream_t stream);
 /* out = x + DropPath_p(y) (per-sample keep, hash keyed); x NULL -> out = scaled y (the backward of the y branch). */
 int fs_residual_droppath(const float* x, const float* y, float* out, long n, long per_sample, float drop_p, uint32_t key,
                          fs_stream_t stream);

@@ -1782,6 +1782,10 @@ def test_layernorm_gelu_dwconv_droppath():
     out.backward(nhwc(cot))
     assert relerr(nchw(out), ref.detach()) <= 1e-5 and relerr(nchw(xd.grad), xr.grad) <= 1e-5
     assert relerr(wd.grad.cpu(), wr.grad) <= 1e-4 and relerr(bd.grad.cpu(), br.grad) <= 1e-4
+    # (round 5: the bias gradient comes out of the weight-gradient launches; without a bias the nine-plane form runs: same dw, bit for bit)
+    x2, w2 = nhwc(xi).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    ops.DwConv3.apply(x2, w2, None).backward(nhwc(cot))
+    assert torch.equal(w2.grad, wd.grad) and torch.equal(x2.grad, xd.grad)
     # residual + DropPath replay
     key = ops.layer_key(2, 5)
     a, y = torch.randn(6, 10, 64, generator=g), torch.randn(6, 10, 64, generator=g)
