@@ -1926,7 +1926,10 @@ def test_attention_layer_leaves_keep_words_in_training():
 
 
 @pytest.mark.parametrize("B,H,W,Ci,Co,k,stride,pad", [(2, 23, 17, 3, 64, 7, 1, 3), (2, 24, 16, 64, 64, 8, 8, 0), (1, 29, 31, 3, 32, 7, 4, 3),
-                                                      (2, 16, 16, 32, 48, 8, 8, 0)])
+                                                      (2, 16, 16, 32, 48, 8, 8, 0),
+                                                      # stride = filter size: the permutation kernels (round 5); 22 x 18 under 4 x 4 patches leaves
+                                                      # two rows and two columns outside every patch (zero gradient there)
+                                                      (2, 22, 18, 64, 64, 4, 4, 0), (1, 12, 10, 128, 64, 2, 2, 0), (3, 9, 11, 320, 320, 2, 2, 0)])
 def test_big_filter_conv_as_unfolded_linear(B, H, W, Ci, Co, k, stride, pad):
     """Filters of more than 32 taps (SegFormer's 7x7 patch embedding, 8x8 stride-8 sequence reduction) run as unfold + one linear layer in
     bf16x3 (ops.conv_bias_any): forward, input gradient (fold), weight and bias gradients against torch in fp64."""
