@@ -1103,7 +1103,11 @@ int launch_tapset_forward(const ConvArgs& c) {
 // bwd-data extras (BatchNorm-backward sums / addend) outside the 3x3 stride-1 family: the kernel launch_affine reaches for this problem is
 // the 1x1 GEMM or the one-launch stride-2 kernel (round 5).  Same predicates, same order as the dispatch below.
 bool bnsum_beyond_wino(const ConvArgs& c) {
-  if (!c.transposed || use_s2fwd(c)) return false;
+  // forward: only the residual form of a 1x1 layer (addend, no sums, no inference epilogue) on the 1x1 GEMM kernel
+  if (!c.transposed)
+    return c.bn_ != nullptr && c.bn_->y == nullptr && c.bn_->ep_scale == nullptr && c.bn_->add_src != nullptr && c.stats_ == nullptr &&
+           use_pointwise(c) && !use_wino(c) && !use_halo(c) && !use_s2fwd(c) && !use_tapset(c);
+  if (use_s2fwd(c)) return false;
   if (c.stride == 1 && use_tapset(c) && !use_halo(c)) return false;
   if (use_wino(c) || use_halo(c)) return false;
   if (use_pointwise(c)) return true;
@@ -1412,6 +1416,39 @@ int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, i
     hipLaunchKernelGGL(conv_igemm_kernel<false>, grid, dim3(256), 0, stream, a);
   FS_LAUNCH_CHECK();
   return FS_OK;
+}
+
+// include/fovealseg.h: fs_conv2d_fwd_residual -- y = res + DropPath(Dropout(conv(x, w) + bias)) for a layer the 1x1 GEMM kernel runs
+int fs_conv2d_fwd_residual_ok(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                              long rows_per_sample, long ws_bytes) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || rows_per_sample <= 0 || ((long)B * Ho * Wo) % rows_per_sample) return 0;
+  ConvArgs a{nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0, 1.f, 0u, 0u};
+  static unsigned char dummy;
+  static const float one = 1.f;
+  const FsBnSums bn{nullptr, nullptr, nullptr, nullptr, &one, nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0u, 0u, 0};
+  a.ws_ = ws_bytes > 0 ? &dummy : nullptr; a.ws_bytes_ = ws_bytes; a.bn_ = &bn;
+  return (aligned_ok(a) && bnsum_beyond_wino(a) && rows_per_sample >= 128 && rows_per_sample < 2147483647L && (long)B * Ho * Wo * Cout < 4294967296L) ? 1 : 0;
+}
+
+int fs_conv2d_fwd_residual(const float* x, const float* w, const float* bias, const float* res, float* y, int B, int H, int W, int Cin, int Ho,
+                           int Wo, int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key, float droppath_p,
+                           uint32_t droppath_key, long rows_per_sample, void* ws, long ws_bytes, const unsigned* w_amax, hipStream_t stream) {
+  FS_REQUIRE(x && w && res && y && drop_p >= 0.f && drop_p < 1.f && droppath_p >= 0.f && droppath_p < 1.f);
+  FS_REQUIRE(fs_conv2d_fwd_residual_ok(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, rows_per_sample, ws_bytes) == 1);
+  ConvArgs a{x, w, bias, y, B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, 0, 1.f, 0u, drop_key};
+  a.stream_ = stream;
+  a.ws_ = ws; a.ws_bytes_ = ws_bytes; a.w_amax_ = w_amax;
+  if (drop_p > 0.f) {
+    a.drop_scale = 1.0f / (float)(1.0 - (double)drop_p);
+    a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
+  }
+  FsBnSums bn{nullptr, nullptr, nullptr, nullptr, res, nullptr, nullptr, nullptr, nullptr, 0, 1.f, 0u, droppath_key, (int)rows_per_sample};
+  if (droppath_p > 0.f) {
+    bn.dp_scale = 1.0f / (float)(1.0 - (double)droppath_p);
+    bn.dp_thresh = (uint32_t)((double)droppath_p * 4294967296.0);
+  }
+  a.bn_ = &bn;
+  return launch_affine(a, (long)B * Ho * Wo);
 }
 
 // include/fovealseg.h: 1 when fs_conv2d_fwd_affine_act can serve this shape (the F(2,3) kernels' row epilogue), else 0

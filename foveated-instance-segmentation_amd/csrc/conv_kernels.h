@@ -34,6 +34,9 @@ struct FsBnSums {
   const float* y; const unsigned char* mask; const float* mean; const float* invstd;      // bwd-data: BatchNorm-backward sums of the consumer layer
   const float* add_src; const unsigned char* add_mask;                                    // bwd-data: second gradient joining in the epilogue
   const float* ep_scale; const float* ep_shift; const float* ep_res; int ep_act;          // forward (inference): affine + residual + activation
+  // forward of a linear layer that ends a residual branch (1x1 GEMM kernel, round 5): dst = add_src + DropPath(Dropout(conv + bias)) --
+  // rows [b * dp_rows, (b + 1) * dp_rows) belong to sample b, kept with the sample hash of fs_residual_droppath (dp_thresh 0: no DropPath)
+  float dp_scale; uint32_t dp_thresh, dp_key; int dp_rows;
 };
 bool fs_wino_eligible(int mode, int B, int H, int W, int Cs, int Cd);
 long fs_wino_pack_bytes(int mode, int Cs, int Cd);

@@ -43,6 +43,8 @@ struct PwArgs {
   // (sum dz, sum dz * zhat) with dz = dst masked by that layer's activation bits -- and a second gradient added to dst in the same epilogue
   const float* bn_y; const unsigned char* bn_mask; const float* bn_mean; const float* bn_invstd;
   const float* add_src; const unsigned char* add_mask;
+  // forward with a residual (FsBnSums, conv_kernels.h): dst = add_src + DropPath(Dropout(acc + bias)); dp_rows rows per sample (>= ROWS)
+  float dp_scale; uint32_t dp_thresh, dp_key; int dp_rows;
 };
 
 // Wp[g = 2 * chunk + s][plane][n][j] = plane-th term of Wt[k = 32 * chunk + 16 * s + j][n] (scaled by 2^(14-Ew) in f16x2), behind a
@@ -387,6 +389,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(PwArgs a) {
     const __amdgpu_buffer_rsrc_t rs_ym = make_rsrc(a.bn_mask, a.bn_mask != nullptr ? a.dst_bytes >> 4 : 0u);
     const __amdgpu_buffer_rsrc_t rs_am = make_rsrc(a.add_mask, a.add_mask != nullptr ? a.dst_bytes >> 4 : 0u);
     const unsigned ym_all = a.bn_mask != nullptr ? 0u : 0xFu, am_all = a.add_mask != nullptr ? 0u : 0xFu;
+    // DropPath of the forward-with-residual form: a 128-row tile spans at most two samples (dp_rows >= ROWS)
+    float dpk0 = 1.f, dpk1 = 1.f;
+    long dp_edge = a.M;
+    if (a.dp_thresh != 0u) {
+      const uint32_t b0 = (uint32_t)(m0 / a.dp_rows);
+      dp_edge = (long)(b0 + 1u) * a.dp_rows;
+      dpk0 = fs_dropout_keep(b0, a.dp_key, a.dp_thresh) ? a.dp_scale : 0.f;
+      dpk1 = fs_dropout_keep(b0 + 1u, a.dp_key, a.dp_thresh) ? a.dp_scale : 0.f;
+    }
     float yv[2][8], av[2][8];
     unsigned ymv[2][8], amv[2][8];
     auto element = [&](int g, int k, unsigned& e) -> bool {            // group g = (sub-tile j, tile mi, row half): 8 accumulator rows
@@ -426,6 +437,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(PwArgs a) {
         unsigned e;
         const bool live = element(g, k, e);
         float v = P::SCALED ? fmaf(acc[mi][j][r] * f2, f1, bv) : acc[mi][j][r] + bv;
+        if (a.drop_thresh != 0u) v = fs_dropout_keep((uint32_t)e, a.drop_key, a.drop_thresh) ? v * a.drop_scale : 0.f;
+        if (a.dp_thresh != 0u) {
+          const int trow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          v *= (m0 + 64 * wm + 32 * mi + row_perm(trow)) < dp_edge ? dpk0 : dpk1;
+        }
         if (want_a) v += ((amv[slot][k] >> bit) & 1u) ? av[slot][k] : 0.f;
         v = live ? v : 0.f;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_d, live ? (int)(e * 4u) : (int)OOB, 0, 0);
@@ -542,9 +558,11 @@ int fs_pointwise_conv(int mode, const float* src, const float* w, const float* b
                       const FsBnSums* bn, hipStream_t stream) {
   PwArgs a;
   a.src = src; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = dst; a.stats = stats;
-  if (bn != nullptr && (!transposed || (bn->y != nullptr && stats == nullptr))) return FS_ERR_ARG;
+  if (bn != nullptr && bn->y != nullptr && (!transposed || stats == nullptr)) return FS_ERR_ARG;      // the sums are a bwd-data extra
+  if (bn != nullptr && bn->dp_thresh != 0u && (transposed || bn->add_src == nullptr || bn->dp_rows < ROWS)) return FS_ERR_ARG;
   a.bn_y = bn ? bn->y : nullptr; a.bn_mask = bn ? bn->mask : nullptr; a.bn_mean = bn ? bn->mean : nullptr; a.bn_invstd = bn ? bn->invstd : nullptr;
   a.add_src = bn ? bn->add_src : nullptr; a.add_mask = bn ? bn->add_mask : nullptr;
+  a.dp_scale = bn ? bn->dp_scale : 1.f; a.dp_thresh = bn ? bn->dp_thresh : 0u; a.dp_key = bn ? bn->dp_key : 0u; a.dp_rows = bn ? bn->dp_rows : 0;
   a.M = M; a.Cs = Cs; a.Cd = Cd;
   const int nwp = pw_nw(Cd);
   a.Npad = ((Cd + 64 * nwp - 1) / (64 * nwp)) * 64 * nwp;
@@ -590,6 +608,7 @@ int fs_pointwise_gather_conv(int mode, const float* x, const float* w, const flo
   const int K = R * S * Cin;
   a.src = x; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = bias; a.dst = y; a.stats = stats;
   a.bn_y = nullptr; a.bn_mask = nullptr; a.bn_mean = nullptr; a.bn_invstd = nullptr; a.add_src = nullptr; a.add_mask = nullptr;
+  a.dp_scale = 1.f; a.dp_thresh = 0u; a.dp_key = 0u; a.dp_rows = 0;
   a.M = (long)B * Ho * Wo; a.Cs = K; a.Cd = Cout;
   const int nwp = pw_nw(Cout);
   a.Npad = ((Cout + 64 * nwp - 1) / (64 * nwp)) * 64 * nwp;
@@ -629,6 +648,8 @@ int fs_pointwise_scatter_conv(int mode, const float* dy, const float* w, float* 
       PwArgs a;
       a.src = dy; a.ws = reinterpret_cast<const unsigned char*>(ws); a.bias = nullptr; a.dst = dx; a.stats = nullptr;
       a.bn_y = nullptr; a.bn_mask = nullptr; a.bn_mean = nullptr; a.bn_invstd = nullptr; a.add_src = nullptr; a.add_mask = nullptr;
+      a.dp_scale = 1.f; a.dp_thresh = 0u; a.dp_key = 0u; a.dp_rows = 0;
+  a.dp_scale = 1.f; a.dp_thresh = 0u; a.dp_key = 0u; a.dp_rows = 0;
       a.M = (long)B * He * We; a.Cs = Cout; a.Cd = Cin;
       const int nwp = pw_nw(Cin);
       a.Npad = ((Cin + 64 * nwp - 1) / (64 * nwp)) * 64 * nwp;

@@ -411,6 +411,24 @@ __global__ __launch_bounds__(256) void residual_droppath_kernel(const float* __r
   }
 }
 
+// Backward of y = x + DropPath(Dropout(z)) with respect to z in one pass: dz = Dropout-mask(DropPath-scale_b * g), the two steps in the
+// order the separate passes apply them (fs_residual_droppath with x = NULL, then fs_dropout on the result)
+__global__ __launch_bounds__(256) void droppath_dropout_bwd_kernel(const float* __restrict__ g, float* __restrict__ dz, long n4, long per_sample4,
+                                                                   float dp_scale, uint32_t dp_thresh, uint32_t dp_key, float drop_scale,
+                                                                   uint32_t drop_thresh, uint32_t drop_key) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const uint32_t b = (uint32_t)(i / per_sample4);
+    const float k = (dp_thresh == 0u || fs_dropout_keep(b, dp_key, dp_thresh)) ? dp_scale : 0.f;
+    f32x4 v = reinterpret_cast<const f32x4*>(g)[i] * k;
+    if (drop_thresh != 0u) {
+      const uint32_t keep = fs_dropout_keep4((uint32_t)(4 * i), drop_key, drop_thresh);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = ((keep >> j) & 1u) ? v[j] * drop_scale : 0.f;
+    }
+    reinterpret_cast<f32x4*>(dz)[i] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // unfold / fold: a convolution whose filter has more taps than the aligned conv kernels take (7x7 patch embedding on 3 channels, the 8x8
 // stride-8 sequence-reduction conv) as rows of patches [B*Ho*Wo][Kp], Kp = k*k*C padded to a multiple of 4 (>= 16), element order (r, s, c)
@@ -1014,6 +1032,20 @@ int fs_residual_droppath(const float* x, const float* y, float* out, long n, lon
   int blocks = cdiv(n / 4, 256); if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(residual_droppath_kernel, dim3(blocks), dim3(256), 0, stream, x, y, out, n / 4, per_sample / 4, scale, thresh,
                      key);
+  FS_LAUNCH_CHECK();
+  return FS_OK;
+}
+
+// include/fovealseg.h: fs_droppath_dropout_bwd
+int fs_droppath_dropout_bwd(const float* g, float* dz, long n, long per_sample, float droppath_p, uint32_t droppath_key, float drop_p,
+                            uint32_t drop_key, hipStream_t stream) {
+  FS_REQUIRE(g && dz && n > 0 && n % 4 == 0 && n < 4294967296L && per_sample > 0 && per_sample % 4 == 0);
+  FS_REQUIRE(droppath_p >= 0.f && droppath_p < 1.f && drop_p >= 0.f && drop_p < 1.f);
+  float dps = 1.f, ds = 1.f; uint32_t dpt = 0u, dt = 0u;
+  if (droppath_p > 0.f) { dps = 1.0f / (float)(1.0 - (double)droppath_p); dpt = (uint32_t)((double)droppath_p * 4294967296.0); }
+  if (drop_p > 0.f) { ds = 1.0f / (float)(1.0 - (double)drop_p); dt = (uint32_t)((double)drop_p * 4294967296.0); }
+  int blocks = cdiv(n / 4, 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(droppath_dropout_bwd_kernel, dim3(blocks), dim3(256), 0, stream, g, dz, n / 4, per_sample / 4, dps, dpt, droppath_key, ds, dt, drop_key);
   FS_LAUNCH_CHECK();
   return FS_OK;
 }

@@ -38,6 +38,7 @@ SIGNATURES = {
     "fs_inverse_grid": "pppiiiii",
     "fs_fill_nearest": "pppiiii",
     "fs_conv2d_fwd": "ppppiiiiiiiiiiiifuplp",
+    "fs_conv2d_fwd_residual": "ppppp" + "iiiiiiiiiiii" + "fufu" + "l" + "plp",
     "fs_conv2d_fwd_stats": "pppppiiiiiiiiiiiifuplp",
     "fs_conv2d_fwd_affine_act": "ppppppp" + "iiiiiiiiiiii" + "i" + "plp",
     "fs_conv2d_bwd_data": "pppiiiiiiiiiiiiplp",
@@ -88,6 +89,7 @@ SIGNATURES = {
     "fs_dwconv3_bwd_weight": "ppppiiiii",
     "fs_dwconv3_bwd_weight_bias": "pppppiiiiii",
     "fs_residual_droppath": "pppllfu",
+    "fs_droppath_dropout_bwd": "ppllfufu",
     "fs_attention_fwd": "pppppiiiiffu",
     "fs_attention_fwd_split": "ppppppp" + "l" + "iiii" + "ffu",
     "fs_attention_bwd": "ppppppppppiiiiffu",
@@ -101,7 +103,7 @@ _lib = None
 # declared in the header, host-side only (no stream argument)
 HOST_ONLY = ("fs_set_conv_precision", "fs_get_conv_precision", "fs_conv2d_workspace_bytes", "fs_conv2d_stats_slabs", "fs_conv2d_kernel_choice",
              "fs_bn_bwd_slabs", "fs_dwconv3_wgrad_lanes", "fs_conv2d_bwd_data_bnsum_slabs",
-             "fs_conv2d_fwd_affine_act_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes", "fs_attention_bwd_split_ws_bytes", "fs_attention_mask_words", "fs_attention_bwd_split_parts_offset",
+             "fs_conv2d_fwd_affine_act_ok", "fs_conv2d_fwd_residual_ok", "fs_linear_bwd_weight_bias_ok", "fs_attention_split_ws_bytes", "fs_attention_bwd_split_ws_bytes", "fs_attention_mask_words", "fs_attention_bwd_split_parts_offset",
              "fs_stream_wait", "fs_set_deterministic", "fs_get_deterministic", "fs_conv2d_bwd_weight_ws_bytes", "fs_linear_bwd_weight_bias_ws_bytes",
              "fs_colsum_scratch_floats", "fs_bn_stats_scratch_doubles", "fs_mask_head_bwd_scratch_floats", "fs_layernorm_bwd_scratch_floats",
              "fs_conv2d_pack_persistent", "fs_conv2d_ws_mode",
@@ -180,6 +182,8 @@ def load():
     lib.fs_conv2d_bwd_data_bnsum_slabs.argtypes = [_I] * 12 + [_L]
     lib.fs_conv2d_fwd_affine_act_ok.restype = _I
     lib.fs_conv2d_fwd_affine_act_ok.argtypes = [_I] * 12 + [_L]
+    lib.fs_conv2d_fwd_residual_ok.restype = _I
+    lib.fs_conv2d_fwd_residual_ok.argtypes = [_I] * 12 + [_L, _L]
     lib.fs_linear_bwd_weight_bias_ok.restype = _I
     lib.fs_linear_bwd_weight_bias_ok.argtypes = [_L, _I, _I]
     lib.fs_attention_split_ws_bytes.restype = _L
@@ -288,6 +292,15 @@ def fwd_affine_act_ok(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, ws_byt
     v = _ws_cache.get(key)
     if v is None:
         v = _ws_cache[key] = int(load().fs_conv2d_fwd_affine_act_ok(*key[1:]))
+    return v == 1
+
+
+def fwd_residual_ok(B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, rows_per_sample, ws_bytes):
+    """True where fs_conv2d_fwd_residual serves this shape under the current precision mode (cached)."""
+    key = ("fres", B, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, rows_per_sample, ws_bytes)
+    v = _ws_cache.get(key)
+    if v is None:
+        v = _ws_cache[key] = int(load().fs_conv2d_fwd_residual_ok(*key[1:]))
     return v == 1
 
 

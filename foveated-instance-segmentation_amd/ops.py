@@ -1643,6 +1643,85 @@ class DwConv3(Function):
         return dx, dw, None
 
 
+LINEAR_RESIDUAL = os.environ.get("FS_LINEAR_RESIDUAL", "1") != "0"      # A/B switch: 0 = linear layer, then a residual + DropPath pass
+
+
+class LinearResidual(Function):
+    """out = res + DropPath_p2(Dropout_p(x W^T + b)): the linear layer that ends a residual branch of a transformer block with the residual add
+    in the GEMM epilogue (fs_conv2d_fwd_residual), and ONE mask pass over the gradient in the backward (fs_droppath_dropout_bwd) where the
+    separate nodes ran two (DropPath's, then the Dropout's).  x (..., Cin), res (B, ..., Cout); samples = res.shape[0]."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, res, drop_p, drop_key, dp_p, dp_key):
+        cout, cin = w.shape[0], w.shape[1]
+        rows = x.numel() // cin
+        x4 = x.reshape(1, rows, 1, cin)
+        rps = rows // res.shape[0]
+        ws, ws_bytes, packed = _pack_for(w, x.device, 1, rows, 1, cin, rows, 1, cout, 1, 1, 1, 0, 1, 0)
+        out = torch.empty_like(res)
+        _launch_conv(packed, "conv_affine", 2.0 * rows * cout * cin, "fs_conv2d_fwd_residual", hip.ptr(x4), hip.ptr(rsck(w)), hip.ptr(bias),
+                     hip.ptr(res), hip.ptr(out), 1, rows, 1, cin, rows, 1, cout, 1, 1, 1, 0, 1, float(drop_p), int(drop_key), float(dp_p), int(dp_key),
+                     rps, hip.ptr(ws), ws_bytes, None)
+        ctx.save_for_backward(x4, w)
+        ctx.cfg = (float(drop_p), int(drop_key), float(dp_p), int(dp_key), rps, bias is not None, tuple(x.shape))
+        ctx.bias_ref = bias
+        ctx.w_via = getattr(w, "_fs_grad_via", None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x4, w = ctx.saved_tensors
+        drop_p, drop_key, dp_p, dp_key, rps, has_bias, x_shape = ctx.cfg
+        cout, cin = w.shape[0], w.shape[1]
+        g = g.contiguous()
+        rows = x4.shape[1]
+        if drop_p > 0.0 or dp_p > 0.0:
+            dy = torch.empty_like(g)
+            hip.call("fs_droppath_dropout_bwd", hip.ptr(g), hip.ptr(dy), g.numel(), rps * cout, dp_p, dp_key, drop_p, drop_key)
+        else:
+            dy = g
+        dy4 = dy.view(1, rows, 1, cout)
+        dx = conv2d_bwd_data(dy4, w, x4.shape, 1, 0).view(x_shape) if ctx.needs_input_grad[0] else None
+        if ctx.w_via is not None and getattr(w, "_fs_grad_via", None) is None:
+            w._fs_grad_via = ctx.w_via
+        dw, db = _linear_param_grads(x4, dy4, w, ctx.bias_ref if has_bias else None)
+        return dx, dw, db, g, None, None, None, None
+
+
+def _linear_param_grads(x4, dy4, w, bias):
+    """(dw, db) of a 1x1 / linear layer as autograd wants them: None where the kernel added straight into the parameter's arena slice."""
+    tgt = _direct_grad_target(w)
+    cout, cin = w.shape[0], w.shape[1]
+    rows = dy4.numel() // cout
+    if bias is not None and hip.linear_bwd_weight_bias_ok(rows, cin, cout):
+        btgt = _direct_grad_target(bias)
+        dw = rsck(tgt) if tgt is not None else torch.empty(1, 1, cin, cout, device=x4.device, dtype=torch.float32)
+        db = btgt if btgt is not None else torch.empty(cout, device=x4.device, dtype=torch.float32)
+        lws_bytes = hip.query("fs_linear_bwd_weight_bias_ws_bytes", cin, cout)      # deterministic mode only
+        lws = torch.empty(lws_bytes, device=x4.device, dtype=torch.uint8) if lws_bytes else None
+        _launch("conv_wgrad", 2.0 * rows * cout * cin, "fs_linear_bwd_weight_bias", hip.ptr(x4), hip.ptr(dy4), hip.ptr(dw), hip.ptr(db),
+                rows, cin, cout, 1 if tgt is not None else 0, 1 if btgt is not None else 0, hip.ptr(lws), lws_bytes)
+        return (None if tgt is not None else dw.permute(3, 2, 0, 1)), (None if btgt is not None else db)
+    dw = conv2d_bwd_weight(x4, dy4, w.shape, 1, 0, out=tgt, accumulate=tgt is not None)
+    db = colsum(dy4, cout, into=_direct_grad_target(bias)) if bias is not None else None
+    return (None if tgt is not None else dw), db
+
+
+def linear_residual(x, w, bias, res, drop_p, drop_key, dp_p, dp_key):
+    """res + DropPath(Dropout(linear(x))): fused where the 1x1 GEMM kernel runs the layer (bf16x3 / f16x2, >= 128 rows per sample), else None
+    (the caller composes ConvBias + ResidualDropPath)."""
+    if not (LINEAR_RESIDUAL and x.is_cuda and hip.get_conv_precision() != "f32"):
+        return None
+    cout, cin = w.shape[0], w.shape[1]
+    rows = x.numel() // cin
+    if rows % res.shape[0] or rows * max(cin, cout) * 4 >= MAX_TENSOR_BYTES:
+        return None
+    wsb = hip.conv_workspace_bytes(rows, 1, cin, rows, 1, cout, 1, 1, 1, 0, 1, 0)
+    if not hip.fwd_residual_ok(1, rows, 1, cin, rows, 1, cout, 1, 1, 1, 0, 1, rows // res.shape[0], wsb):
+        return None
+    return LinearResidual.apply(x, w, bias, res.contiguous(), drop_p, drop_key, dp_p, dp_key)
+
+
 class ResidualDropPath(Function):
     """out = x + DropPath_p(y): per-sample keep from the hash (p = 0: plain residual add)."""
 

@@ -43,14 +43,23 @@ class HipLinear(nn.Module):
         self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(torch.zeros(cout))
 
-    def forward(self, x, drop_p=0.0, drop_path=""):
-        """drop_p > 0 (training): the nn.Dropout(drop_p) that follows this layer, keyed by its module path, fused into the epilogue."""
+    def forward(self, x, drop_p=0.0, drop_path="", residual=None):
+        """drop_p > 0 (training): the nn.Dropout(drop_p) that follows this layer, keyed by its module path, fused into the epilogue.
+        residual = (res, droppath_p, droppath_key): the layer ends a residual branch -- returns res + DropPath(Dropout(linear(x))), with the
+        add in the GEMM epilogue where that kernel runs the layer (ops.linear_residual), as a separate pass otherwise."""
         cin = x.shape[-1]
         lead = x.shape[:-1]
         w4 = ops.param_view(self.weight, lambda t: t.view(t.shape[0], t.shape[1], 1, 1))
         key = ops.DropoutState.key(ops.layer_id_from_name(drop_path)) if drop_p > 0 else 0
-        y = ops.ConvBias.apply(x.reshape(1, -1, 1, cin), w4, self.bias, 1, 0, float(drop_p), key)
-        return y.view(*lead, -1)
+        if residual is not None:
+            res, dp_p, dp_key = residual
+            out = ops.linear_residual(x, w4, self.bias, res, float(drop_p), key, float(dp_p), int(dp_key))
+            if out is not None:
+                return out
+        y = ops.ConvBias.apply(x.reshape(1, -1, 1, cin), w4, self.bias, 1, 0, float(drop_p), key).view(*lead, -1)
+        if residual is not None:
+            return ops.ResidualDropPath.apply(res, y, dp_p, dp_key)
+        return y
 
 
 LN_FAN = os.environ.get("FS_LN_FAN", "1") != "0"      # A/B switch: 0 = separate LayerNorm node, the engine adds the residual's gradient
@@ -108,8 +117,8 @@ class SelfOutput(nn.Module):
         self.dense = HipLinear(hidden, hidden)
         self._path = ""
 
-    def forward(self, x):
-        return self.dense(x, HIDDEN_DROPOUT if self.training else 0.0, self._path + ".dropout")
+    def forward(self, x, residual=None):
+        return self.dense(x, HIDDEN_DROPOUT if self.training else 0.0, self._path + ".dropout", residual=residual)
 
 
 class SegformerAttention(nn.Module):
@@ -118,8 +127,8 @@ class SegformerAttention(nn.Module):
         self.self = EfficientSelfAttention(hidden, heads, sr)
         self.output = SelfOutput(hidden)
 
-    def forward(self, x):
-        return self.output(self.self(x))
+    def forward(self, x, residual=None):
+        return self.output(self.self(x), residual=residual)
 
 
 class DWConv(nn.Module):
@@ -139,13 +148,13 @@ class MixFFN(nn.Module):
         self.dense2 = HipLinear(hidden * MLP_RATIO, hidden)
         self._path = ""
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         y = self.dwconv(self.dense1(x))
         if self.training and HIDDEN_DROPOUT > 0 and y.numel() < 2 ** 32:
             y = ops.GeluDropout.apply(y, HIDDEN_DROPOUT, ops.DropoutState.key(ops.layer_id_from_name(self._path + ".dropout1")))
         else:
             y = _drop(ops.Gelu.apply(y), HIDDEN_DROPOUT, self.training, self._path + ".dropout1")
-        return self.dense2(y, HIDDEN_DROPOUT if self.training else 0.0, self._path + ".dropout2")
+        return self.dense2(y, HIDDEN_DROPOUT if self.training else 0.0, self._path + ".dropout2", residual=residual)
 
 
 class SegformerLayer(nn.Module):
@@ -163,12 +172,16 @@ class SegformerLayer(nn.Module):
         key = ops.DropoutState.key(ops.layer_id_from_name(self._path + tag)) if p > 0 else 0
         return ops.ResidualDropPath.apply(x, y, p, key)
 
+    def _res(self, x, tag):
+        p = self.drop_path_rate if self.training else 0.0
+        return (x, p, ops.DropoutState.key(ops.layer_id_from_name(self._path + tag)) if p > 0 else 0)
+
     def forward(self, x):
         if LN_FAN:           # x feeds the LayerNorm and the residual add: one node for both, the gradients meet inside the LayerNorm backward
             y, x = ops.LayerNormFan.apply(x, self.layer_norm_1.weight, self.layer_norm_1.bias, LN_EPS)
-            x = self._dp(x, self.attention(y), ".drop_path1")
+            x = self.attention(y, residual=self._res(x, ".drop_path1"))      # ... and the residual add is the last linear layer's epilogue
             y, x = ops.LayerNormFan.apply(x, self.layer_norm_2.weight, self.layer_norm_2.bias, LN_EPS)
-            return self._dp(x, self.mlp(y), ".drop_path2")
+            return self.mlp(y, residual=self._res(x, ".drop_path2"))
         x = self._dp(x, self.attention(_ln(self.layer_norm_1, x)), ".drop_path1")
         return self._dp(x, self.mlp(_ln(self.layer_norm_2, x)), ".drop_path2")
 

@@ -164,6 +164,18 @@ int fs_weight_amax_segments(const float* arena, const long* offsets, const long*
 int fs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Ho, int Wo,
                   int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key, void* ws, long ws_bytes,
                   const unsigned* w_amax, fs_stream_t stream);
+/* The forward of a linear layer that ENDS a residual branch of a transformer block (transformers' modeling_segformer.py SegformerSelfOutput /
+ * SegformerMixFFN.dense2 followed by `hidden_states = drop_path(...) + hidden_states`, the network /root/reference/models/segformer.py:88-100
+ * runs), with the residual add in the GEMM epilogue (round 5):   y = res + DropPath_b(Dropout(conv(x, w) + bias)).
+ * Dropout: the element hash of fs_conv2d_fwd (drop_p 0 = none); DropPath: the per-sample hash of fs_residual_droppath over samples of
+ * rows_per_sample consecutive output pixels (droppath_p 0 = none).  Only where the 1x1 GEMM kernel runs the layer:
+ * fs_conv2d_fwd_residual_ok (host only) says so, otherwise call fs_conv2d_fwd + fs_residual_droppath. */
+int fs_conv2d_fwd_residual_ok(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil,
+                              long rows_per_sample, long ws_bytes);
+int fs_conv2d_fwd_residual(const float* x, const float* w, const float* bias, const float* res, float* y, int B, int H, int W, int Cin,
+                           int Ho, int Wo, int Cout, int R, int S, int stride, int pad, int dil, float drop_p, uint32_t drop_key,
+                           float droppath_p, uint32_t droppath_key, long rows_per_sample, void* ws, long ws_bytes, const unsigned* w_amax,
+                           fs_stream_t stream);
 /* Same forward conv, additionally writing per-workgroup BatchNorm partial sums of the stored output into
  * stats = [fs_conv2d_stats_slabs(...)][Cout][2] floats (needs Cin%4==0 && Cout%4==0); finalise with
  * fs_bn_finalize_slab.  Fuses the statistics pass of F.batch_norm(training=True)
@@ -354,6 +366,10 @@ int fs_dwconv3_bwd_weight_bias(const float* x, const float* dy, float* dw, float
 /* out = x + DropPath_p(y) (per-sample keep, hash keyed); x NULL -> out = scaled y (the backward of the y branch). */
 int fs_residual_droppath(const float* x, const float* y, float* out, long n, long per_sample, float drop_p, uint32_t key,
                          fs_stream_t stream);
+/* ... and that form's gradient with respect to the layer's output in one pass: dz = Dropout-mask(DropPath-scale_b * g), the two masks in
+ * the order fs_residual_droppath (x = NULL) followed by fs_dropout apply them.  n < 2^32, n and per_sample multiples of 4. */
+int fs_droppath_dropout_bwd(const float* g, float* dz, long n, long per_sample, float droppath_p, uint32_t droppath_key, float drop_p,
+                            uint32_t drop_key, fs_stream_t stream);
 /* A convolution whose filter has more taps than the aligned kernels take (SegFormer's 7x7 patch embedding on 3 channels and 8x8 stride-8
  * sequence-reduction conv: transformers 4.46.2 SegformerOverlapPatchEmbeddings / SegformerEfficientSelfAttention.sr, models/segformer.py:
  * 9-11,33-37) as patch rows: col[B*Ho*Wo][Kp], element (r, s, c) of the k x k patch in the RSCK weight's row order, zeros outside the image

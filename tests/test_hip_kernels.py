@@ -1797,6 +1797,46 @@ def test_layernorm_gelu_dwconv_droppath():
     assert torch.equal(ad.grad.cpu(), torch.ones(6, 10, 64)) and relerr(yd.grad.cpu(), (keep / 0.75).expand(6, 10, 64)) <= 1e-6
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("B,N,Ci,Co,drop_p,dp_p", [(3, 200, 64, 320, 0.3, 0.25), (2, 131, 1280, 320, 0.3, 0.1), (4, 128, 320, 320, 0.0, 0.0),
+                                                    (2, 400, 128, 128, 0.0, 0.4), (5, 160, 36, 32, 0.3, 0.0)])
+def test_linear_with_the_residual_in_its_epilogue(B, N, Ci, Co, drop_p, dp_p, mode):
+    """Round 5: out = res + DropPath(Dropout(linear(x))) with the add in the 1x1 GEMM kernel's epilogue (fs_conv2d_fwd_residual) and one mask
+    pass in the backward (fs_droppath_dropout_bwd), against the composition it replaces (ConvBias with its fused Dropout, then
+    ResidualDropPath): same masks -- the zeros coincide -- same values to rounding, same gradients; 131 tokens per sample puts sample
+    boundaries inside the 128-row tiles."""
+    fovealseg.hip.set_conv_precision(mode)
+    try:
+        g = torch.Generator().manual_seed(B * 100 + N + Ci)
+        x = torch.randn(B, N, Ci, generator=g).to(DEV)
+        res = torch.randn(B, N, Co, generator=g).to(DEV)
+        w = rsck_param(torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5)
+        b = (torch.randn(Co, generator=g) * 0.1).to(DEV)
+        cot = torch.randn(B, N, Co, generator=g).to(DEV)
+        k1, k2 = ops.layer_key(7, 11), ops.layer_key(7, 12)
+
+        def run(fused):
+            xs, rs, ws_, bs = x.clone().requires_grad_(True), res.clone().requires_grad_(True), w.detach().clone().requires_grad_(True), b.clone().requires_grad_(True)
+            ws_ = rsck_param(w.detach().cpu()).requires_grad_(True)
+            if fused:
+                out = ops.linear_residual(xs, ws_, bs, rs, drop_p, k1 if drop_p > 0 else 0, dp_p, k2 if dp_p > 0 else 0)
+                assert out is not None
+            else:
+                y = ops.ConvBias.apply(xs.reshape(1, -1, 1, Ci), ws_, bs, 1, 0, drop_p, k1 if drop_p > 0 else 0).view(B, N, Co)
+                out = ops.ResidualDropPath.apply(rs, y, dp_p, k2 if dp_p > 0 else 0)
+            out.backward(cot)
+            return out.detach(), xs.grad, rs.grad, ws_.grad, bs.grad
+        fo, fx, fr, fw, fb = run(True)
+        uo, ux, ur, uw, ub = run(False)
+        branch_f, branch_u = fo - res, uo - res
+        assert torch.equal(branch_f.abs() < 1e-12, branch_u.abs() < 1e-12) or float(((branch_f == 0) != (branch_u == 0)).float().mean()) < 1e-6
+        assert float((fo - uo).abs().max()) <= 2e-6 * float(uo.abs().max())
+        assert torch.equal(fr, ur) and torch.equal(fr, cot)
+        assert relerr(fx, ux) <= 2e-6 and relerr(fw, uw) <= 2e-5 and relerr(fb, ub) <= 2e-5
+    finally:
+        fovealseg.hip.set_conv_precision(fovealseg.hip.default_conv_precision())
+
+
 # Nk = 100 / 400: the sequence-reduced key counts at 80x80 / 160x160 inputs (BASELINE configs[3]); ragged N and Nk; N < one wave tile
 @pytest.mark.parametrize("heads,N,Nk,p", [(1, 200, 100, 0.0), (5, 77, 100, 0.2), (2, 130, 25, 0.2), (2, 1600, 400, 0.2), (1, 300, 7, 0.0),
                                          (8, 25, 25, 0.0), (1, 6400, 100, 0.2)])
