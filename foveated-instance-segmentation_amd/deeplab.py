@@ -6,11 +6,16 @@ architecture from its published definition with the same state_dict keys (`deepl
 `deeplab.classifier.*`), computing through the HIP ops.  Parity is pinned only against this repo's own
 CPU oracle (oracle/deeplab_oracle.py) -- "parity unpinned" w.r.t. torchvision itself.
 """
+import os
+
 import torch.nn as nn
 
 from . import ops
 from .modules import HipBatchNorm2d, HipConv2d, conv_bn_act, to_nchw_view, to_nhwc, _assign_paths
+from . import modules as M
 from .ops import ACT_NONE, ACT_RELU
+
+PHASE_DOMAIN = os.environ.get("FS_PHASE_DOMAIN", "1") != "0"      # A/B switch: 0 = every atrous 3x3 re-orders around itself
 
 
 def _bn(c):
@@ -38,11 +43,20 @@ class TVBottleneck(nn.Module):
         self.bn3 = _bn(planes * 4)
         self.downsample = _Down(inplanes, planes * 4, stride) if downsample else None
 
-    def forward(self, x):
-        r = x if self.downsample is None else self.downsample(x)
-        o = conv_bn_act(x, self.conv1, self.bn1, ACT_RELU)
-        o = conv_bn_act(o, self.conv2, self.bn2, ACT_RELU)
-        return conv_bn_act(o, self.conv3, self.bn3, ACT_RELU, res=r)
+    def forward(self, x, phase=1):
+        """phase = d > 1: x is in the phase domain of this block's dilation (modules.conv_bn_act); so is the result."""
+        r = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1], ACT_NONE, phase=phase)
+        o = conv_bn_act(x, self.conv1, self.bn1, ACT_RELU, phase=phase)
+        o = conv_bn_act(o, self.conv2, self.bn2, ACT_RELU, phase=phase)
+        return conv_bn_act(o, self.conv3, self.bn3, ACT_RELU, res=r, phase=phase)
+
+    def phase_of(self, x_shape):
+        """The phase domain this block can run in: its dilation d when its 3x3 is an atrous stride-1 layer on a map that d divides, else 1."""
+        c = self.conv2
+        d = c.dilation
+        ok = (d > 1 and c.stride == 1 and c.padding == d and x_shape[1] % d == 0 and x_shape[2] % d == 0 and
+              (self.downsample is None or (self.downsample[0].stride == 1 and self.downsample[0].k == 1)))
+        return d if ok else 1
 
 
 class _Seq(nn.Sequential):
@@ -79,7 +93,25 @@ class ResNet101Dilated(nn.Module):
     def forward(self, x):
         x = conv_bn_act(x, self.conv1, self.bn1, ACT_RELU)
         x = ops.MaxPool.apply(x, 3, 2, 1)
-        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.layer2(self.layer1(x))
+        if not (PHASE_DOMAIN and M.SPACE_TO_BATCH_DILATED and ops.ACT_TRACE is None):
+            return self.layer4(self.layer3(x))
+        # Round 5: the atrous blocks of layer3 / layer4 run in the phase domain of their dilation (the d*d sub-sampled phase images as batch
+        # entries: modules._space_to_batch) -- and since everything else in a Bottleneck is point-wise in space (1x1 convs, BatchNorm over the
+        # same element set, ReLU, the residual add), a RUN of blocks with the same dilation enters the domain once and leaves it once,
+        # instead of re-ordering around every 3x3 (88 copy launches per configs[4] step for layer3's 22 dilation-2 blocks)
+        cur = 1
+        for blk in list(self.layer3) + list(self.layer4):
+            shape = (x.shape[0] // (cur * cur), x.shape[1] * cur, x.shape[2] * cur, x.shape[3])
+            want = blk.phase_of(shape)
+            if want != cur:
+                if cur > 1:
+                    x = M._batch_to_space(x, cur)
+                if want > 1:
+                    x = M._space_to_batch(x, want)
+                cur = want
+            x = blk(x, phase=cur)
+        return M._batch_to_space(x, cur) if cur > 1 else x
 
 
 class _ConvBnRelu(nn.Sequential):

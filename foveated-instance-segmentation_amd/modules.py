@@ -68,7 +68,9 @@ class _NbtCounter:
         self.bn._pending_batches += n
 
 
-def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, act, res=None, drop_p=0.0, layer_id=0, stride=None):
+def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, act, res=None, drop_p=0.0, layer_id=0, stride=None, phase=1):
+    """phase = d > 1: x (and res) are ALREADY in the phase domain of dilation d (_space_to_batch(., d), done once by the caller for a run of
+    layers): a 3x3 layer of dilation d runs as the plain 3x3 / pad 1 layer it is there, a 1x1 layer is unchanged; the result stays in the domain."""
     training = bn.training
     meta = dict(stride=conv.stride if stride is None else stride, pad=conv.padding, dil=conv.dilation, act=act, training=training, momentum=bn.momentum,
                 drop_p=drop_p, drop_key=ops.DropoutState.key(layer_id) if (training and drop_p > 0) else 0,
@@ -76,7 +78,10 @@ def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, act, res=None, drop_p=0.
                 grad_enabled=torch.is_grad_enabled())
     x, w = ops.pad_in_channels(x, conv.weight)
     d = meta["dil"]
-    if (SPACE_TO_BATCH_DILATED and d > 1 and w.shape[2] == 3 and w.shape[3] == 3 and meta["stride"] == 1 and meta["pad"] == d
+    if phase > 1:
+        assert meta["stride"] == 1 and not (training and drop_p > 0) and ((w.shape[2] == 1 and meta["pad"] == 0) or (w.shape[2] == 3 and d == phase and meta["pad"] == d))
+        z = ops.ConvBnAct.apply(x, w, conv.bias, bn.weight, bn.bias, res, dict(meta, dil=1, pad=1 if w.shape[2] == 3 else 0))
+    elif (SPACE_TO_BATCH_DILATED and d > 1 and w.shape[2] == 3 and w.shape[3] == 3 and meta["stride"] == 1 and meta["pad"] == d
             and d >= x.shape[1] and d >= x.shape[2]):
         # ASPP rates of 12 / 24 / 36 on a 10 x 10 map: every tap but the centre reads zero padding only, so the layer IS the 1 x 1 conv of its
         # centre tap (and the other taps' gradients are exactly zero)
