@@ -445,7 +445,20 @@ constexpr int GG_BANDS = 4;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// row pass on the band [x0, x0 + bw): R0[y][ox - x0] = sum_s g[s] xs[y][clamp(ox+s-pad)],  R1 = same * cx(ox+s)
+// TRAIN.def_saliency_pad_mode (models/models.py:819-825): which source index the padded position t = j - pad reads.
+//   PAD_REPLICATION  nn.ReplicationPad2d: the border pixel;   PAD_REFLECT  F.pad(mode='reflect'): mirrored about the border pixel
+//   (torch asks pad <= n - 1);   PAD_ZERO  F.pad(mode='constant'): nothing (-1).  The mode is a template parameter, so the default
+//   (replication) instantiation is the code it was before the other two existed.
+constexpr int PAD_REPLICATION = 0, PAD_REFLECT = 1, PAD_ZERO = 2;
+template <int MODE>
+__device__ __forceinline__ int padmap(int t, int n) {
+  if (MODE == PAD_REPLICATION) return clampi(t, 0, n - 1);
+  if (MODE == PAD_REFLECT) return t < 0 ? -t : (t > n - 1 ? 2 * (n - 1) - t : t);
+  return (t < 0 || t > n - 1) ? -1 : t;
+}
+
+// row pass on the band [x0, x0 + bw): R0[y][ox - x0] = sum_s g[s] xs[y][padmap(ox+s-pad)],  R1 = same * cx(ox+s)
+template <int MODE>
 __device__ void gauss_rows(const float* xs, const double* g, int hs, int ws, int pad, int x0, int bw, float* R0, float* R1) {
   const int K = 2 * pad + 1;
   const double inv = 1.0 / (double)(ws - 1);
@@ -454,7 +467,9 @@ __device__ void gauss_rows(const float* xs, const double* g, int hs, int ws, int
     double a0 = 0.0, a1 = 0.0;
     for (int s = 0; s < K; ++s) {
       const int j = ox + s;
-      const double v = g[s] * (double)xs[y * ws + clampi(j - pad, 0, ws - 1)];
+      const int sx = padmap<MODE>(j - pad, ws);
+      if (MODE == PAD_ZERO && sx < 0) continue;
+      const double v = g[s] * (double)xs[y * ws + sx];
       a0 += v;
       a1 += v * ((double)(j - pad) * inv);
     }
@@ -463,6 +478,7 @@ __device__ void gauss_rows(const float* xs, const double* g, int hs, int ws, int
 }
 
 // column pass at (oy, band column xb): R0 / R1 are [hs][bw]
+template <int MODE>
 __device__ __forceinline__ void gauss_cols_at(const float* R0, const float* R1, const double* g, int hs, int bw, int pad,
                                               int oy, int xb, double& p, double& ax, double& ay) {
   const int K = 2 * pad + 1;
@@ -470,7 +486,8 @@ __device__ __forceinline__ void gauss_cols_at(const float* R0, const float* R1, 
   p = 0.0; ax = 0.0; ay = 0.0;
   for (int r = 0; r < K; ++r) {
     const int i = oy + r;
-    const int y = clampi(i - pad, 0, hs - 1);
+    const int y = padmap<MODE>(i - pad, hs);
+    if (MODE == PAD_ZERO && y < 0) continue;
     const double v0 = g[r] * (double)R0[y * bw + xb];
     p += v0;
     ax += g[r] * (double)R1[y * bw + xb];
@@ -486,6 +503,7 @@ __device__ __forceinline__ void gg_band(int ws, int& x0, int& bw, int& b) {
   bw = x0 >= ws ? 0 : (x0 + w <= ws ? w : ws - x0);
 }
 
+template <int MODE>
 __global__ __launch_bounds__(1024) void gauss_grid_fwd_kernel(const float* __restrict__ xs_g, const double* __restrict__ g1d,
                                                               float* __restrict__ grid, int hs, int ws, int pad) {
   extern __shared__ float sm[];
@@ -498,12 +516,12 @@ __global__ __launch_bounds__(1024) void gauss_grid_fwd_kernel(const float* __res
   for (int i = threadIdx.x; i < 2 * pad + 1; i += blockDim.x) g[i] = g1d[i];
   for (int i = threadIdx.x; i < n; i += blockDim.x) X[i] = xs_g[(long)b * n + i];
   __syncthreads();
-  gauss_rows(X, g, hs, ws, pad, x0, bw, R0, R1);
+  gauss_rows<MODE>(X, g, hs, ws, pad, x0, bw, R0, R1);
   __syncthreads();
   for (int i = threadIdx.x; i < hs * bw; i += blockDim.x) {
     const int oy = i / bw, xb = i - oy * bw;
     double p, ax, ay;
-    gauss_cols_at(R0, R1, g, hs, bw, pad, oy, xb, p, ax, ay);
+    gauss_cols_at<MODE>(R0, R1, g, hs, bw, pad, oy, xb, p, ax, ay);
     float gx = (float)(ax / p * 2.0 - 1.0), gy = (float)(ay / p * 2.0 - 1.0);
     gx = fminf(fmaxf(gx, -1.f), 1.f);
     gy = fminf(fmaxf(gy, -1.f), 1.f);
@@ -514,6 +532,7 @@ __global__ __launch_bounds__(1024) void gauss_grid_fwd_kernel(const float* __res
 }
 
 // backward, launch 1 of 2: dgrid (B,hs,ws,2) -> (dp, dax, day) per grid point of the band -> scratch [B][3][n]
+template <int MODE>
 __global__ __launch_bounds__(1024) void gauss_grid_bwd1_kernel(const float* __restrict__ xs_g, const double* __restrict__ g1d,
                                                                const float* __restrict__ dgrid, float* __restrict__ scratch,
                                                                int hs, int ws, int pad) {
@@ -527,14 +546,14 @@ __global__ __launch_bounds__(1024) void gauss_grid_bwd1_kernel(const float* __re
   for (int i = threadIdx.x; i < 2 * pad + 1; i += blockDim.x) g[i] = g1d[i];
   for (int i = threadIdx.x; i < n; i += blockDim.x) X[i] = xs_g[(long)b * n + i];
   __syncthreads();
-  gauss_rows(X, g, hs, ws, pad, x0, bw, R0, R1);
+  gauss_rows<MODE>(X, g, hs, ws, pad, x0, bw, R0, R1);
   __syncthreads();
   float* S = scratch + (long)b * 3 * n;
   for (int i = threadIdx.x; i < hs * bw; i += blockDim.x) {
     const int oy = i / bw, xb = i - oy * bw;
     const int pt = oy * ws + x0 + xb;
     double p, ax, ay;
-    gauss_cols_at(R0, R1, g, hs, bw, pad, oy, xb, p, ax, ay);
+    gauss_cols_at<MODE>(R0, R1, g, hs, bw, pad, oy, xb, p, ax, ay);
     const double ux = ax / p * 2.0 - 1.0, uy = ay / p * 2.0 - 1.0;
     // clamp(-1,1) passes the gradient where the un-clamped value lies inside [-1,1] (bounds included)
     const double dgx = (ux >= -1.0 && ux <= 1.0) ? (double)dgrid[((long)b * n + pt) * 2 + 0] : 0.0;
@@ -545,8 +564,22 @@ __global__ __launch_bounds__(1024) void gauss_grid_bwd1_kernel(const float* __re
   }
 }
 
-// backward, launch 2 of 2: the transposed separable filter on (dp, dax, day), the replication padding folded back onto the border pixels;
-// the band's columns of dxs.
+// padded positions j in [0, n + 2 pad) that read source index x under reflect (the pixel itself, its mirror image in the low pad when
+// 1 <= x <= pad, its mirror image in the high pad when n-1-pad <= x <= n-2) or zero padding (the pixel itself): at most three
+template <int MODE>
+__device__ __forceinline__ int pad_sources(int x, int n, int pad, int* js) {
+  int c = 0;
+  js[c++] = x + pad;
+  if (MODE == PAD_REFLECT) {
+    if (x >= 1 && x <= pad) js[c++] = pad - x;
+    if (x <= n - 2 && x >= n - 1 - pad) js[c++] = pad + 2 * (n - 1) - x;
+  }
+  return c;
+}
+
+// backward, launch 2 of 2: the transposed separable filter on (dp, dax, day), the padding folded back onto the pixels it copies (replication:
+// the border pixels collect pad + 1 positions each; reflect: up to three positions per pixel; zero: one); the band's columns of dxs.
+template <int MODE>
 __global__ __launch_bounds__(1024) void gauss_grid_bwd2_kernel(const float* __restrict__ scratch, const double* __restrict__ g1d,
                                                                float* __restrict__ dxs, int hs, int ws, int pad) {
   extern __shared__ float sm[];
@@ -567,7 +600,7 @@ __global__ __launch_bounds__(1024) void gauss_grid_bwd2_kernel(const float* __re
   // sums over the padded positions are folded into per-source weights first:
   //   T0[o] = sum_j g[j-o],  T1[o] = sum_j c(j) g[j-o]   over the border's j range (left/top: [0,pad], right/bottom: [n-1+pad, n+2pad-1])
   const double invx = 1.0 / (double)(ws - 1), invy = 1.0 / (double)(hs - 1);
-  const bool tables = hs <= BT && ws <= BT;
+  const bool tables = MODE == PAD_REPLICATION && hs <= BT && ws <= BT;
   if (tables) {
     for (int q = threadIdx.x; q < 2 * (ws + hs); q += blockDim.x) {
       const bool isx = q < 2 * ws;
@@ -604,8 +637,11 @@ __global__ __launch_bounds__(1024) void gauss_grid_bwd2_kernel(const float* __re
       continue;
     }
     const int j_lo = (x == 0) ? 0 : x + pad, j_hi = (x == ws - 1) ? ws + 2 * pad - 1 : x + pad;
+    int js[3];
+    const int nj = MODE == PAD_REPLICATION ? j_hi - j_lo + 1 : pad_sources<MODE>(x, ws, pad, js);
     double va = 0.0, vb = 0.0;
-    for (int j = j_lo; j <= j_hi; ++j) {
+    for (int q = 0; q < nj; ++q) {
+      const int j = MODE == PAD_REPLICATION ? j_lo + q : js[q];
       const double cx = (double)(j - pad) * invx;
       int o_lo = j - (K - 1); if (o_lo < 0) o_lo = 0;
       int o_hi = j; if (o_hi > ws - 1) o_hi = ws - 1;
@@ -634,8 +670,11 @@ __global__ __launch_bounds__(1024) void gauss_grid_bwd2_kernel(const float* __re
       continue;
     }
     const int i_lo = (y == 0) ? 0 : y + pad, i_hi = (y == hs - 1) ? hs + 2 * pad - 1 : y + pad;
+    int is[3];
+    const int ni = MODE == PAD_REPLICATION ? i_hi - i_lo + 1 : pad_sources<MODE>(y, hs, pad, is);
     double acc = 0.0;
-    for (int i = i_lo; i <= i_hi; ++i) {
+    for (int q = 0; q < ni; ++q) {
+      const int i = MODE == PAD_REPLICATION ? i_lo + q : is[q];
       const double cy = (double)(i - pad) * invy;
       int o_lo = i - (K - 1); if (o_lo < 0) o_lo = 0;
       int o_hi = i; if (o_hi > hs - 1) o_hi = hs - 1;
@@ -1088,32 +1127,65 @@ static int gg_set_lds(const void* fn, int bytes, unsigned long long& done) {
   return FS_OK;
 }
 
-int fs_gauss_grid_fwd(const float* xs, const double* g1d, float* grid, int B, int hs, int ws, int pad, hipStream_t stream) {
-  FS_REQUIRE(xs && g1d && grid && B > 0 && hs > 1 && ws > 1 && hs * ws <= GMAX && pad >= 0 && 2 * pad + 1 <= 256);
+extern "C++" {
+template <int MODE>
+static int gauss_grid_fwd_launch(const float* xs, const double* g1d, float* grid, int B, int hs, int ws, int pad, hipStream_t stream) {
   static unsigned long long done = 0ull;
-  const int r = gg_set_lds((const void*)gauss_grid_fwd_kernel, 3 * GMAX * (int)sizeof(float), done);
+  const int r = gg_set_lds((const void*)gauss_grid_fwd_kernel<MODE>, 3 * GMAX * (int)sizeof(float), done);
   if (r != FS_OK) return r;
-  hipLaunchKernelGGL(gauss_grid_fwd_kernel, dim3(B * GG_BANDS), dim3(1024), 3 * GMAX * sizeof(float), stream, xs, g1d, grid, hs, ws, pad);
+  hipLaunchKernelGGL(gauss_grid_fwd_kernel<MODE>, dim3(B * GG_BANDS), dim3(1024), 3 * GMAX * sizeof(float), stream, xs, g1d, grid, hs, ws, pad);
   FS_LAUNCH_CHECK();
   return FS_OK;
+}
+}  // extern "C++"
+
+// include/fovealseg.h: pad_mode 0 replication / 1 reflect / 2 zero (TRAIN.def_saliency_pad_mode, models/models.py:819-825)
+int fs_gauss_grid_fwd_mode(const float* xs, const double* g1d, float* grid, int B, int hs, int ws, int pad, int pad_mode, hipStream_t stream) {
+  FS_REQUIRE(xs && g1d && grid && B > 0 && hs > 1 && ws > 1 && hs * ws <= GMAX && pad >= 0 && 2 * pad + 1 <= 256);
+  FS_REQUIRE(pad_mode >= PAD_REPLICATION && pad_mode <= PAD_ZERO);
+  FS_REQUIRE(pad_mode != PAD_REFLECT || (pad <= hs - 1 && pad <= ws - 1));          // F.pad(mode='reflect') refuses a pad >= the side
+  if (pad_mode == PAD_REFLECT) return gauss_grid_fwd_launch<PAD_REFLECT>(xs, g1d, grid, B, hs, ws, pad, stream);
+  if (pad_mode == PAD_ZERO) return gauss_grid_fwd_launch<PAD_ZERO>(xs, g1d, grid, B, hs, ws, pad, stream);
+  return gauss_grid_fwd_launch<PAD_REPLICATION>(xs, g1d, grid, B, hs, ws, pad, stream);
+}
+
+int fs_gauss_grid_fwd(const float* xs, const double* g1d, float* grid, int B, int hs, int ws, int pad, hipStream_t stream) {
+  return fs_gauss_grid_fwd_mode(xs, g1d, grid, B, hs, ws, pad, PAD_REPLICATION, stream);
 }
 
 // include/fovealseg.h: floats of scratch fs_gauss_grid_bwd needs ((dp, dax, day) per grid point, handed from its first launch to its second)
 long fs_gauss_grid_bwd_scratch_floats(int B, int hs, int ws) { return (B > 0 && hs > 0 && ws > 0) ? 3L * B * hs * ws : 0; }
 
-int fs_gauss_grid_bwd(const float* xs, const double* g1d, const float* dgrid, float* dxs, int B, int hs, int ws, int pad,
-                      float* scratch, hipStream_t stream) {
-  FS_REQUIRE(xs && g1d && dgrid && dxs && scratch && B > 0 && hs > 1 && ws > 1 && hs * ws <= GMAX && pad >= 0 && 2 * pad + 1 <= 256);
+extern "C++" {
+template <int MODE>
+static int gauss_grid_bwd_launch(const float* xs, const double* g1d, const float* dgrid, float* dxs, int B, int hs, int ws, int pad,
+                                 float* scratch, hipStream_t stream) {
   static unsigned long long done1 = 0ull, done2 = 0ull;
-  int r = gg_set_lds((const void*)gauss_grid_bwd1_kernel, 3 * GMAX * (int)sizeof(float), done1);
+  int r = gg_set_lds((const void*)gauss_grid_bwd1_kernel<MODE>, 3 * GMAX * (int)sizeof(float), done1);
   if (r != FS_OK) return r;
-  r = gg_set_lds((const void*)gauss_grid_bwd2_kernel, 5 * GMAX * (int)sizeof(float), done2);
+  r = gg_set_lds((const void*)gauss_grid_bwd2_kernel<MODE>, 5 * GMAX * (int)sizeof(float), done2);
   if (r != FS_OK) return r;
-  hipLaunchKernelGGL(gauss_grid_bwd1_kernel, dim3(B * GG_BANDS), dim3(1024), 3 * GMAX * sizeof(float), stream, xs, g1d, dgrid, scratch, hs, ws, pad);
+  hipLaunchKernelGGL(gauss_grid_bwd1_kernel<MODE>, dim3(B * GG_BANDS), dim3(1024), 3 * GMAX * sizeof(float), stream, xs, g1d, dgrid, scratch, hs, ws, pad);
   FS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gauss_grid_bwd2_kernel, dim3(B * GG_BANDS), dim3(1024), 5 * GMAX * sizeof(float), stream, scratch, g1d, dxs, hs, ws, pad);
+  hipLaunchKernelGGL(gauss_grid_bwd2_kernel<MODE>, dim3(B * GG_BANDS), dim3(1024), 5 * GMAX * sizeof(float), stream, scratch, g1d, dxs, hs, ws, pad);
   FS_LAUNCH_CHECK();
   return FS_OK;
+}
+}  // extern "C++"
+
+int fs_gauss_grid_bwd_mode(const float* xs, const double* g1d, const float* dgrid, float* dxs, int B, int hs, int ws, int pad, int pad_mode,
+                           float* scratch, hipStream_t stream) {
+  FS_REQUIRE(xs && g1d && dgrid && dxs && scratch && B > 0 && hs > 1 && ws > 1 && hs * ws <= GMAX && pad >= 0 && 2 * pad + 1 <= 256);
+  FS_REQUIRE(pad_mode >= PAD_REPLICATION && pad_mode <= PAD_ZERO);
+  FS_REQUIRE(pad_mode != PAD_REFLECT || (pad <= hs - 1 && pad <= ws - 1));
+  if (pad_mode == PAD_REFLECT) return gauss_grid_bwd_launch<PAD_REFLECT>(xs, g1d, dgrid, dxs, B, hs, ws, pad, scratch, stream);
+  if (pad_mode == PAD_ZERO) return gauss_grid_bwd_launch<PAD_ZERO>(xs, g1d, dgrid, dxs, B, hs, ws, pad, scratch, stream);
+  return gauss_grid_bwd_launch<PAD_REPLICATION>(xs, g1d, dgrid, dxs, B, hs, ws, pad, scratch, stream);
+}
+
+int fs_gauss_grid_bwd(const float* xs, const double* g1d, const float* dgrid, float* dxs, int B, int hs, int ws, int pad,
+                      float* scratch, hipStream_t stream) {
+  return fs_gauss_grid_bwd_mode(xs, g1d, dgrid, dxs, B, hs, ws, pad, PAD_REPLICATION, scratch, stream);
 }
 
 // include/fovealseg.h: fs_grid_upsample_fwd / _bwd

@@ -28,6 +28,8 @@ SIGNATURES = {
     "fs_edge_loss_bwd": "pplfppp",
     "fs_gauss_grid_fwd": "pppiiii",
     "fs_gauss_grid_bwd": "ppppiiii" + "p",
+    "fs_gauss_grid_fwd_mode": "pppiiiii",
+    "fs_gauss_grid_bwd_mode": "ppppiiiii" + "p",
     "fs_grid_upsample_fwd": "ppiiiii",
     "fs_grid_upsample_bwd": "ppiiiii",
     "fs_grid_sample_fwd": "pppiiiiiii",

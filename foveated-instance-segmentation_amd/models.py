@@ -110,7 +110,9 @@ class DeformSegmentationModule(nn.Module):
         if ti != si and (ti[0] % si[0] or ti[1] % si[1]):
             raise NotImplementedError("task_input_size must be an integer multiple of saliency_input_size (grid up-sampling, models/models.py:621-631)")
         if cfg.DATASET.segm_downsampling_rate != 1:
-            raise NotImplementedError("DATASET.segm_downsampling_rate must be 1 (grid_y == grid, models/models.py:627)")
+            raise NotImplementedError("DATASET.segm_downsampling_rate must be 1 (grid_y == grid, models/models.py:627): with any other rate the "
+                                      "reference samples the label at task_input_size // rate and multiplies it with cls_label.repeat(1, HS, WS) at the "
+                                      "saliency size (:968) against a prediction at the task size -- a shape error with every encoder of this path")
         k = 2 * self.padding_size_x + 1
         self.filter = _FilterHolder(k, cfg.MODEL.gaussian_radius)
         self.register_buffer("g1d", torch.from_numpy(make_gaussian_1d(k, cfg.MODEL.gaussian_radius)), persistent=False)
@@ -125,10 +127,16 @@ class DeformSegmentationModule(nn.Module):
                 raise NotImplementedError(f"{name}=True is outside the built hot path (SURVEY.md Appendix A)")
         if c.MODEL.upsample and c.MODEL.rev_deform_interp != "nearest":
             raise NotImplementedError("MODEL.upsample needs rev_deform_interp='nearest' (the reference's 'tri' default calls an undefined name)")
-        if c.MODEL.uniform_sample != "":
-            raise NotImplementedError("MODEL.uniform_sample must be '' (learned sampling)")
-        if c.TRAIN.def_saliency_pad_mode != "replication":
-            raise NotImplementedError("only replication padding of the saliency map is built")
+        if c.MODEL.uniform_sample == "BI":
+            raise NotImplementedError("MODEL.uniform_sample='BI' is unreachable in the reference with this fork's (B,1,H,W) labels: "
+                                      "nn.Upsample(mode='bilinear') of y.float().unsqueeze(1) is handed a 5-D tensor (models/models.py:877); "
+                                      "'' (learned sampling) and any other value (uniform saliency, config/defaults.py:69) are built")
+        if c.TRAIN.def_saliency_pad_mode not in ops.PAD_MODES:
+            # models/models.py:819-825 has no else branch: xs_hm stays unbound and line 845 raises the NameError subclass below
+            raise UnboundLocalError("local variable 'xs_hm' referenced before assignment (TRAIN.def_saliency_pad_mode must be "
+                                    "'replication', 'reflect' or 'zero', models/models.py:819-825)")
+        if c.TRAIN.def_saliency_pad_mode == "reflect" and self.padding_size_x > min(self.grid_size_x, self.grid_size_y) - 1:
+            raise NotImplementedError("def_saliency_pad_mode='reflect' needs gaussian_radius <= saliency side - 1 (F.pad refuses it too)")
         if not c.TRAIN.opt_deform_LabelEdge_norm:
             raise NotImplementedError("only the min/max-normalised edge loss is built")
         if self.deep_sup_scale is not None:
@@ -142,10 +150,10 @@ class DeformSegmentationModule(nn.Module):
         return self.net_compress.softmax_nhwc(s), x_low
 
     def create_grid(self, xs):
-        """xs (B,1,hs,ws) -> grid (B,ht,wt,2) at the task network's input size; replication pad folded in
-        (models/models.py:594-637,821).  When task_input_size != saliency_input_size the (hs,ws) grid is bilinearly up-sampled
+        """xs (B,1,hs,ws) -> grid (B,ht,wt,2) at the task network's input size; the padding of TRAIN.def_saliency_pad_mode
+        ('replication' nn.ReplicationPad2d, 'reflect' / 'zero' F.pad) folded in (models/models.py:594-637,819-825).  When task_input_size != saliency_input_size the (hs,ws) grid is bilinearly up-sampled
         (nn.Upsample(size=input_size_net, mode='bilinear'), :621-631); grid_y is the same tensor (segm_downsampling_rate 1)."""
-        grid = ops.GaussGrid.apply(xs, self.g1d, self.padding_size_x)
+        grid = ops.GaussGrid.apply(xs, self.g1d, self.padding_size_x, ops.PAD_MODES[self.cfg.TRAIN.def_saliency_pad_mode])
         ht, wt = int(self.input_size_net[0]), int(self.input_size_net[1])
         if (ht, wt) != (grid.shape[1], grid.shape[2]):
             grid = ops.GridUpsample.apply(grid, ht, wt)
@@ -208,7 +216,12 @@ class DeformSegmentationModule(nn.Module):
         xs, _ = self.saliency(x, focus)
         self._note_nan(xs)
         xs = ops.grad_probe(xs, "dxs_sum")                              # (ops.GRAD_TRACE: no-ops unless a test switched the recorder on)
-        grid = ops.grad_probe(self.create_grid(ops.grad_probe(xs, "dxs_grid", alias=True)), "dgrid")
+        xs_grid = xs
+        if cfg.MODEL.uniform_sample != "":
+            # models/models.py:816-818 ('Saliency', config/defaults.py:69): the sampler runs on a uniform map; the edge loss keeps the learned
+            # one (xs_our is cloned at :726, before this line) and the grid path hands the saliency net a zero gradient (d(xs*0)/dxs)
+            xs_grid = xs * 0 + 1.0 / (self.grid_size_x * self.grid_size_y)
+        grid = ops.grad_probe(self.create_grid(ops.grad_probe(xs_grid, "dxs_grid", alias=True)), "dgrid")
 
         joint = cfg.TRAIN.deform_joint_loss
         if joint:

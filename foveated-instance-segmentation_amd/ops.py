@@ -1323,16 +1323,24 @@ class EdgeLoss(Function):
         return dxs, None, None
 
 
+PAD_MODES = {"replication": 0, "reflect": 1, "zero": 2}      # TRAIN.def_saliency_pad_mode (models/models.py:819-825)
+
+
 class GaussGrid(Function):
-    """xs (B,1,hs,ws) -> grid (B,hs,ws,2); g1d = separable Gaussian taps (float64, device)."""
+    """xs (B,1,hs,ws) -> grid (B,hs,ws,2); g1d = separable Gaussian taps (float64, device); pad_mode = PAD_MODES[...] (the padded map
+    is never written: the kernels read the source pixel a padded position copies)."""
 
     @staticmethod
-    def forward(ctx, xs, g1d, pad):
+    def forward(ctx, xs, g1d, pad, pad_mode=0):
         B, _, hs, ws = xs.shape
         grid = torch.empty(B, hs, ws, 2, device=xs.device, dtype=torch.float32)
-        _launch("fe_gauss_grid_fwd", 4.0 * B * hs * ws * 3, "fs_gauss_grid_fwd", hip.ptr(xs), hip.ptr(g1d), hip.ptr(grid), B, hs, ws, pad)
+        if pad_mode == 0:
+            _launch("fe_gauss_grid_fwd", 4.0 * B * hs * ws * 3, "fs_gauss_grid_fwd", hip.ptr(xs), hip.ptr(g1d), hip.ptr(grid), B, hs, ws, pad)
+        else:
+            _launch("fe_gauss_grid_fwd", 4.0 * B * hs * ws * 3, "fs_gauss_grid_fwd_mode", hip.ptr(xs), hip.ptr(g1d), hip.ptr(grid), B, hs, ws, pad,
+                    pad_mode)
         ctx.save_for_backward(xs, g1d)
-        ctx.pad = pad
+        ctx.pad, ctx.pad_mode = pad, pad_mode
         return grid
 
     @staticmethod
@@ -1341,9 +1349,13 @@ class GaussGrid(Function):
         B, _, hs, ws = xs.shape
         dxs = torch.empty_like(xs)
         scratch = torch.empty(hip.query("fs_gauss_grid_bwd_scratch_floats", B, hs, ws), device=xs.device, dtype=torch.float32)
-        _launch("fe_gauss_grid_bwd", 4.0 * B * hs * ws * 4, "fs_gauss_grid_bwd", hip.ptr(xs), hip.ptr(g1d), hip.ptr(dgrid.contiguous()), hip.ptr(dxs), B, hs, ws,
-                ctx.pad, hip.ptr(scratch))
-        return dxs, None, None
+        if ctx.pad_mode == 0:
+            _launch("fe_gauss_grid_bwd", 4.0 * B * hs * ws * 4, "fs_gauss_grid_bwd", hip.ptr(xs), hip.ptr(g1d), hip.ptr(dgrid.contiguous()), hip.ptr(dxs),
+                    B, hs, ws, ctx.pad, hip.ptr(scratch))
+        else:
+            _launch("fe_gauss_grid_bwd", 4.0 * B * hs * ws * 4, "fs_gauss_grid_bwd_mode", hip.ptr(xs), hip.ptr(g1d), hip.ptr(dgrid.contiguous()),
+                    hip.ptr(dxs), B, hs, ws, ctx.pad, ctx.pad_mode, hip.ptr(scratch))
+        return dxs, None, None, None
 
 
 class GridUpsample(Function):

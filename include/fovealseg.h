@@ -67,6 +67,13 @@ int fs_gauss_grid_fwd(const float* xs, const double* g1d, float* grid, int B, in
 long fs_gauss_grid_bwd_scratch_floats(int B, int hs, int ws);
 int fs_gauss_grid_bwd(const float* xs, const double* g1d, const float* dgrid, float* dxs, int B, int hs, int ws, int pad,
                       float* scratch, fs_stream_t stream);
+/* The same pair under the other two settings of TRAIN.def_saliency_pad_mode (models/models.py:819-825): pad_mode 0 = 'replication'
+ * (nn.ReplicationPad2d, what the two entry points above run), 1 = 'reflect' (F.pad(mode='reflect'); FS_ERR_ARG when pad > side - 1, which
+ * torch refuses too), 2 = 'zero' (F.pad(mode='constant')).  The padded map is never materialised in any mode. */
+int fs_gauss_grid_fwd_mode(const float* xs, const double* g1d, float* grid, int B, int hs, int ws, int pad, int pad_mode,
+                           fs_stream_t stream);
+int fs_gauss_grid_bwd_mode(const float* xs, const double* g1d, const float* dgrid, float* dxs, int B, int hs, int ws, int pad,
+                           int pad_mode, float* scratch, fs_stream_t stream);
 /* nn.Upsample(size=(H,W), mode='bilinear') of the deformation grid, align_corners=False: grid (B,h,w,2) -> out (B,H,W,2); the
  * task network may run at a higher resolution than the saliency map (TRAIN.task_input_size != saliency_input_size).
  * The backward needs integer factors H/h, W/w.  models/models.py:621-631. */

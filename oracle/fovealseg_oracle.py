@@ -407,12 +407,21 @@ def create_grid(xs_hm: torch.Tensor, filt: torch.Tensor, P: torch.Tensor, hs: in
     return torch.cat((gx, gy), 1).permute(0, 2, 3, 1)
 
 
-def create_grid_f64(xs: torch.Tensor, radius: int) -> torch.Tensor:
+# TRAIN.def_saliency_pad_mode -> F.pad mode (models/models.py:819-825: nn.ReplicationPad2d / F.pad 'reflect' / F.pad 'constant')
+PAD_MODES = {"replication": "replicate", "reflect": "reflect", "zero": "constant"}
+
+
+def pad_saliency(xs: torch.Tensor, radius: int, pad_mode: str = "replication") -> torch.Tensor:
+    """models/models.py:819-825 with padding_size_x == padding_size_y == radius (gaussian_ap 0.0 on a square saliency map, :496-500)."""
+    return F.pad(xs, (radius,) * 4, mode=PAD_MODES[pad_mode])
+
+
+def create_grid_f64(xs: torch.Tensor, radius: int, pad_mode: str = "replication") -> torch.Tensor:
     """fp64 evaluation of the same formula with the separable Gaussian (accuracy yardstick;
     SURVEY.md §7: the reference's own fp32 result is ~1.75e-5 away from this)."""
     B, _, hs, ws = xs.shape
     g = torch.from_numpy(gaussian_1d(2 * radius + 1, radius))
-    x = F.pad(xs.double(), (radius,) * 4, mode="replicate")[:, 0]
+    x = pad_saliency(xs.double(), radius, pad_mode)[:, 0]
     ci = (torch.arange(ws + 2 * radius, dtype=torch.float64) - radius) / (ws - 1.0)
     ri = (torch.arange(hs + 2 * radius, dtype=torch.float64) - radius) / (hs - 1.0)
 
@@ -506,11 +515,13 @@ def accuracies(pred: torch.Tensor, gt: torch.Tensor, bg: int = 50):
 # --------------------------------------------------------------------------------------------
 class OracleDeformSeg(nn.Module):
     """models/models.py:476-1094 under the effective LVIS-50 configuration:
-    joint loss on, loss at low resolution, no upsample, replication pad, learned sampling."""
+    joint loss on, loss at low resolution, no upsample, replication pad, learned sampling.  Two off-default settings are restated
+    too: pad_mode = TRAIN.def_saliency_pad_mode (:819-825) and uniform = (MODEL.uniform_sample != '') (:816-818)."""
 
-    def __init__(self, hs=80, ws=80, radius=45, num_class=51, fc_dim=960, edge_scale=100.0):
+    def __init__(self, hs=80, ws=80, radius=45, num_class=51, fc_dim=960, edge_scale=100.0, pad_mode="replication", uniform=False):
         super().__init__()
         self.hs, self.ws, self.radius, self.edge_scale = hs, ws, radius, edge_scale
+        self.pad_mode, self.uniform = pad_mode, uniform
         self.localization = OracleFovSim()
         self.net_compress = OracleCompress()
         self.encoder = OracleHRNet()
@@ -530,8 +541,9 @@ class OracleDeformSeg(nn.Module):
         return F.softmax(s.view(B, -1), dim=1).view(B, 1, self.hs, self.ws), x_low
 
     def grid_from_saliency(self, xs):
-        r = self.radius
-        xs_hm = F.pad(xs, (r, r, r, r), mode="replicate")          # models.py:821
+        if self.uniform:
+            xs = xs * 0 + 1.0 / (self.hs * self.ws)                     # models.py:818 (the edge loss keeps the learned map, :726)
+        xs_hm = pad_saliency(xs, self.radius, self.pad_mode)           # models.py:819-825
         return create_grid(xs_hm, self.filter.weight, self.P_basis, self.hs, self.ws)
 
     def forward(self, feed: Dict[str, torch.Tensor], is_inference=False, drop_fn: Optional[DropFn] = None,
