@@ -16,6 +16,8 @@ from . import modules as M
 from .ops import ACT_NONE, ACT_RELU
 
 PHASE_DOMAIN = os.environ.get("FS_PHASE_DOMAIN", "1") != "0"      # A/B switch: 0 = every atrous 3x3 re-orders around itself
+# A/B switch: 0 = the block input is read twice and the autograd engine adds the two gradients (one ATen add + bn3's own reduction pass per block)
+BLOCK_FANOUT = os.environ.get("FS_DEEPLAB_FANOUT", "1") != "0"
 
 
 def _bn(c):
@@ -45,8 +47,11 @@ class TVBottleneck(nn.Module):
 
     def forward(self, x, phase=1):
         """phase = d > 1: x is in the phase domain of this block's dilation (modules.conv_bn_act); so is the result."""
-        r = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1], ACT_NONE, phase=phase)
-        o = conv_bn_act(x, self.conv1, self.bn1, ACT_RELU, phase=phase)
+        # conv path + residual through one fan-out, as in the HRNet Bottleneck (modules.Bottleneck): the residual gradient joins conv1's dx in
+        # its bwd-data epilogue, which also forms the BatchNorm-backward sums of the block in front (no ATen add, no reduction pass for that bn3)
+        xa, xr = ops.fan_out(x, 2) if BLOCK_FANOUT else (x, x)
+        r = xr if self.downsample is None else conv_bn_act(xr, self.downsample[0], self.downsample[1], ACT_NONE, phase=phase)
+        o = conv_bn_act(xa, self.conv1, self.bn1, ACT_RELU, phase=phase)
         o = conv_bn_act(o, self.conv2, self.bn2, ACT_RELU, phase=phase)
         return conv_bn_act(o, self.conv3, self.bn3, ACT_RELU, res=r, phase=phase)
 
