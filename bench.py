@@ -23,6 +23,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+T_START = time.perf_counter()      # (main() resets it: wall seconds of the phases go into the line as "wall")
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
@@ -205,6 +206,8 @@ def parse_args():
 
 
 def main():
+    global T_START
+    T_START = time.perf_counter()
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -264,6 +267,10 @@ def main():
 
     results = {}
     comm = {}
+    # wall seconds of each phase of this process (a GPU-busy average over the whole run mixes the timed passes with the CPU
+    # baseline): which seconds the GPU was the one working, and which the host cores
+    phases = {"setup_s": round(time.perf_counter() - T_START, 1)}
+    tp = time.perf_counter()
     for mode in modes:
         fovealseg.hip.set_conv_precision(mode)
         for opt in optimizers:
@@ -314,6 +321,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    phases["gpu_timed_and_kernel_timer_passes_s"] = round(time.perf_counter() - tp, 1)
+    tp = time.perf_counter()
     # forward-only (inference) rate of the same path, SURVEY.md 8(d): eval mode (running statistics, no dropout), no autograd
     fwd_only = None
     if world == 1 and not args.no_forward_only:
@@ -345,6 +354,7 @@ def main():
             h2d = host_fed_rate(T, module, optimizers, cfg, args, dev, modes[0], results[modes[0]]["value"])
         except Exception as exc:
             h2d = {"error": repr(exc)}
+    phases["gpu_forward_only_and_host_fed_s"] = round(time.perf_counter() - tp, 1)
     distributed = {"world_size": world, "backend": dist.get_backend() if dist.is_initialized() else None,
                    "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
                    "gradient_bytes_per_step": int(sum(o.flat.grad.numel() for o in optimizers) * 4), "comm": comm or None,
@@ -354,12 +364,18 @@ def main():
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
+            tp = time.perf_counter()
             try:
                 cpu = cpu_baseline()
             except Exception as exc:
                 cpu = {"error": repr(exc)}
+            phases["cpu_baseline_gpu_idle_s"] = round(time.perf_counter() - tp, 1)
         line, detail = build_lines(args.headline, world, args.steps, args.warmup, args.batch, args.size, results, fwd_only, cpu)
         detail["h2d_included"] = h2d
+        detail["phases"] = phases
+        line["wall"] = {"gpu_s": round(phases["gpu_timed_and_kernel_timer_passes_s"] + phases["gpu_forward_only_and_host_fed_s"], 1),
+                        "cpu_baseline_s": phases.get("cpu_baseline_gpu_idle_s", 0.0), "setup_s": phases["setup_s"]}
+        assert len(json.dumps(line)) < MAX_LINE_BYTES
         detail["distributed"] = distributed
         write_detail(detail)
         print(json.dumps(line), flush=True)          # the LAST thing on stdout, < 2 KB: the driver parses this line
