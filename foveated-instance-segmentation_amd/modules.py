@@ -117,6 +117,7 @@ def _batch_to_space(y, d):
     return y.reshape(B, d, d, h, w, C).permute(0, 3, 1, 4, 2, 5).reshape(B, h * d, w * d, C)
 
 
+C1_STASH = os.environ.get("FS_C1_STASH", "1") != "0"      # A/B switch, read once: 0 = `feat` read twice, the autograd engine adds the two gradients
 PARALLEL_BRANCHES = True
 PARALLEL_FUSE = os.environ.get("FS_PARALLEL_FUSE", "1") != "0"      # fuse rows on the branch streams too (A/B switch, read once)
 STREAM_DEPS = os.environ.get("FS_STREAM_DEPS", "1") != "0"          # modules of a stage chained stream by stream, one join per stage (A/B switch)
@@ -503,9 +504,15 @@ class C1(nn.Module):
         self.cls_net = ResNet(inplanes=fc_dim, num_classes=num_class)
 
     def forward_nhwc(self, feat):
-        x = self.cbr(feat)
+        # `feat` has two readers.  Through one fan-out, with the classification branch's gradient handed to the 3x3 conv's bwd-data epilogue
+        # (ops.StashGrad; the node is created after the mask branch so that its backward runs first): no 1.57 GB + 1.57 GB add pass at B = 64
+        fa, fb = ops.fan_out(feat, 2) if C1_STASH else (feat, feat)
+        x = self.cbr(fa)
         m = ops.MaskHead.apply(x, self.conv_last.weight, self.conv_last.bias)      # (B,H,W)
-        cls = self.cls_net(feat)                                                    # (B,K)
+        fan = getattr(fb, "_fs_fan", None)
+        if fan is not None:
+            fb = ops.StashGrad.apply(fb, fan[0])
+        cls = self.cls_net(fb)                                                      # (B,K)
         return ops.PredAssemble.apply(cls, m)                                       # (B,K,H,W) NCHW
 
     def forward(self, conv_out, segSize=None, res=None):

@@ -743,6 +743,27 @@ def fan_out(x, n):
     return outs
 
 
+class StashGrad(Function):
+    """Identity on one alias of a two-way fan-out whose OTHER alias feeds a convolution (C1: `feat` -> the 3x3 conv of the mask branch and ->
+    the classification branch).  Backward: the gradient that arrives here is left in PENDING_RES under the fan id and None is returned, so the
+    convolution's bwd-data adds it in its epilogue (one read) instead of FanOut.backward adding two 1.57 GB tensors in a pass of its own
+    (806 us per configs[1] step).  The branch behind this node must run its backward BEFORE the convolution's: put the node in the forward
+    AFTER the convolution branch (the engine runs ready nodes in reverse order of creation); if the convolution's backward came first anyway
+    (FAN_DONE), the gradient is returned as usual and the fan-out adds it."""
+
+    @staticmethod
+    def forward(ctx, x, fan_id):
+        ctx.fan_id = fan_id
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None or ctx.fan_id in FAN_DONE or ctx.fan_id in PENDING_RES or not (FUSE_BN_BWD_SUMS and FANOUT):
+            return g, None
+        PENDING_RES[ctx.fan_id] = (g if g.is_contiguous() else g.contiguous(), None)
+        return None, None
+
+
 FANOUT_SUBSAMPLE = os.environ.get("FS_FANOUT_SUBSAMPLE", "1") != "0"
 
 

@@ -1178,6 +1178,51 @@ def test_g9_c1(golden, hipmod, oracle, mode, prec):
     _restore(oracle)
 
 
+def test_c1_classification_gradient_joins_the_mask_branch_epilogue(hipmod):
+    """C1 reads `feat` twice.  The classification branch's gradient is handed (ops.StashGrad) to the bwd-data epilogue of the mask branch's
+    3x3 conv instead of being added by a pass of its own: same dfeat and parameter gradients as with the two readers left to autograd, the
+    fused launch really carries the addend, nothing is left stashed."""
+    from fovealseg import modules as Mods
+    _restore(hipmod)
+    dec = hipmod.decoder
+    dec.train(True)
+    gg = torch.Generator().manual_seed(99)
+    f9 = torch.randn(2, 960, 80, 80, generator=gg) * 0.5
+    cot = None
+    got = {}
+    keep = Mods.C1_STASH
+    real = fovealseg.hip.call
+    try:
+        for stash in (True, False):
+            Mods.C1_STASH = stash
+            ops.reset_step_state()
+            addends = []
+
+            def spy(name, *args, _real=real, _a=addends):
+                if name == "fs_conv2d_bwd_data_bnsum" and args[-2] not in (None, 0):
+                    _a.append(name)
+                return _real(name, *args)
+            fovealseg.hip.call = ops.hip.call = spy
+            fd = f9.to(DEV).requires_grad_(True)
+            pred = dec([fd])
+            if cot is None:
+                cot = (torch.randn(pred.shape, generator=gg) * 0.01).to(DEV)
+            dec.zero_grad()
+            pred.backward(cot)
+            fovealseg.hip.call = ops.hip.call = real
+            assert not ops.PENDING_RES
+            assert (len(addends) == 1) == stash, (stash, addends)
+            got[stash] = (fd.grad.cpu().clone(), {k: q.grad.detach().cpu().clone() for k, q in dec.named_parameters()})
+    finally:
+        fovealseg.hip.call = ops.hip.call = real
+        Mods.C1_STASH = keep
+    assert relerr(got[True][0], got[False][0]) <= 1e-6
+    for k, v in got[False][1].items():
+        # (weight gradients are split-K atomic sums: equal up to the order of the adds)
+        assert relerr(got[True][1][k], v) <= 1e-5 or float(v.abs().max()) == 0.0, k
+    _restore(hipmod)
+
+
 class _InjectValue(torch.autograd.Function):
     """forward: the injected value; backward: gradient flows to the computed tensor."""
 
