@@ -443,3 +443,54 @@ def test_flat_adam_refuses_gradients_outside_its_arena():
     opt.check_grads_in_arena()
     assert all(torch.equal(p.grad, w) for p, w in zip(net.parameters(), want))
     assert float(opt.flat.grad.abs().sum()) > 0
+
+
+def test_stash_grad_hands_the_second_reader_gradient_to_the_conv_consumer():
+    """ops.StashGrad (C1: `feat` read by the mask branch's conv and by the classification branch) on CPU tensors, with a stand-in for the conv
+    consumer that does what ConvBnAct.backward does with the fan-out's records: (a) stash node created AFTER the conv branch in the forward ->
+    the engine runs it first, the conv consumer finds the gradient in PENDING_RES and the fan-out adds nothing; (b) created BEFORE it -> the
+    conv consumer runs first (FAN_DONE), the gradient is returned as usual and the fan-out adds it.  Same result both ways."""
+    import fovealseg  # noqa: F401
+    from fovealseg import ops
+
+    log = []
+
+    class ConvStandIn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, k):
+            ctx.fan = getattr(x, "_fs_fan", None)
+            ctx.k = k
+            return x * k
+
+        @staticmethod
+        def backward(ctx, g):
+            pend = ops.PENDING_RES.pop(ctx.fan[0], None)
+            ops.FAN_DONE.add(ctx.fan[0])
+            log.append("conv+addend" if pend is not None else "conv")
+            dx = g * ctx.k
+            return (dx + pend[0] if pend is not None else dx), None
+
+    def run(stash_after_conv):
+        ops.reset_step_state()
+        log.clear()
+        x = torch.arange(8, dtype=torch.float32).view(2, 4).requires_grad_(True)
+        h = x * 1.0                                    # a non-leaf, like the encoder's output
+        fa, fb = ops.fan_out(h, 2)
+        fan = fa._fs_fan
+        if not stash_after_conv:
+            fb = ops.StashGrad.apply(fb, fan[0])
+        y1 = ConvStandIn.apply(fa, 3.0)
+        if stash_after_conv:
+            fb = ops.StashGrad.apply(fb, fan[0])
+        y2 = (fb * fb).sum()
+        (y1.sum() + y2).backward()
+        assert not ops.PENDING_RES
+        return x.grad.clone()
+
+    want = 3.0 + 2.0 * torch.arange(8, dtype=torch.float32).view(2, 4)
+    ga = run(True)
+    assert log == ["conv+addend"], log
+    gb = run(False)
+    assert log == ["conv"], log
+    assert torch.equal(ga, want) and torch.equal(gb, want)
+    ops.reset_step_state()
