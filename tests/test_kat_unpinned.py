@@ -120,6 +120,29 @@ def test_deeplab_oracle_known_answers_unpinned():
     assert tuple(feat.shape) == (1, 2048, 10, 10)
 
 
+def test_deeplab_size_note_of_the_reference_unpinned():
+    """The one datum the reference itself holds about its DeepLab encoder: the note its author left behind a (commented-out) thop profile of
+    `CustomDeepLab` -- `Params: {params / 1e6:.4f} M` ... `#resnet101 11G 58M` (models/deeplab.py:436-439).  torchvision 0.19.1's
+    deeplabv3_resnet101 with the reference's three replacements (models/deeplab.py:11-49) adds up to 58 660 352 parameters from its published
+    layer shapes: ResNet-101 without the fc 42 500 160; ASPP(2048, (12, 24, 36)) 15 535 104; classifier[1] Conv1x1(256, 512) + BN(512) and
+    classifier[4] Conv1x1(512, 960), both with bias, 625 088.  A weak pin (a count, not arithmetic) -- the encoder stays PARITY UNPINNED --
+    but the oracle and the HIP-side module must both land on it, tensor by tensor alike."""
+    from fovealseg import deeplab as D
+    o, m = DO.OracleDeepLab(), D.deeplab()
+    no = sum(p.numel() for p in o.parameters())
+    nm = sum(p.numel() for p in m.parameters())
+    assert no == nm == 58_660_352
+    assert int(nm / 1e6) == 58                                                 # "58M"
+    parts = {"backbone": 42_500_160, "classifier.0": 15_535_104}
+    for net in (o, m):
+        for prefix, want in parts.items():
+            got = sum(p.numel() for k, p in net.named_parameters() if k.startswith("deeplab." + prefix + "."))
+            assert got == want, (prefix, got, want)
+    shapes_o = {k: tuple(p.shape) for k, p in o.named_parameters()}
+    shapes_m = {k: tuple(p.shape) for k, p in m.named_parameters()}
+    assert shapes_o == shapes_m
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # GPU: the HIP modules against the same closed forms
 # ---------------------------------------------------------------------------------------------------------------
